@@ -1,0 +1,152 @@
+/* tenpy_amd.h -- C-ABI of the MI355X (gfx950) backend for TeNPy's block-sparse hot path.
+ *
+ * Every entry point replaces one native call site of the reference
+ * (tenpy/linalg/_npc_helper.pyx, tenpy/linalg/np_conserved.py; cited per function).
+ * Conventions:
+ *   - all pointers named *_dev / *base are DEVICE pointers (HBM); `stream` is a hipStream_t
+ *     passed as void* (NULL = default stream); everything is asynchronous on that stream
+ *     unless the doc says "synchronises".
+ *   - dtype: TPA_F64 (real double) or TPA_C128 (interleaved complex double) -- the only two
+ *     calculation dtypes of the reference (_npc_helper.pyx:410-424 `_find_calc_dtype`).
+ *   - block data: an Array's blocks are packed back to back in ONE device arena; a block is
+ *     addressed as (arena base, element offset).  Offsets / sizes are in ELEMENTS of dtype.
+ *   - return value: 0 = ok, >0 = hipError_t of the failing runtime call,
+ *     <0 = TPA_E_* argument/algorithm error (mapped to ValueError / RuntimeError /
+ *     LinAlgError by the Python shim, SURVEY 8(b) "Errors").
+ */
+#ifndef TENPY_AMD_H
+#define TENPY_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPA_F64 0
+#define TPA_C128 1
+
+#define TPA_E_BADARG (-1)      /* -> ValueError  */
+#define TPA_E_NOCONV (-2)      /* -> numpy.linalg.LinAlgError (Jacobi sweeps exhausted)  */
+#define TPA_E_NAN (-3)         /* -> ValueError("NaN ...") like np_conserved.py:4978-4982 */
+#define TPA_E_NOMEM (-4)
+
+/* ---- library / device --------------------------------------------------------------- */
+int tpa_version(void);
+/* Fills name (<=255 chars), number of CUs, HBM bytes of the current device. */
+int tpa_device_info(char *name, int name_len, int *n_cu, int64_t *hbm_bytes);
+const char *tpa_last_error(void);
+
+/* ---- K1: grouped, chained GEMM  (replaces CblasGemmBatch.run, _npc_helper.pyx:204-273;
+ *          python twin `fast_dot_sum`, np_conserved.py:4807-4837) ----------------------
+ * The reference queues (A,B,C,m,k,n) per accumulation *level* and runs level 0 with beta=0
+ * and later levels with beta=1.  Here the levels of one C block form a *chain* that is
+ * accumulated in MFMA registers (no beta=1 re-read of C):
+ *        C_t (m x n, row stride ldc)  =  [C_t +]  sum_{l in chain(t)} A_l (m x k_l) * B_l (k_l x n)
+ * links  : int64[n_links][8]  = {a_off, b_off, k, a_rs, a_ks, b_ks, b_ns, flags}
+ *          A_l(i,kk) = Abase[a_off + i*a_rs + kk*a_ks], B_l(kk,j) = Bbase[b_off + kk*b_ks + j*b_ns]
+ *          (one of a_rs/a_ks and one of b_ks/b_ns should be 1 for coalescing; any strides are legal)
+ *          flags bit0: conj(A), bit1: conj(B)   (complex only)
+ * tasks  : int64[n_tasks][8]  = {c_off, m, n, ldc, link_begin, link_count, accumulate, 0}
+ * tiles  : int32[n_tiles][4]  = {task, tile_row, tile_col, 0}   (tile = TPA_GEMM_BM x TPA_GEMM_BN)
+ * All three tables live on the DEVICE (uploaded once per cached contraction plan).
+ */
+#define TPA_GEMM_BM 128
+#define TPA_GEMM_BN 128
+int tpa_gemm_chain(int dtype, const int64_t *tasks_dev, const int64_t *links_dev,
+                   const int32_t *tiles_dev, int n_tiles, const void *Abase, const void *Bbase,
+                   void *Cbase, void *stream);
+
+/* ---- K2-K4: vector kernels over packed arenas (replace ddot/zdotc/zdotu
+ *      _npc_helper.pyx:1854-1871, daxpy/zaxpy :316-336, dscal/zscal :339-364,
+ *      np.linalg.norm per block np_conserved.py:2252-2255) ------------------------------
+ * `n` counts elements of dtype.  Scalars alpha are passed as (re, im); im ignored for F64.
+ * Reductions are deterministic two-pass (per-workgroup partials, then one workgroup);
+ * `scratch_dev` must hold >= TPA_RED_SCRATCH doubles; the result (2 doubles: re, im) is
+ * written to out_dev[0..1] on the stream (no host sync).
+ */
+#define TPA_RED_SCRATCH 4096
+int tpa_axpy(int dtype, int64_t n, double alpha_re, double alpha_im, const void *x_dev,
+             void *y_dev, void *stream);
+int tpa_scal(int dtype, int64_t n, double alpha_re, double alpha_im, void *x_dev, void *stream);
+/* out = sum conj?(x_i) * y_i ;  do_conj as in _inner_worker(a, b, do_conj) */
+int tpa_dot(int dtype, int64_t n, const void *x_dev, const void *y_dev, int do_conj,
+            double *out_dev, double *scratch_dev, void *stream);
+/* out[0] = sum |x_i|^2  (2-norm squared; host takes the sqrt) */
+int tpa_nrm2sq(int dtype, int64_t n, const void *x_dev, double *out_dev, double *scratch_dev,
+               void *stream);
+/* Fused Lanczos recurrence step (krylov_based.py:660-672):
+ *   w -= alpha * v1 ; w -= beta * v0 (v0 may be NULL) ; out[0] = sum |w_i|^2           */
+int tpa_lanczos_update(int dtype, int64_t n, void *w_dev, double alpha_re, double alpha_im,
+                       const void *v1_dev, double beta_re, double beta_im, const void *v0_dev,
+                       double *out_dev, double *scratch_dev, void *stream);
+
+/* ---- K8/K9/K10: data movement ---------------------------------------------------------
+ * Generic strided N-d block copy (N <= TPA_COPY_MAXDIM), batched.  Replaces
+ * _sliced_strided_copy/_sliced_copy (_npc_helper.pyx:368, :754; combine/split legs :1112-1123,
+ * :1235-1240) and the per-block PyArray_Transpose+copy of itranspose (:853).
+ * jobs : int64[n_jobs][4 + 3*TPA_COPY_MAXDIM] =
+ *        {dst_off, src_off, ndim, flags, shape[MAXDIM], dst_stride[MAXDIM], src_stride[MAXDIM]}
+ *        flags bit0: conjugate while copying (complex only).
+ * The last dim is the fastest-varying loop index; strides in elements.
+ */
+#define TPA_COPY_MAXDIM 6
+int tpa_copy_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
+                   const void *src_base, void *dst_base, void *stream);
+/* x_b[i, j, l] *= s[s_off_b + j]  for each block b viewed as (pre, len, post).  Replaces
+ * iscale_axis, np_conserved.py:2132-2140.  jobs: int64[n][6] = {x_off, pre, len, post, s_off, 0};
+ * the scale vector s is real (F64) or of `dtype` when s_is_complex. */
+int tpa_scale_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
+                         void *x_base, const void *s_dev, int s_is_complex, void *stream);
+int tpa_fill_zero(void *dst_dev, int64_t n_bytes, void *stream);
+
+/* ---- K5: batched block SVD, one-sided (Hestenes) Jacobi -- replaces svd_flat / LAPACK gesdd
+ *      per charge block (np_conserved.py:4970-4980 via svd_robust.py:36-75) ---------------
+ * jobs : int64[n_jobs][8] = {a_off, m, n, u_off, s_off, vh_off, 0, 0}  (HOST pointer)
+ *   A_b is m x n row-major at a_off in a_base; on return
+ *   U_b (m x k, row-major, k=min(m,n)) at u_off in u_base, S_b (k, descending) at s_off in s_dev
+ *   (always real), VH_b (k x n, row-major) at vh_off in vh_base.  A is NOT overwritten.
+ * work_dev: >= tpa_svd_worksize(...) bytes.  Synchronises the stream (sweep-convergence test).
+ * Returns TPA_E_NOCONV if max_sweeps is exhausted, TPA_E_NAN if the input holds NaN/Inf.
+ */
+int64_t tpa_svd_worksize(int dtype, const int64_t *jobs_host, int n_jobs);
+int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base,
+                  void *u_base, double *s_dev, void *vh_base, void *work_dev, int64_t work_bytes,
+                  int max_sweeps, double tol, int *sweeps_done, void *stream);
+
+/* ---- K6: batched Householder QR (np.linalg.qr per block, np_conserved.py:4190) ----------
+ * jobs : int64[n_jobs][8] = {a_off, m, n, q_off, r_off, 0,0,0} (HOST); reduced mode:
+ *   Q_b m x k row-major, R_b k x n row-major, k = min(m,n).  A not overwritten. */
+int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base,
+                 void *r_base, void *stream);
+
+/* ---- K7: batched Hermitian eigendecomposition, cyclic Jacobi (np.linalg.eigh per block,
+ *      np_conserved.py:5059-5061) ----------------------------------------------------------
+ * jobs : int64[n_jobs][8] = {a_off, n, w_off, v_off, 0,0,0,0} (HOST);  A_b n x n Hermitian row-major,
+ *   eigenvalues ascending at w_off in w_dev, eigenvectors as COLUMNS of V_b (n x n row-major).
+ * work_dev >= tpa_eigh_worksize bytes. Synchronises the stream. */
+int64_t tpa_eigh_worksize(int dtype, const int64_t *jobs_host, int n_jobs);
+int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base,
+                   double *w_dev, void *v_base, void *work_dev, int64_t work_bytes, int max_sweeps,
+                   double tol, int *sweeps_done, void *stream);
+
+/* ---- host planner: integer bookkeeping of _tensordot_worker (_npc_helper.pyx:1498-1786) ---
+ * Inputs describe operand a with its contracted legs LAST and b with its contracted legs FIRST
+ * (i.e. after _tensordot_transpose_axes, :1260-1295), block lists in any order.
+ *   a_qdata : int64[na][ra]  qindices,  a_keep = ra - ncontr ;  likewise b.
+ *   *_block_size: for each leg, `nblk` block sizes are looked up through leg_sizes/leg_ptr:
+ *       size of qindex q on leg L of a = a_leg_sizes[a_leg_ptr[L] + q].
+ * Outputs (caller-allocated, capacities given; counts returned through n_*):
+ *   res_qdata   : int64[n_res][a_keep + b_keep]   lex-sorted like the reference (:1777)
+ *   res_a_first, res_b_first: representative a / b block of each result block
+ *   gemm        : int64[n_gemm][3] = {res_index, a_block, b_block}  ordered by (res_index, level)
+ * Returns 0, or TPA_E_BADARG if a capacity is too small (n_* then hold the needed sizes).
+ */
+int tpa_plan_tensordot(const int64_t *a_qdata, int64_t na, int ra, const int64_t *b_qdata,
+                       int64_t nb, int rb, int ncontr, const int64_t *contr_nblocks,
+                       int64_t *res_qdata, int64_t *res_a_first, int64_t *res_b_first,
+                       int64_t cap_res, int64_t *n_res, int64_t *gemm, int64_t cap_gemm,
+                       int64_t *n_gemm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

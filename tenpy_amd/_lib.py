@@ -1,0 +1,100 @@
+"""ctypes binding of the C-ABI in ``include/tenpy_amd.h`` (the drop-in boundary).
+
+There is NO CPU fallback: if the shared library is missing or no MI355X is visible, every compute
+entry point raises.  ``torch`` is imported first so that the process-wide HIP runtime
+(``libamdhip64.so.7``) is the one torch already loaded; torch is used only for device memory and
+streams.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+F64, C128 = 0, 1
+E_BADARG, E_NOCONV, E_NAN, E_NOMEM = -1, -2, -3, -4
+
+_lib = None
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+_SIGS = {
+    "tpa_version": (ctypes.c_int, []),
+    "tpa_last_error": (ctypes.c_char_p, []),
+    "tpa_device_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _i64p]),
+    "tpa_gemm_tile_shape": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "tpa_gemm_chain": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "tpa_axpy": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp]),
+    "tpa_scal": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _vp, _vp]),
+    "tpa_dot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "tpa_nrm2sq": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    "tpa_lanczos_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_double, ctypes.c_double, _vp,
+                                          ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    "tpa_copy_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]),
+    "tpa_scale_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp]),
+    "tpa_gather_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    "tpa_fill_zero": (ctypes.c_int, [_vp, ctypes.c_int64, _vp]),
+    "tpa_svd_worksize": (ctypes.c_int64, [ctypes.c_int, _vp, ctypes.c_int]),
+    "tpa_svd_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64,
+                                     ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp]),
+    "tpa_qr_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "tpa_eigh_worksize": (ctypes.c_int64, [ctypes.c_int, _vp, ctypes.c_int]),
+    "tpa_eigh_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int64,
+                                      ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp]),
+    "tpa_plan_tensordot": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int64, _i64p, _vp,
+                                          ctypes.c_int64, _i64p]),
+}
+
+
+class BackendError(RuntimeError):
+    """The HIP extension is missing or a HIP runtime call failed."""
+
+
+def load(build_if_missing=True):
+    """Load ``libtenpy_amd.so`` (building it in-tree if needed) and declare all signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads libamdhip64.so.7 first; device memory + streams come from torch)
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise BackendError("tenpy_amd: %s not built; run `python -m tenpy_amd._build`" % path)
+        _build.build()
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        f = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc, what=""):
+    """Map a C-ABI status to the reference's exception types (SURVEY 8(b) 'Errors')."""
+    if rc == 0:
+        return
+    msg = load().tpa_last_error()
+    msg = msg.decode() if msg else ""
+    if rc == E_BADARG:
+        raise ValueError("tenpy_amd %s: %s" % (what, msg))
+    if rc == E_NOCONV:
+        raise np.linalg.LinAlgError("tenpy_amd %s: %s" % (what, msg))
+    if rc == E_NAN:
+        raise ValueError("tenpy_amd %s: NaN/Inf encountered: %s" % (what, msg))
+    raise BackendError("tenpy_amd %s: HIP error %d: %s" % (what, rc, msg))
+
+
+def require_gpu():
+    """Raise loudly unless an AMD GPU is usable (no CPU fallback exists)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise BackendError("tenpy_amd: no GPU visible (torch.cuda.is_available() is False); "
+                           "this backend has no CPU fallback")
+    load()

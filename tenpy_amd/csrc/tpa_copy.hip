@@ -1,0 +1,159 @@
+// K8/K9/K10: data-movement kernels (HBM-bound), gfx950.
+//
+//  * tpa_copy_batch      : batched N-d strided sub-block copy.  One job = one (old block -> slice of
+//                          new block) memcpy of the reference's combine/split workers
+//                          (_npc_helper.pyx:1112-1123, :1235-1240 via _sliced_strided_copy :368) or one
+//                          per-block transpose of itranspose (:853).  The host builds the copy plan
+//                          from the integer bookkeeping; the device only moves bytes.
+//  * tpa_scale_axis_batch: iscale_axis (np_conserved.py:2132-2140).
+//  * tpa_gather_axis_batch: iproject's np.compress along one axis (np_conserved.py:1982).
+#include "tpa_common.h"
+
+namespace {
+constexpr int NT = 256;
+constexpr int MAXD = TPA_COPY_MAXDIM;
+
+struct CopyJob {  // int64[4 + 3*MAXD]
+    int64_t dst_off, src_off, ndim, flags;
+    int64_t shape[MAXD], dstr[MAXD], sstr[MAXD];
+};
+
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void copy_batch_kernel(const CopyJob *__restrict__ jobs,
+                                                        const double *__restrict__ src,
+                                                        double *__restrict__ dst) {
+    const CopyJob &J = jobs[blockIdx.y];
+    const int nd = (int)J.ndim;
+    int64_t total = 1;
+    for (int d = 0; d < nd; ++d) total *= J.shape[d];
+    const bool conj = CPLX && (J.flags & 1);
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        int64_t rem = e, so = J.src_off, dof = J.dst_off;
+        for (int d = nd - 1; d >= 0; --d) {
+            const int64_t s = J.shape[d];
+            const int64_t q = rem / s;
+            const int64_t i = rem - q * s;
+            rem = q;
+            so += i * J.sstr[d];
+            dof += i * J.dstr[d];
+        }
+        if (CPLX) {
+            double2 v = reinterpret_cast<const double2 *>(src)[so];
+            if (conj) v.y = -v.y;
+            reinterpret_cast<double2 *>(dst)[dof] = v;
+        } else {
+            dst[dof] = src[so];
+        }
+    }
+}
+
+struct ScaleJob {  // int64[6]
+    int64_t x_off, pre, len, post, s_off, pad;
+};
+
+template <bool CPLX, bool SCPLX>
+__global__ __launch_bounds__(NT) void scale_axis_kernel(const ScaleJob *__restrict__ jobs,
+                                                        double *__restrict__ x,
+                                                        const double *__restrict__ s) {
+    const ScaleJob J = jobs[blockIdx.y];
+    const int64_t total = J.pre * J.len * J.post;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int64_t j = (e / J.post) % J.len;
+        if (!CPLX) {
+            x[J.x_off + e] *= s[J.s_off + j];
+        } else {
+            double2 v = reinterpret_cast<double2 *>(x)[J.x_off + e];
+            if (SCPLX) {
+                const double2 f = reinterpret_cast<const double2 *>(s)[J.s_off + j];
+                v = double2{v.x * f.x - v.y * f.y, v.x * f.y + v.y * f.x};
+            } else {
+                const double f = s[J.s_off + j];
+                v.x *= f;
+                v.y *= f;
+            }
+            reinterpret_cast<double2 *>(x)[J.x_off + e] = v;
+        }
+    }
+}
+
+struct GatherJob {  // int64[8]
+    int64_t dst_off, src_off, pre, len_src, len_dst, post, idx_off, pad;
+};
+
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void gather_axis_kernel(const GatherJob *__restrict__ jobs,
+                                                         const int64_t *__restrict__ idx,
+                                                         const double *__restrict__ src,
+                                                         double *__restrict__ dst) {
+    const GatherJob J = jobs[blockIdx.y];
+    const int64_t total = J.pre * J.len_dst * J.post;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int64_t l = e % J.post;
+        const int64_t t = e / J.post;
+        const int64_t j = t % J.len_dst;
+        const int64_t i = t / J.len_dst;
+        const int64_t so = J.src_off + (i * J.len_src + idx[J.idx_off + j]) * J.post + l;
+        if (CPLX)
+            reinterpret_cast<double2 *>(dst)[J.dst_off + e] = reinterpret_cast<const double2 *>(src)[so];
+        else
+            dst[J.dst_off + e] = src[so];
+    }
+}
+
+inline int grid_x(int64_t max_elems) {
+    int64_t g = (max_elems + NT * 4 - 1) / (NT * 4);
+    if (g < 1) g = 1;
+    if (g > 512) g = 512;
+    return (int)g;
+}
+}  // namespace
+
+extern "C" int tpa_copy_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
+                              const void *src_base, void *dst_base, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n_jobs <= 0) return 0;
+    TPA_ARG_CHECK(n_jobs <= 65535);
+    dim3 grid(grid_x(max_job_elems), n_jobs);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TPA_F64)
+        copy_batch_kernel<false><<<grid, NT, 0, st>>>((const CopyJob *)jobs_dev, (const double *)src_base, (double *)dst_base);
+    else
+        copy_batch_kernel<true><<<grid, NT, 0, st>>>((const CopyJob *)jobs_dev, (const double *)src_base, (double *)dst_base);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_scale_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs,
+                                    int64_t max_job_elems, void *x_base, const void *s_dev,
+                                    int s_is_complex, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    TPA_ARG_CHECK(!(dtype == TPA_F64 && s_is_complex));
+    if (n_jobs <= 0) return 0;
+    TPA_ARG_CHECK(n_jobs <= 65535);
+    dim3 grid(grid_x(max_job_elems), n_jobs);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TPA_F64)
+        scale_axis_kernel<false, false><<<grid, NT, 0, st>>>((const ScaleJob *)jobs_dev, (double *)x_base, (const double *)s_dev);
+    else if (s_is_complex)
+        scale_axis_kernel<true, true><<<grid, NT, 0, st>>>((const ScaleJob *)jobs_dev, (double *)x_base, (const double *)s_dev);
+    else
+        scale_axis_kernel<true, false><<<grid, NT, 0, st>>>((const ScaleJob *)jobs_dev, (double *)x_base, (const double *)s_dev);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_gather_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs,
+                                     int64_t max_job_elems, const int64_t *idx_dev,
+                                     const void *src_base, void *dst_base, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n_jobs <= 0) return 0;
+    TPA_ARG_CHECK(n_jobs <= 65535);
+    dim3 grid(grid_x(max_job_elems), n_jobs);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TPA_F64)
+        gather_axis_kernel<false><<<grid, NT, 0, st>>>((const GatherJob *)jobs_dev, idx_dev, (const double *)src_base, (double *)dst_base);
+    else
+        gather_axis_kernel<true><<<grid, NT, 0, st>>>((const GatherJob *)jobs_dev, idx_dev, (const double *)src_base, (double *)dst_base);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}

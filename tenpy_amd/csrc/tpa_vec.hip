@@ -1,0 +1,224 @@
+// K2-K4: vector kernels over packed block arenas (HBM-bound), gfx950.
+//
+// An Array's blocks are packed back to back in one arena, so when two Arrays share the same block
+// structure (always true inside a Lanczos run) the block-wise BLAS-1 loops of the reference
+// (_inner_worker _npc_helper.pyx:1791-1875, _blas_inpl_add :316, _blas_inpl_scale :339,
+// Array.norm np_conserved.py:2241-2255) collapse to ONE flat pass over the arena.
+// Reductions are deterministic: pass 1 writes one partial per workgroup, pass 2 (one workgroup)
+// sums them in a fixed order.
+#include "tpa_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXBLK = 1024;  // partials per reduction (<= TPA_RED_SCRATCH / 2)
+
+__host__ inline int grid_for(int64_t n, int per_thread) {
+    int64_t g = (n + (int64_t)NT * per_thread - 1) / ((int64_t)NT * per_thread);
+    if (g < 1) g = 1;
+    if (g > MAXBLK) g = MAXBLK;
+    return (int)g;
+}
+
+// ---- y += alpha x ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void axpy_f64(int64_t n, double a, const double *__restrict__ x,
+                                               double *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        y[i] = fma(a, x[i], y[i]);
+}
+__global__ __launch_bounds__(NT) void axpy_c128(int64_t n, double ar, double ai,
+                                                const double2 *__restrict__ x,
+                                                double2 *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        double2 xv = x[i], yv = y[i];
+        yv.x += ar * xv.x - ai * xv.y;
+        yv.y += ar * xv.y + ai * xv.x;
+        y[i] = yv;
+    }
+}
+__global__ __launch_bounds__(NT) void scal_f64(int64_t n, double a, double *__restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        x[i] *= a;
+}
+__global__ __launch_bounds__(NT) void scal_c128(int64_t n, double ar, double ai,
+                                                double2 *__restrict__ x) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        double2 v = x[i];
+        x[i] = double2{ar * v.x - ai * v.y, ar * v.y + ai * v.x};
+    }
+}
+
+// ---- reductions -------------------------------------------------------------------------------
+// mode 0: dot(x,y) real; 1: sum conj(x) y (complex); 2: sum x y (complex, no conj); 3: sum |x|^2
+template <int MODE>
+__global__ __launch_bounds__(NT) void reduce_pass1(int64_t n, const double *__restrict__ x,
+                                                   const double *__restrict__ y,
+                                                   double *__restrict__ partial) {
+    __shared__ double red[NT / 64];
+    double sr = 0, si = 0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        if (MODE == 0) {
+            sr = fma(x[i], y[i], sr);
+        } else if (MODE == 3) {
+            sr = fma(x[i], x[i], sr);
+        } else {
+            const double2 a = reinterpret_cast<const double2 *>(x)[i];
+            const double2 b = reinterpret_cast<const double2 *>(y)[i];
+            if (MODE == 1) {  // conj(a) * b
+                sr += a.x * b.x + a.y * b.y;
+                si += a.x * b.y - a.y * b.x;
+            } else {
+                sr += a.x * b.x - a.y * b.y;
+                si += a.x * b.y + a.y * b.x;
+            }
+        }
+    }
+    sr = block_sum<NT>(sr, red);
+    if (MODE == 1 || MODE == 2) si = block_sum<NT>(si, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sr;
+        partial[2 * blockIdx.x + 1] = si;
+    }
+}
+
+__global__ __launch_bounds__(NT) void reduce_pass2(int nblk, const double *__restrict__ partial,
+                                                   double *__restrict__ out) {
+    __shared__ double red[NT / 64];
+    double sr = 0, si = 0;
+    for (int i = threadIdx.x; i < nblk; i += NT) {
+        sr += partial[2 * i];
+        si += partial[2 * i + 1];
+    }
+    sr = block_sum<NT>(sr, red);
+    si = block_sum<NT>(si, red);
+    if (threadIdx.x == 0) {
+        out[0] = sr;
+        out[1] = si;
+    }
+}
+
+// ---- fused Lanczos three-term recurrence: w -= a v1 ; w -= b v0 ; partial |w|^2 ----------------
+template <bool CPLX, bool HAVE_V0>
+__global__ __launch_bounds__(NT) void lanczos_update_kernel(int64_t n, double *__restrict__ w,
+                                                            double ar, double ai,
+                                                            const double *__restrict__ v1, double br,
+                                                            double bi, const double *__restrict__ v0,
+                                                            double *__restrict__ partial) {
+    __shared__ double red[NT / 64];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        if (!CPLX) {
+            double t = w[i];
+            t = fma(-ar, v1[i], t);
+            if (HAVE_V0) t = fma(-br, v0[i], t);
+            w[i] = t;
+            s = fma(t, t, s);
+        } else {
+            double2 t = reinterpret_cast<double2 *>(w)[i];
+            const double2 p = reinterpret_cast<const double2 *>(v1)[i];
+            t.x -= ar * p.x - ai * p.y;
+            t.y -= ar * p.y + ai * p.x;
+            if (HAVE_V0) {
+                const double2 q = reinterpret_cast<const double2 *>(v0)[i];
+                t.x -= br * q.x - bi * q.y;
+                t.y -= br * q.y + bi * q.x;
+            }
+            reinterpret_cast<double2 *>(w)[i] = t;
+            s += t.x * t.x + t.y * t.y;
+        }
+    }
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int tpa_axpy(int dtype, int64_t n, double ar, double ai, const void *x, void *y,
+                        void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = grid_for(n, 4) * 2;
+    if (dtype == TPA_F64)
+        axpy_f64<<<g, NT, 0, st>>>(n, ar, (const double *)x, (double *)y);
+    else
+        axpy_c128<<<g, NT, 0, st>>>(n, ar, ai, (const double2 *)x, (double2 *)y);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_scal(int dtype, int64_t n, double ar, double ai, void *x, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = grid_for(n, 4) * 2;
+    if (dtype == TPA_F64)
+        scal_f64<<<g, NT, 0, st>>>(n, ar, (double *)x);
+    else
+        scal_c128<<<g, NT, 0, st>>>(n, ar, ai, (double2 *)x);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_dot(int dtype, int64_t n, const void *x, const void *y, int do_conj,
+                       double *out, double *scratch, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = (n > 0) ? grid_for(n, 8) : 1;
+    if (dtype == TPA_F64)
+        reduce_pass1<0><<<g, NT, 0, st>>>(n, (const double *)x, (const double *)y, scratch);
+    else if (do_conj)
+        reduce_pass1<1><<<g, NT, 0, st>>>(n, (const double *)x, (const double *)y, scratch);
+    else
+        reduce_pass1<2><<<g, NT, 0, st>>>(n, (const double *)x, (const double *)y, scratch);
+    TPA_LAUNCH_CHECK();
+    reduce_pass2<<<1, NT, 0, st>>>(g, scratch, out);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_nrm2sq(int dtype, int64_t n, const void *x, double *out, double *scratch,
+                          void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nd = (dtype == TPA_C128) ? 2 * n : n;  // |z|^2 = re^2 + im^2: flat real pass
+    const int g = (nd > 0) ? grid_for(nd, 8) : 1;
+    reduce_pass1<3><<<g, NT, 0, st>>>(nd, (const double *)x, (const double *)x, scratch);
+    TPA_LAUNCH_CHECK();
+    reduce_pass2<<<1, NT, 0, st>>>(g, scratch, out);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_lanczos_update(int dtype, int64_t n, void *w, double ar, double ai,
+                                  const void *v1, double br, double bi, const void *v0, double *out,
+                                  double *scratch, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    TPA_ARG_CHECK(v1 != nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = (n > 0) ? grid_for(n, 8) : 1;
+    if (dtype == TPA_F64) {
+        if (v0)
+            lanczos_update_kernel<false, true><<<g, NT, 0, st>>>(n, (double *)w, ar, ai, (const double *)v1, br, bi, (const double *)v0, scratch);
+        else
+            lanczos_update_kernel<false, false><<<g, NT, 0, st>>>(n, (double *)w, ar, ai, (const double *)v1, br, bi, nullptr, scratch);
+    } else {
+        if (v0)
+            lanczos_update_kernel<true, true><<<g, NT, 0, st>>>(n, (double *)w, ar, ai, (const double *)v1, br, bi, (const double *)v0, scratch);
+        else
+            lanczos_update_kernel<true, false><<<g, NT, 0, st>>>(n, (double *)w, ar, ai, (const double *)v1, br, bi, nullptr, scratch);
+    }
+    TPA_LAUNCH_CHECK();
+    reduce_pass2<<<1, NT, 0, st>>>(g, scratch, out);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_fill_zero(void *dst, int64_t n_bytes, void *stream) {
+    if (n_bytes <= 0) return 0;
+    TPA_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)n_bytes, (hipStream_t)stream));
+    return 0;
+}

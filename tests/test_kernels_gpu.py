@@ -1,0 +1,303 @@
+"""Raw C-ABI kernel numerics vs a plain torch fp64 reference of the same op (floating-point kernels)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from tenpy_amd import _lib
+    _lib.require_gpu()
+    lib = _lib.load()
+    return torch, lib, _lib
+
+
+def _dev(torch, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def _run_gemm(torch, lib, _lib, dtype, tasks, links, A, B, C):
+    bm, bn = ctypes.c_int(), ctypes.c_int()
+    lib.tpa_gemm_tile_shape(dtype, ctypes.byref(bm), ctypes.byref(bn))
+    tiles = []
+    for t, tk in enumerate(tasks):
+        m, n = tk[1], tk[2]
+        for i in range((m + bm.value - 1) // bm.value):
+            for j in range((n + bn.value - 1) // bn.value):
+                tiles.append([t, i, j, 0])
+    tasks_d = _dev(torch, np.array(tasks, np.int64))
+    links_d = _dev(torch, np.array(links, np.int64))
+    tiles_d = _dev(torch, np.array(tiles, np.int32))
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tpa_gemm_chain(dtype, tasks_d.data_ptr(), links_d.data_ptr(), tiles_d.data_ptr(), len(tiles),
+                                  A.data_ptr(), B.data_ptr(), C.data_ptr(), st), "gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 5, 7), (16, 16, 16), (37, 129, 65), (128, 128, 64), (130, 131, 17),
+                                   (300, 257, 290), (543, 545, 1086)])
+def test_gemm_single(env, cplx, shape):
+    torch, lib, _lib = env
+    m, n, k = shape
+    g = torch.Generator(device="cpu").manual_seed(m * 1000 + n * 10 + k)
+    dt = torch.complex128 if cplx else torch.float64
+    A = torch.randn(m, k, dtype=dt, generator=g).cuda()
+    B = torch.randn(k, n, dtype=dt, generator=g).cuda()
+    C = torch.full((m, n), float("nan"), dtype=dt).cuda()
+    links = [[0, 0, k, k, 1, n, 1, 0]]
+    tasks = [[0, m, n, n, 0, 1, 0, 0]]
+    _run_gemm(torch, lib, _lib, int(cplx), tasks, links, A, B, C)
+    ref = A @ B
+    err = (C - ref).abs().max().item()
+    assert err <= 1e-13 * k * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_gemm_strided_chain_accumulate(env, cplx):
+    """transposed operands (m-fast A, k-fast B), conj flags, a 3-link chain and accumulate=1."""
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(7)
+    dt = torch.complex128 if cplx else torch.float64
+    m, n = 70, 45
+    ks = [33, 4, 129]
+    # arena A holds A0 (m x k0 row-major), A1^T (k1 x m, i.e. m-fast), A2 (row-major)
+    A0 = torch.randn(m, ks[0], dtype=dt, generator=g)
+    A1T = torch.randn(ks[1], m, dtype=dt, generator=g)
+    A2 = torch.randn(m, ks[2], dtype=dt, generator=g)
+    B0 = torch.randn(ks[0], n, dtype=dt, generator=g)
+    B1T = torch.randn(n, ks[1], dtype=dt, generator=g)  # k-fast B
+    B2 = torch.randn(ks[2], n, dtype=dt, generator=g)
+    Aar = torch.cat([A0.reshape(-1), A1T.reshape(-1), A2.reshape(-1)]).cuda()
+    Bar = torch.cat([B0.reshape(-1), B1T.reshape(-1), B2.reshape(-1)]).cuda()
+    C0 = torch.randn(m, n, dtype=dt, generator=g)
+    C = C0.clone().cuda()
+    a_offs = [0, A0.numel(), A0.numel() + A1T.numel()]
+    b_offs = [0, B0.numel(), B0.numel() + B1T.numel()]
+    fl = [1, 2, 3] if cplx else [0, 0, 0]
+    links = [[a_offs[0], b_offs[0], ks[0], ks[0], 1, n, 1, fl[0]],
+             [a_offs[1], b_offs[1], ks[1], 1, m, 1, ks[1], fl[1]],
+             [a_offs[2], b_offs[2], ks[2], ks[2], 1, n, 1, fl[2]]]
+    tasks = [[0, m, n, n, 0, 3, 1, 0]]
+    _run_gemm(torch, lib, _lib, int(cplx), tasks, links, Aar, Bar, C)
+
+    def cj(x, f):
+        return x.conj() if f else x
+    ref = (C0 + cj(A0, fl[0] & 1) @ cj(B0, fl[0] & 2) + cj(A1T.T, fl[1] & 1) @ cj(B1T.T, fl[1] & 2)
+           + cj(A2, fl[2] & 1) @ cj(B2, fl[2] & 2)).cuda()
+    assert (C - ref).abs().max().item() < 1e-11
+
+
+def test_gemm_many_tasks(env):
+    torch, lib, _lib = env
+    rng = np.random.default_rng(3)
+    sizes = [(int(rng.integers(1, 200)), int(rng.integers(1, 200)), int(rng.integers(1, 200))) for _ in range(40)]
+    As, Bs, a_off, b_off, c_off = [], [], [0], [0], [0]
+    for (m, n, k) in sizes:
+        As.append(rng.standard_normal((m, k)))
+        Bs.append(rng.standard_normal((k, n)))
+        a_off.append(a_off[-1] + m * k)
+        b_off.append(b_off[-1] + k * n)
+        c_off.append(c_off[-1] + m * n)
+    A = _dev(torch, np.concatenate([x.ravel() for x in As]))
+    B = _dev(torch, np.concatenate([x.ravel() for x in Bs]))
+    C = torch.zeros(c_off[-1], dtype=torch.float64).cuda()
+    links = [[a_off[i], b_off[i], k, k, 1, n, 1, 0] for i, (m, n, k) in enumerate(sizes)]
+    tasks = [[c_off[i], m, n, n, i, 1, 0, 0] for i, (m, n, k) in enumerate(sizes)]
+    _run_gemm(torch, lib, _lib, 0, tasks, links, A, B, C)
+    Ch = C.cpu().numpy()
+    for i, (m, n, k) in enumerate(sizes):
+        ref = As[i] @ Bs[i]
+        np.testing.assert_allclose(Ch[c_off[i]:c_off[i + 1]].reshape(m, n), ref, rtol=0, atol=1e-12 * k)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_vec_kernels(env, cplx):
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(11)
+    dt = torch.complex128 if cplx else torch.float64
+    n = 100003
+    x = torch.randn(n, dtype=dt, generator=g).cuda()
+    y = torch.randn(n, dtype=dt, generator=g).cuda()
+    z = torch.randn(n, dtype=dt, generator=g).cuda()
+    out = torch.zeros(2, dtype=torch.float64).cuda()
+    scr = torch.zeros(4096, dtype=torch.float64).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    d = int(cplx)
+    for do_conj in ([0, 1] if cplx else [0]):
+        _lib.check(lib.tpa_dot(d, n, x.data_ptr(), y.data_ptr(), do_conj, out.data_ptr(), scr.data_ptr(), st))
+        ref = ((x.conj() if do_conj else x) * y).sum()
+        got = complex(out[0].item(), out[1].item())
+        assert abs(got - complex(ref.item())) < 1e-10
+    _lib.check(lib.tpa_nrm2sq(d, n, x.data_ptr(), out.data_ptr(), scr.data_ptr(), st))
+    assert abs(out[0].item() - (x.abs() ** 2).sum().item()) < 1e-9
+    al = complex(0.3, -0.7) if cplx else 0.3
+    y0 = y.clone()
+    _lib.check(lib.tpa_axpy(d, n, al.real, al.imag if cplx else 0.0, x.data_ptr(), y.data_ptr(), st))
+    assert (y - (y0 + al * x)).abs().max().item() < 1e-14
+    _lib.check(lib.tpa_scal(d, n, al.real, al.imag if cplx else 0.0, y.data_ptr(), st))
+    assert (y - al * (y0 + al * x)).abs().max().item() < 1e-14
+    be = complex(-0.2, 0.1) if cplx else -0.2
+    w0 = z.clone()
+    _lib.check(lib.tpa_lanczos_update(d, n, z.data_ptr(), al.real, al.imag if cplx else 0.0, x.data_ptr(),
+                                      be.real, be.imag if cplx else 0.0, y0.data_ptr(), out.data_ptr(),
+                                      scr.data_ptr(), st))
+    ref = w0 - al * x - be * y0
+    assert (z - ref).abs().max().item() < 1e-14
+    assert abs(out[0].item() - (ref.abs() ** 2).sum().item()) < 1e-9
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("shapes", [[(1, 1)], [(5, 3), (3, 5), (4, 4)], [(40, 17), (17, 40), (64, 64), (2, 9)],
+                                    [(130, 200), (257, 129)]])
+def test_svd_batch(env, cplx, shapes):
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(5 + len(shapes))
+    dt = torch.complex128 if cplx else torch.float64
+    mats = [torch.randn(m, n, dtype=dt, generator=g) for (m, n) in shapes]
+    # make one block rank deficient / graded
+    if len(mats) > 1:
+        mats[1][:, 0] = mats[1][:, -1]
+    jobs, a_off, u_off, s_off, v_off = [], 0, 0, 0, 0
+    for (m, n) in shapes:
+        k = min(m, n)
+        jobs.append([a_off, m, n, u_off, s_off, v_off, 0, 0])
+        a_off += m * n
+        u_off += m * k
+        s_off += k
+        v_off += k * n
+    A = torch.cat([x.reshape(-1) for x in mats]).cuda()
+    U = torch.zeros(u_off, dtype=dt).cuda()
+    S = torch.zeros(s_off, dtype=torch.float64).cuda()
+    VH = torch.zeros(v_off, dtype=dt).cuda()
+    jh = np.array(jobs, np.int64)
+    wb = lib.tpa_svd_worksize(int(cplx), jh.ctypes.data, len(jobs))
+    work = torch.empty(wb, dtype=torch.uint8).cuda()
+    sw = ctypes.c_int()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tpa_svd_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), U.data_ptr(), S.data_ptr(),
+                                 VH.data_ptr(), work.data_ptr(), wb, 40, 0.0, ctypes.byref(sw), st), "svd")
+    torch.cuda.synchronize()
+    for b, (m, n) in enumerate(shapes):
+        k = min(m, n)
+        j = jobs[b]
+        u = U[j[3]:j[3] + m * k].reshape(m, k).cpu()
+        s = S[j[4]:j[4] + k].cpu()
+        vh = VH[j[5]:j[5] + k * n].reshape(k, n).cpu()
+        ref_s = torch.linalg.svdvals(mats[b])
+        assert (s - ref_s).abs().max().item() <= 1e-13 * ref_s[0].item() * max(m, n)
+        rec = (u * s.to(dt)) @ vh
+        assert (rec - mats[b]).abs().max().item() < 1e-12 * ref_s[0].item() * max(m, n)
+        nz = s > 1e-10 * s[0]
+        un = u[:, nz]
+        assert (un.conj().T @ un - torch.eye(int(nz.sum()), dtype=dt)).abs().max().item() < 1e-12
+        vn = vh[nz, :]
+        assert (vn @ vn.conj().T - torch.eye(int(nz.sum()), dtype=dt)).abs().max().item() < 1e-12
+        assert bool((s[:-1] >= s[1:]).all())
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_qr_batch(env, cplx):
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(9)
+    dt = torch.complex128 if cplx else torch.float64
+    shapes = [(1, 1), (7, 3), (3, 7), (50, 50), (130, 40), (33, 90)]
+    mats = [torch.randn(m, n, dtype=dt, generator=g) for (m, n) in shapes]
+    mats[3][:, 1] = 0  # zero column
+    jobs, a_off, q_off, r_off = [], 0, 0, 0
+    for (m, n) in shapes:
+        k = min(m, n)
+        jobs.append([a_off, m, n, q_off, r_off, 0, 0, 0])
+        a_off += m * n
+        q_off += m * k
+        r_off += k * n
+    A = torch.cat([x.reshape(-1) for x in mats]).cuda()
+    Q = torch.zeros(q_off, dtype=dt).cuda()
+    R = torch.zeros(r_off, dtype=dt).cuda()
+    jh = np.array(jobs, np.int64)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tpa_qr_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), Q.data_ptr(), R.data_ptr(), st))
+    torch.cuda.synchronize()
+    for b, (m, n) in enumerate(shapes):
+        k = min(m, n)
+        j = jobs[b]
+        q = Q[j[3]:j[3] + m * k].reshape(m, k).cpu()
+        r = R[j[4]:j[4] + k * n].reshape(k, n).cpu()
+        assert (q @ r - mats[b]).abs().max().item() < 1e-12 * max(m, n)
+        assert (q.conj().T @ q - torch.eye(k, dtype=dt)).abs().max().item() < 1e-13 * max(m, n)
+        assert torch.tril(r, -1).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_eigh_batch(env, cplx):
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(13)
+    dt = torch.complex128 if cplx else torch.float64
+    ns = [1, 2, 9, 64, 150]
+    mats = []
+    for n in ns:
+        x = torch.randn(n, n, dtype=dt, generator=g)
+        mats.append(x + x.conj().T)
+    mats[2] = torch.diag(torch.tensor([1., -1., 1., -1., 2., -2., 0., 0., 3.], dtype=torch.float64)).to(dt)
+    jobs, a_off, w_off = [], 0, 0
+    for n in ns:
+        jobs.append([a_off, n, w_off, a_off, 0, 0, 0, 0])
+        a_off += n * n
+        w_off += n
+    A = torch.cat([x.reshape(-1) for x in mats]).cuda()
+    W = torch.zeros(w_off, dtype=torch.float64).cuda()
+    V = torch.zeros(a_off, dtype=dt).cuda()
+    jh = np.array(jobs, np.int64)
+    wb = lib.tpa_eigh_worksize(int(cplx), jh.ctypes.data, len(jobs))
+    work = torch.empty(wb, dtype=torch.uint8).cuda()
+    sw = ctypes.c_int()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tpa_eigh_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), W.data_ptr(), V.data_ptr(),
+                                  work.data_ptr(), wb, 40, 0.0, ctypes.byref(sw), st), "eigh")
+    torch.cuda.synchronize()
+    for b, n in enumerate(ns):
+        j = jobs[b]
+        w = W[j[2]:j[2] + n].cpu()
+        v = V[j[3]:j[3] + n * n].reshape(n, n).cpu()
+        ref = torch.linalg.eigvalsh(mats[b])
+        nrm = max(1.0, mats[b].abs().max().item()) * n
+        assert (w - ref).abs().max().item() < 1e-13 * nrm
+        assert (mats[b] @ v - v * w.to(dt)).abs().max().item() < 1e-12 * nrm
+        assert (v.conj().T @ v - torch.eye(n, dtype=dt)).abs().max().item() < 1e-12
+
+
+def test_copy_scale_gather(env):
+    torch, lib, _lib = env
+    rng = np.random.default_rng(0)
+    src = rng.standard_normal((6, 5, 4))
+    s_d = _dev(torch, src.ravel())
+    dst = torch.zeros(4 * 6 * 5 + 10, dtype=torch.float64).cuda()
+    # job: transpose (6,5,4)->(4,6,5) written at offset 10
+    MAXD = 6
+    job = np.zeros(4 + 3 * MAXD, np.int64)
+    job[0], job[1], job[2], job[3] = 10, 0, 3, 0
+    job[4:7] = [4, 6, 5]
+    job[4 + MAXD:4 + MAXD + 3] = [30, 5, 1]
+    job[4 + 2 * MAXD:4 + 2 * MAXD + 3] = [1, 20, 4]
+    jd = _dev(torch, job.reshape(1, -1))
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tpa_copy_batch(0, jd.data_ptr(), 1, 120, s_d.data_ptr(), dst.data_ptr(), st))
+    got = dst.cpu().numpy()[10:].reshape(4, 6, 5)
+    np.testing.assert_array_equal(got, src.transpose(2, 0, 1))
+    # scale axis 1 of (6,5,4)
+    sv = rng.standard_normal(7)
+    sj = _dev(torch, np.array([[0, 6, 5, 4, 2, 0]], np.int64))
+    x = s_d.clone()
+    _lib.check(lib.tpa_scale_axis_batch(0, sj.data_ptr(), 1, 120, x.data_ptr(), _dev(torch, sv).data_ptr(), 0, st))
+    np.testing.assert_allclose(x.cpu().numpy().reshape(6, 5, 4), src * sv[2:7][None, :, None], rtol=1e-15)
+    # gather along axis 1
+    idx = np.array([4, 0, 2], np.int64)
+    gj = _dev(torch, np.array([[0, 0, 6, 5, 3, 4, 0, 0]], np.int64))
+    out = torch.zeros(6 * 3 * 4, dtype=torch.float64).cuda()
+    _lib.check(lib.tpa_gather_axis_batch(0, gj.data_ptr(), 1, 72, _dev(torch, idx).data_ptr(), s_d.data_ptr(),
+                                         out.data_ptr(), st))
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(6, 3, 4), src[:, idx, :])
