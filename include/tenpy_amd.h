@@ -97,6 +97,17 @@ int tpa_copy_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_j
 int tpa_scale_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
                          void *x_base, const void *s_dev, int s_is_complex, void *stream);
 int tpa_fill_zero(void *dst_dev, int64_t n_bytes, void *stream);
+/* dst[b][i, j, l] = src[b][i, idx[idx_off + j], l] for blocks viewed as (pre, len, post): the np.compress
+ * of iproject (np_conserved.py:1982).  jobs: int64[n][8] = {dst_off, src_off, pre, len_src, len_dst, post,
+ * idx_off, 0}; idx_dev: int64 indices. */
+int tpa_gather_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
+                          const int64_t *idx_dev, const void *src_base, void *dst_base, void *stream);
+/* Flat dtype conversion / (complex) conjugation of an arena: astype (np_conserved.py:1865) and
+ * iconj's complex_conj (np_conserved.py:2202-2235).  c128->f64 keeps the real part. */
+int tpa_convert(int from_dtype, int to_dtype, int64_t n, const void *src_dev, void *dst_dev, int conj,
+                void *stream);
+/* Tile shape (rows, cols of C per workgroup) the GEMM kernel of `dtype` was built with. */
+int tpa_gemm_tile_shape(int dtype, int *bm, int *bn);
 
 /* ---- K5: batched block SVD, one-sided (Hestenes) Jacobi -- replaces svd_flat / LAPACK gesdd
  *      per charge block (np_conserved.py:4970-4980 via svd_robust.py:36-75) ---------------

@@ -100,6 +100,26 @@ __global__ __launch_bounds__(NT) void gather_axis_kernel(const GatherJob *__rest
     }
 }
 
+// dtype conversion / conjugation over a flat arena.  MODE 0: f64->f64 copy, 1: f64->c128, 2: c128->f64 (real
+// part), 3: c128->c128 (optionally conjugated)
+template <int MODE>
+__global__ __launch_bounds__(NT) void convert_kernel(int64_t n, const double *__restrict__ src,
+                                                     double *__restrict__ dst, int conj) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        if (MODE == 0) {
+            dst[i] = src[i];
+        } else if (MODE == 1) {
+            reinterpret_cast<double2 *>(dst)[i] = double2{src[i], 0.0};
+        } else if (MODE == 2) {
+            dst[i] = reinterpret_cast<const double2 *>(src)[i].x;
+        } else {
+            double2 v = reinterpret_cast<const double2 *>(src)[i];
+            if (conj) v.y = -v.y;
+            reinterpret_cast<double2 *>(dst)[i] = v;
+        }
+    }
+}
+
 inline int grid_x(int64_t max_elems) {
     int64_t g = (max_elems + NT * 4 - 1) / (NT * 4);
     if (g < 1) g = 1;
@@ -154,6 +174,25 @@ extern "C" int tpa_gather_axis_batch(int dtype, const int64_t *jobs_dev, int n_j
         gather_axis_kernel<false><<<grid, NT, 0, st>>>((const GatherJob *)jobs_dev, idx_dev, (const double *)src_base, (double *)dst_base);
     else
         gather_axis_kernel<true><<<grid, NT, 0, st>>>((const GatherJob *)jobs_dev, idx_dev, (const double *)src_base, (double *)dst_base);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_convert(int from_dtype, int to_dtype, int64_t n, const void *src, void *dst, int conj,
+                           void *stream) {
+    TPA_ARG_CHECK((from_dtype == TPA_F64 || from_dtype == TPA_C128) && (to_dtype == TPA_F64 || to_dtype == TPA_C128));
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int g = grid_x(n) * 4;
+    if (g > 2048) g = 2048;
+    if (from_dtype == TPA_F64 && to_dtype == TPA_F64)
+        convert_kernel<0><<<g, NT, 0, st>>>(n, (const double *)src, (double *)dst, 0);
+    else if (from_dtype == TPA_F64)
+        convert_kernel<1><<<g, NT, 0, st>>>(n, (const double *)src, (double *)dst, 0);
+    else if (to_dtype == TPA_F64)
+        convert_kernel<2><<<g, NT, 0, st>>>(n, (const double *)src, (double *)dst, 0);
+    else
+        convert_kernel<3><<<g, NT, 0, st>>>(n, (const double *)src, (double *)dst, conj);
     TPA_LAUNCH_CHECK();
     return 0;
 }

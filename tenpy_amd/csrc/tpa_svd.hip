@@ -372,7 +372,7 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
 // ================================================================================================
 // K7: batched Hermitian eigendecomposition on the same Jacobi machinery.
 // Replaces np.linalg.eigh per block (np_conserved.py:5059-5061).  A Hermitian block is shifted to be
-// positive semi-definite, A' = A + mu I with mu = ||A||_F >= rho(A); then the SVD A' = U S U^H *is* its
+// positive definite, A' = A + mu I with mu = 2 ||A||_F >= 2 rho(A); then the SVD A' = U S U^H *is* its
 // eigendecomposition (no +/-lambda mixing of singular subspaces), and lambda_j = S_j - mu.
 // Absolute accuracy ~ eps * ||A||_F, the same class as LAPACK's eigh.
 namespace {
@@ -393,7 +393,9 @@ __global__ __launch_bounds__(NT) void eigh_shift_kernel(const EighJob *__restric
     double s = 0;
     for (int64_t e = threadIdx.x; e < tot; e += NT) s = fma(a[e], a[e], s);
     s = block_sum<NT>(s, red);
-    const double m = sqrt(s);
+    // mu = 2 ||A||_F (1 if A == 0): spectrum of A' lies in [||A||_F, 3 ||A||_F] > 0, so every singular
+    // vector is well defined and the Jacobi iteration sees a condition number <= 3.
+    const double m = (s > 0.0) ? 2.0 * sqrt(s) : 1.0;
     if (threadIdx.x == 0) mu[blockIdx.x] = m;
     for (int64_t e = threadIdx.x; e < n * n; e += NT) {
         const int64_t i = e / n, j = e % n;

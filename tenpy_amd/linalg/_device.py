@@ -1,0 +1,104 @@
+"""Thin device helpers: arenas in HBM via torch (memory + streams only) and calls into the C-ABI.
+
+torch is *plumbing* here (allocation, H2D/D2H copies, the current HIP stream); every arithmetic or
+data-movement kernel on block data is one of the hand-written HIP kernels behind ``include/tenpy_amd.h``.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+
+_torch = None
+_scratch = {}
+
+
+def torch():
+    global _torch
+    if _torch is None:
+        import torch as _t
+        _torch = _t
+    return _torch
+
+
+def lib():
+    """The loaded C-ABI library; raises if no GPU is visible (no CPU fallback)."""
+    _lib.require_gpu()
+    return _lib.load()
+
+
+def stream():
+    return torch().cuda.current_stream().cuda_stream
+
+
+def code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return _lib.F64
+    if dtype == np.complex128:
+        return _lib.C128
+    raise ValueError("tenpy_amd computes in float64 / complex128 only, got " + str(dtype))
+
+
+def tdtype(dtype):
+    t = torch()
+    return t.float64 if np.dtype(dtype) == np.float64 else t.complex128
+
+
+def empty(n, dtype):
+    _lib.require_gpu()
+    return torch().empty(int(n), dtype=tdtype(dtype), device='cuda')
+
+
+def zeros(n, dtype):
+    arena = empty(n, dtype)
+    if n > 0:
+        _lib.check(lib().tpa_fill_zero(arena.data_ptr(), int(n) * arena.element_size(), stream()), "fill_zero")
+    return arena
+
+
+def to_device(arr):
+    """numpy array (any int/float dtype) -> device tensor of the same dtype (blocking H2D)."""
+    _lib.require_gpu()
+    arr = np.ascontiguousarray(arr)
+    return torch().from_numpy(arr).to('cuda')
+
+
+def clone(tensor):
+    return tensor.clone()
+
+
+def take(tensor, index_array):
+    """Gather a few scalars (e.g. a diagonal) from an arena; index_array is a host int64 array."""
+    return tensor[to_device(np.asarray(index_array, dtype=np.int64))]
+
+
+def to_host(tensor):
+    return tensor.cpu().numpy()
+
+
+def ptr(tensor):
+    return tensor.data_ptr() if tensor is not None else None
+
+
+def reduction_buffers():
+    """Per-device (out[4], scratch[TPA_RED_SCRATCH]) doubles for the deterministic reductions."""
+    t = torch()
+    dev = t.cuda.current_device()
+    if dev not in _scratch:
+        _scratch[dev] = (t.zeros(4, dtype=t.float64, device='cuda'), t.zeros(4096, dtype=t.float64, device='cuda'))
+    return _scratch[dev]
+
+
+def read_scalar(out, cplx):
+    """Blocking read of a reduction result written to ``out[0:2]``."""
+    v = out[:2].cpu()
+    return complex(float(v[0]), float(v[1])) if cplx else float(v[0])
+
+
+def check(rc, what=""):
+    _lib.check(rc, what)
+
+
+c_int = ctypes.c_int
+byref = ctypes.byref

@@ -1,0 +1,299 @@
+"""TEST INFRASTRUCTURE ONLY: a numpy emulation of the *device* entry points of the C-ABI.
+
+Purpose: exercise the HOST logic of ``tenpy_amd`` (charge bookkeeping, contraction/copy plans, leg
+fusion, truncation, Lanczos driver ...) in ``-m "not gpu"`` tests in a container without a GPU.  The
+product never imports this file; without the ``mock_device`` fixture every compute call raises
+``BackendError`` on a GPU-less machine (``tests/test_no_fallback.py`` checks exactly that).
+
+The emulation follows the *documented contract* of ``include/tenpy_amd.h`` (table layouts, strides,
+job formats), so it also pins that contract: a host-side change that builds wrong tables fails here.
+Host-only entry points (``tpa_plan_tensordot``, ``tpa_gemm_tile_shape``, ...) are forwarded to the real
+shared library.
+"""
+import bisect
+import ctypes
+
+import numpy as np
+import scipy.linalg
+import torch
+
+from tenpy_amd import _lib
+from tenpy_amd.linalg import _device as dev
+
+MAXD = 6
+
+
+class _Registry:
+    """Maps raw addresses back to the CPU tensors that own them."""
+
+    def __init__(self):
+        self.starts, self.tensors = [], []
+
+    def add(self, t):
+        if t.numel() == 0:
+            return t
+        p = t.data_ptr()
+        i = bisect.bisect_left(self.starts, p)
+        self.starts.insert(i, p)
+        self.tensors.insert(i, t)
+        if len(self.starts) > 20000:
+            self.starts, self.tensors = self.starts[-10000:], self.tensors[-10000:]
+        return t
+
+    def view(self, ptr, np_dtype):
+        """numpy view (of dtype) starting at ptr up to the end of the owning tensor."""
+        if ptr is None or ptr == 0:
+            return None
+        i = bisect.bisect_right(self.starts, ptr) - 1
+        while i >= 0:
+            t = self.tensors[i]
+            nbytes = t.numel() * t.element_size()
+            if self.starts[i] <= ptr < self.starts[i] + nbytes:
+                raw = t.reshape(-1).view(torch.uint8).numpy()
+                raw = raw[ptr - self.starts[i]:]
+                isz = np.dtype(np_dtype).itemsize
+                return raw[:len(raw) // isz * isz].view(np_dtype)
+            i -= 1
+        raise KeyError("mock_device: pointer %x not owned by a registered tensor" % ptr)
+
+
+REG = _Registry()
+
+
+def _npdt(code):
+    return np.float64 if code == 0 else np.complex128
+
+
+def _host(ptr, shape, dtype=np.int64):
+    n = int(np.prod(shape))
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class MockLib:
+    def __init__(self):
+        self.real = _lib.load()
+
+    def __getattr__(self, name):  # host-only entry points
+        return getattr(self.real, name)
+
+    # ---- K1 --------------------------------------------------------------------------------------
+    def tpa_gemm_chain(self, code, tasks_p, links_p, tiles_p, n_tiles, A_p, B_p, C_p, stream):
+        dt = _npdt(code)
+        tiles = REG.view(tiles_p, np.int32)[:4 * n_tiles].reshape(n_tiles, 4)
+        tasks_all = REG.view(tasks_p, np.int64)
+        links_all = REG.view(links_p, np.int64)
+        A, B, C = REG.view(A_p, dt), REG.view(B_p, dt), REG.view(C_p, dt)
+        bm, bn = ctypes.c_int(), ctypes.c_int()
+        self.real.tpa_gemm_tile_shape(code, ctypes.byref(bm), ctypes.byref(bn))
+        bm, bn = bm.value, bn.value
+        for t, tr, tc, _ in tiles:
+            c_off, m, n, ldc, lb, lc, acc, _ = tasks_all[8 * t:8 * t + 8]
+            r0, r1 = tr * bm, min(m, (tr + 1) * bm)
+            c0, c1 = tc * bn, min(n, (tc + 1) * bn)
+            assert r0 < m and c0 < n, "tile outside of task"
+            out = np.zeros((r1 - r0, c1 - c0), dtype=dt)
+            for l in range(lb, lb + lc):
+                a_off, b_off, k, a_rs, a_ks, b_ks, b_ns, flags = links_all[8 * l:8 * l + 8]
+                if k <= 0:
+                    continue
+                ai = a_off + np.arange(r0, r1)[:, None] * a_rs + np.arange(k)[None, :] * a_ks
+                bi = b_off + np.arange(k)[:, None] * b_ks + np.arange(c0, c1)[None, :] * b_ns
+                Am, Bm = A[ai], B[bi]
+                if flags & 1:
+                    Am = Am.conj()
+                if flags & 2:
+                    Bm = Bm.conj()
+                out += Am @ Bm
+            ci = c_off + np.arange(r0, r1)[:, None] * ldc + np.arange(c0, c1)[None, :]
+            if acc:
+                C[ci] += out
+            else:
+                C[ci] = out
+        return 0
+
+    # ---- K2-K4 -----------------------------------------------------------------------------------
+    def tpa_axpy(self, code, n, ar, ai, x_p, y_p, stream):
+        dt = _npdt(code)
+        al = complex(ar, ai) if code else ar
+        x, y = REG.view(x_p, dt)[:n], REG.view(y_p, dt)[:n]
+        y += al * x
+        return 0
+
+    def tpa_scal(self, code, n, ar, ai, x_p, stream):
+        dt = _npdt(code)
+        x = REG.view(x_p, dt)[:n]
+        x *= (complex(ar, ai) if code else ar)
+        return 0
+
+    def tpa_dot(self, code, n, x_p, y_p, do_conj, out_p, scr_p, stream):
+        dt = _npdt(code)
+        x, y = REG.view(x_p, dt)[:n], REG.view(y_p, dt)[:n]
+        v = np.sum((x.conj() if (do_conj and code) else x) * y)
+        out = REG.view(out_p, np.float64)
+        out[0], out[1] = np.real(v), np.imag(v)
+        return 0
+
+    def tpa_nrm2sq(self, code, n, x_p, out_p, scr_p, stream):
+        x = REG.view(x_p, _npdt(code))[:n]
+        out = REG.view(out_p, np.float64)
+        out[0], out[1] = float(np.sum(np.abs(x) ** 2)), 0.
+        return 0
+
+    def tpa_lanczos_update(self, code, n, w_p, ar, ai, v1_p, br, bi, v0_p, out_p, scr_p, stream):
+        dt = _npdt(code)
+        w, v1 = REG.view(w_p, dt)[:n], REG.view(v1_p, dt)[:n]
+        w -= (complex(ar, ai) if code else ar) * v1
+        if v0_p:
+            w -= (complex(br, bi) if code else br) * REG.view(v0_p, dt)[:n]
+        out = REG.view(out_p, np.float64)
+        out[0], out[1] = float(np.sum(np.abs(w) ** 2)), 0.
+        return 0
+
+    # ---- data movement ----------------------------------------------------------------------------
+    def tpa_copy_batch(self, code, jobs_p, n_jobs, max_elems, src_p, dst_p, stream):
+        dt = _npdt(code)
+        W = 4 + 3 * MAXD
+        jobs = REG.view(jobs_p, np.int64)[:W * n_jobs].reshape(n_jobs, W)
+        src, dst = REG.view(src_p, dt), REG.view(dst_p, dt)
+        for j in jobs:
+            nd = int(j[2])
+            shape = tuple(int(x) for x in j[4:4 + nd])
+            n = int(np.prod(shape))
+            assert n <= max_elems, "max_job_elems too small"
+            if n == 0:
+                continue
+            idx = np.indices(shape).reshape(nd, -1)
+            so = j[1] + (idx * j[4 + 2 * MAXD:4 + 2 * MAXD + nd, None]).sum(0)
+            do = j[0] + (idx * j[4 + MAXD:4 + MAXD + nd, None]).sum(0)
+            v = src[so]
+            if code and (j[3] & 1):
+                v = v.conj()
+            dst[do] = v
+        return 0
+
+    def tpa_scale_axis_batch(self, code, jobs_p, n_jobs, max_elems, x_p, s_p, s_cplx, stream):
+        dt = _npdt(code)
+        jobs = REG.view(jobs_p, np.int64)[:6 * n_jobs].reshape(n_jobs, 6)
+        x = REG.view(x_p, dt)
+        s = REG.view(s_p, np.complex128 if s_cplx else np.float64)
+        for x_off, pre, ln, post, s_off, _ in jobs:
+            blk = x[x_off:x_off + pre * ln * post].reshape(pre, ln, post)
+            blk *= s[s_off:s_off + ln][None, :, None]
+        return 0
+
+    def tpa_gather_axis_batch(self, code, jobs_p, n_jobs, max_elems, idx_p, src_p, dst_p, stream):
+        dt = _npdt(code)
+        jobs = REG.view(jobs_p, np.int64)[:8 * n_jobs].reshape(n_jobs, 8)
+        idx = REG.view(idx_p, np.int64)
+        src, dst = REG.view(src_p, dt), REG.view(dst_p, dt)
+        for d_off, s_off, pre, ls, ld, post, i_off, _ in jobs:
+            sb = src[s_off:s_off + pre * ls * post].reshape(pre, ls, post)
+            dst[d_off:d_off + pre * ld * post] = sb[:, idx[i_off:i_off + ld], :].reshape(-1)
+        return 0
+
+    def tpa_convert(self, cf, ct, n, src_p, dst_p, conj, stream):
+        src = REG.view(src_p, _npdt(cf))[:n].copy()
+        dst = REG.view(dst_p, _npdt(ct))[:n]
+        if cf == 1 and ct == 0:
+            dst[:] = src.real
+        elif cf == 1 and ct == 1 and conj:
+            dst[:] = src.conj()
+        else:
+            dst[:] = src
+        return 0
+
+    def tpa_fill_zero(self, dst_p, nbytes, stream):
+        REG.view(dst_p, np.uint8)[:nbytes] = 0
+        return 0
+
+    # ---- factorizations (LAPACK stands in for the Jacobi / Householder kernels) --------------------
+    def tpa_svd_worksize(self, code, jobs_p, n):
+        return 256
+
+    def tpa_svd_batch(self, code, jobs_p, n_jobs, a_p, u_p, s_p, vh_p, work_p, wb, max_sweeps, tol, sweeps_p, stream):
+        dt = _npdt(code)
+        jobs = _host(jobs_p, (n_jobs, 8))
+        A, U, VH = REG.view(a_p, dt), REG.view(u_p, dt), REG.view(vh_p, dt)
+        S = REG.view(s_p, np.float64)
+        for a_off, m, n, u_off, s_off, v_off, _, _ in jobs:
+            k = min(m, n)
+            blk = A[a_off:a_off + m * n].reshape(m, n)
+            if not np.all(np.isfinite(blk)):
+                return _lib.E_NAN
+            u, s, vh = scipy.linalg.svd(blk, full_matrices=False, lapack_driver='gesvd')
+            U[u_off:u_off + m * k] = u.reshape(-1)
+            S[s_off:s_off + k] = s
+            VH[v_off:v_off + k * n] = vh.reshape(-1)
+        return 0
+
+    def tpa_qr_batch(self, code, jobs_p, n_jobs, a_p, q_p, r_p, stream):
+        dt = _npdt(code)
+        jobs = _host(jobs_p, (n_jobs, 8))
+        A, Q, R = REG.view(a_p, dt), REG.view(q_p, dt), REG.view(r_p, dt)
+        for a_off, m, n, q_off, r_off, _, _, _ in jobs:
+            k = min(m, n)
+            q, r = np.linalg.qr(A[a_off:a_off + m * n].reshape(m, n), mode='reduced')
+            Q[q_off:q_off + m * k] = q.reshape(-1)
+            R[r_off:r_off + k * n] = r.reshape(-1)
+        return 0
+
+    def tpa_eigh_worksize(self, code, jobs_p, n):
+        return 256
+
+    def tpa_eigh_batch(self, code, jobs_p, n_jobs, a_p, w_p, v_p, work_p, wb, max_sweeps, tol, sweeps_p, stream):
+        dt = _npdt(code)
+        jobs = _host(jobs_p, (n_jobs, 8))
+        A, V = REG.view(a_p, dt), REG.view(v_p, dt)
+        W = REG.view(w_p, np.float64)
+        for a_off, n, w_off, v_off, _, _, _, _ in jobs:
+            w, v = np.linalg.eigh(A[a_off:a_off + n * n].reshape(n, n), 'L')
+            W[w_off:w_off + n] = w
+            V[v_off:v_off + n * n] = v.reshape(-1)
+        return 0
+
+
+class _FakeCuda:
+    @staticmethod
+    def current_device():
+        return 0
+
+
+def install(monkeypatch):
+    """Patch ``tenpy_amd.linalg._device`` so that arenas are CPU tensors and kernels are emulated."""
+    mock = MockLib()
+
+    def empty(n, dtype):
+        return REG.add(torch.empty(int(n), dtype=dev.tdtype(dtype)))
+
+    def zeros(n, dtype):
+        return REG.add(torch.zeros(int(n), dtype=dev.tdtype(dtype)))
+
+    def to_device(arr):
+        return REG.add(torch.from_numpy(np.array(arr, copy=True, order='C')))
+
+    def reduction_buffers():
+        if 'mock' not in dev._scratch:
+            dev._scratch['mock'] = (REG.add(torch.zeros(4, dtype=torch.float64)),
+                                    REG.add(torch.zeros(4096, dtype=torch.float64)))
+        return dev._scratch['mock']
+
+    class _T:
+        """torch facade: allocation helpers register their tensors."""
+        uint8 = torch.uint8
+        float64 = torch.float64
+        complex128 = torch.complex128
+
+        @staticmethod
+        def empty(n, dtype=None, device=None):
+            return REG.add(torch.empty(int(n), dtype=dtype))
+
+    monkeypatch.setattr(dev, "empty", empty)
+    monkeypatch.setattr(dev, "zeros", zeros)
+    monkeypatch.setattr(dev, "to_device", to_device)
+    monkeypatch.setattr(dev, "clone", lambda t: REG.add(t.clone()))
+    monkeypatch.setattr(dev, "lib", lambda: mock)
+    monkeypatch.setattr(dev, "stream", lambda: 0)
+    monkeypatch.setattr(dev, "reduction_buffers", reduction_buffers)
+    monkeypatch.setattr(dev, "torch", lambda: _T)
+    return mock
