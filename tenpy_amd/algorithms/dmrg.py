@@ -1,0 +1,140 @@
+"""Two-site finite DMRG sweep driver -- the measurement harness around the hot path.
+
+Follows the call sequence of the reference: ``Sweep.sweep`` (mps_common.py:345) ->
+``prepare_update_local`` (:498) -> ``update_local`` (dmrg.py:529: ``diag`` :672 = Lanczos,
+``mixed_svd`` :876 = ``svd_theta``, ``set_B`` :934) -> ``update_env`` (:569).  Options keep the
+reference's names (``trunc_params``, ``lanczos_params``, ``chi_list``, ``max_sweeps``, ``min_sweeps``,
+``max_E_err``, ``N_sweeps_check``, ``combine``).  Only what a finite two-site sweep without mixer needs is
+here; the rest of ``algorithms/dmrg.py`` (mixers, infinite MPS, one-site engine) is out of scope this round.
+"""
+import time
+
+import numpy as np
+
+from ..linalg import np_conserved as npc
+from ..linalg.krylov_based import LanczosGroundState
+from ..linalg.truncation import svd_theta, TruncationError
+from ..networks.mpo import MPOEnvironment
+from .mps_common import TwoSiteH
+
+__all__ = ['TwoSiteDMRGEngine', 'run']
+
+
+class TwoSiteDMRGEngine:
+    def __init__(self, psi, model_H, options):
+        self.psi = psi
+        self.H = model_H
+        self.options = options = dict(options)
+        self.trunc_params = dict(options.get('trunc_params', {}))
+        self.lanczos_params = dict(options.get('lanczos_params', {}))
+        self.chi_list = options.get('chi_list', None)
+        self.combine = options.get('combine', True)
+        self.env = MPOEnvironment(psi, model_H)
+        self.sweeps = 0
+        self.update_stats = {k: [] for k in ['i0', 'E_total', 'N_lanczos', 'time', 'err', 'chi', 'flops', 'bytes']}
+        self.sweep_stats = {k: [] for k in ['sweep', 'E', 'S', 'time', 'max_trunc_err', 'max_chi', 'N_updates']}
+        self.E_trunc_list = []
+        self.time0 = time.time()
+        self.log_matvec = options.get('log_matvec', False)
+        self.matvec_log = []
+        self.hooks = {}
+
+    def get_sweep_schedule(self):
+        L = self.psi.L
+        i0s = list(range(0, L - 2)) + list(range(L - 2, 0, -1))
+        move_right = [True] * (L - 2) + [False] * (L - 2)
+        update_LP_RP = [[True, False]] * (L - 2) + [[False, True]] * (L - 2)
+        return list(zip(i0s, move_right, update_LP_RP))
+
+    def sweep(self, optimize=True):
+        """One sweep = 2(L-2) two-site updates.  Returns the maximal truncation error."""
+        if self.chi_list is not None:
+            keys = [k for k in self.chi_list if k <= self.sweeps]
+            if keys:
+                self.trunc_params['chi_max'] = self.chi_list[max(keys)]
+        t0 = time.time()
+        max_err, n_upd = 0., 0
+        for i0, move_right, (upd_LP, upd_RP) in self.get_sweep_schedule():
+            err = self.update_bond(i0, move_right, upd_LP, upd_RP)
+            max_err = max(max_err, err.eps)
+            n_upd += 1
+        self.sweeps += 1
+        st = self.sweep_stats
+        st['sweep'].append(self.sweeps)
+        st['E'].append(self.update_stats['E_total'][-1])
+        st['S'].append(float(np.max(self.psi.entanglement_entropy())))
+        st['time'].append(time.time() - t0)
+        st['max_trunc_err'].append(max_err)
+        st['max_chi'].append(int(np.max(self.psi.chi)))
+        st['N_updates'].append(n_upd)
+        return max_err
+
+    def update_bond(self, i0, move_right=True, update_LP=True, update_RP=False):
+        t0 = time.time()
+        psi = self.psi
+        eff_H = TwoSiteH(self.env, i0, combine=True, move_right=move_right)
+        theta = psi.get_theta(i0, n=2)
+        theta = eff_H.combine_theta(theta)
+        lanczos = LanczosGroundState(eff_H, theta, self.lanczos_params)
+        E0, theta, N = lanczos.run()
+        i1 = i0 + 1
+        qtotal_i0 = psi.get_B(i0, None).qtotal
+        U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[qtotal_i0, None], inner_labels=['vR', 'vL'])
+        if update_LP:
+            eff_H.update_LP(self.env, i1, U)
+        if update_RP:
+            eff_H.update_RP(self.env, i0, VH)
+        A = U.split_legs(['(vL.p0)']).ireplace_label('p0', 'p')
+        B = VH.split_legs(['(p1.vR)']).ireplace_label('p1', 'p')
+        psi.set_B(i0, A, form='A')
+        psi.set_B(i1, B, form='B')
+        psi.set_SR(i0, S)
+        # environments that depended on the old tensors are stale now
+        for j in range(i1 + 1, psi.L):
+            if self.env._LP[j] is None:
+                break
+            self.env._LP[j] = None
+        if not update_LP and self.env._LP[i1] is not None:
+            self.env._LP[i1] = None
+        for j in range(i0 - 1, -1, -1):
+            if self.env._RP[j] is None:
+                break
+            self.env._RP[j] = None
+        if not update_RP and self.env._RP[i0] is not None:
+            self.env._RP[i0] = None
+        us = self.update_stats
+        us['i0'].append(i0)
+        us['E_total'].append(float(E0))
+        us['N_lanczos'].append(N)
+        us['time'].append(time.time() - t0)
+        us['err'].append(err.eps)
+        us['chi'].append(len(S))
+        us['flops'].append(eff_H.flops_per_matvec)
+        us['bytes'].append(eff_H.bytes_per_matvec)
+        if self.log_matvec:
+            self.matvec_log.append((i0, N, eff_H.flops_per_matvec, eff_H.bytes_per_matvec, theta.shape))
+        return err
+
+    def run(self):
+        """Sweep until converged (``max_E_err``) or ``max_sweeps``; returns ``(E, psi)``."""
+        opt = self.options
+        max_sweeps = opt.get('max_sweeps', 1000)
+        min_sweeps = opt.get('min_sweeps', 1)
+        max_E_err = opt.get('max_E_err', 1.e-8)
+        n_check = opt.get('N_sweeps_check', 1)
+        E_old = None
+        while self.sweeps < max_sweeps:
+            for _ in range(n_check):
+                self.sweep()
+            E = self.sweep_stats['E'][-1]
+            if E_old is not None and self.sweeps >= min_sweeps:
+                if abs((E - E_old) / max(abs(E), 1.)) < max_E_err:
+                    break
+            E_old = E
+        return self.sweep_stats['E'][-1], self.psi
+
+
+def run(psi, model_H, options):
+    eng = TwoSiteDMRGEngine(psi, model_H, options)
+    E, psi = eng.run()
+    return {'E': E, 'sweep_statistics': eng.sweep_stats, 'update_statistics': eng.update_stats}

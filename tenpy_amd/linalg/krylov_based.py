@@ -1,0 +1,182 @@
+"""Lanczos ground-state search on device-resident block vectors.
+
+Mirrors ``tenpy/linalg/krylov_based.py`` (``KrylovBased`` :28, ``LanczosGroundState`` :584,
+``_build_krylov`` :645, ``_converged`` :678, ``_calc_result_full`` :160) -- same options, same
+convergence criteria, same returned triple ``(E0, psi0, N)`` -- but the three-term recurrence is fused:
+
+* all Krylov vectors of one run share ONE block structure, so every BLAS-1 step is a flat pass over
+  the packed arenas;
+* ``w -= alpha v_k ; w -= beta v_{k-1} ; |w|^2`` is a single kernel (``tpa_lanczos_update``) instead of
+  two axpy + a norm (reference :665-672); alpha and beta are the only two host synchronisations per
+  iteration (the tridiagonal ``eigh`` stays on the host).
+"""
+import logging
+
+import numpy as np
+
+from . import _device as dev
+from . import np_conserved as npc
+
+logger = logging.getLogger(__name__)
+
+__all__ = ['LanczosGroundState', 'lanczos']
+
+
+class LanczosGroundState:
+    """Lanczos algorithm for the ground state of a hermitian ``H`` given through ``H.matvec(vec)``.
+
+    Options (defaults as in the reference): ``N_min`` 2, ``N_max`` 20, ``P_tol`` 1e-14, ``min_gap`` 1e-12,
+    ``E_tol`` inf, ``N_cache`` N_max, ``cutoff`` 100*eps, ``reortho`` False, ``E_shift`` None.
+    """
+
+    def __init__(self, H, psi0, options):
+        self.H = H
+        self.psi0 = psi0.copy(deep=True)
+        self.options = options = dict(options) if options is not None else {}
+        self.N_min = int(options.get('N_min', 2))
+        self.N_max = int(options.get('N_max', 20))
+        self.P_tol = options.get('P_tol', 1.e-14)
+        self.min_gap = options.get('min_gap', 1.e-12)
+        self.reortho = bool(options.get('reortho', False))
+        self.E_shift = options.get('E_shift', None)
+        self.E_tol = options.get('E_tol', np.inf)
+        self.N_cache = int(options.get('N_cache', self.N_max))
+        if self.N_min < 2:
+            raise ValueError("Should perform at least 2 steps.")
+        if self.N_cache < 2:
+            raise ValueError("Need to cache at least two vectors.")
+        self._cutoff = options.get('cutoff', np.finfo(np.float64).eps * 100)
+        self._cache = []
+        self._psi0_norm = None
+        self.Es = np.zeros([self.N_max, self.N_max], dtype=np.float64)
+        self._h_krylov = np.zeros([self.N_max + 1, self.N_max + 1], dtype=np.float64)
+        self._result_krylov = None
+
+    # ---- public -----------------------------------------------------------------------------------------
+    def run(self):
+        """Returns ``(E0, psi0, N)``: energy estimate, normalised ground state estimate, iterations."""
+        N = self._build_krylov()
+        E0 = self.Es[N - 1, 0]
+        if self.E_shift is not None:
+            E0 -= self.E_shift
+        if N == 1:
+            return E0, self.psi0.copy(deep=True), N
+        return E0, self._calc_result_full(N), N
+
+    # ---- internals ------------------------------------------------------------------------------------------
+    def _matvec(self, w):
+        r = self.H.matvec(w)
+        if self.E_shift is not None:
+            r.iadd_prefactor_other(self.E_shift, w)
+        return r
+
+    def _flat_ok(self, w, *others):
+        return w.stored_blocks > 0 and w._is_packed() and all(w._same_structure(o) and w.dtype == o.dtype for o in others)
+
+    def _build_krylov(self):
+        h = self._h_krylov
+        w = self.psi0
+        beta = npc.norm(w)
+        if beta < self._cutoff:
+            raise ValueError("Norm of self.psi0 too small: {0}".format(beta))
+        if self._psi0_norm is None:
+            self._psi0_norm = beta
+        k = 0
+        for k in range(self.N_max):
+            w.iscale_prefactor(1. / beta)
+            self._to_cache(w)
+            w = self._matvec(w)
+            v1 = self._cache[-1]
+            alpha = float(np.real(npc.inner(w, v1, axes='range', do_conj=True)))
+            h[k, k] = alpha
+            self._calc_result_krylov(k)
+            v0 = self._cache[-2] if (k > 0 and not self.reortho) else None
+            beta_prev = beta
+            if self._flat_ok(w, v1, *([v0] if v0 is not None else [])):
+                out, scr = dev.reduction_buffers()
+                dev.check(dev.lib().tpa_lanczos_update(
+                    dev.code(w.dtype), w._arena.numel(), w._arena.data_ptr(), alpha, 0., v1._arena.data_ptr(),
+                    beta_prev, 0., v0._arena.data_ptr() if v0 is not None else None, out.data_ptr(), scr.data_ptr(),
+                    dev.stream()), "lanczos_update")
+                if self.reortho:
+                    for c in self._cache[:-1]:
+                        w.iadd_prefactor_other(-npc.inner(c, w, axes='range', do_conj=True), c)
+                    beta = npc.norm(w)
+                else:
+                    beta = float(np.sqrt(dev.read_scalar(out, False)))
+            else:  # generic path (block structures differ, e.g. H creates / drops blocks)
+                w.iadd_prefactor_other(-alpha, v1)
+                if self.reortho:
+                    for c in self._cache[:-1]:
+                        w.iadd_prefactor_other(-npc.inner(c, w, axes='range', do_conj=True), c)
+                elif k > 0:
+                    w.iadd_prefactor_other(-beta_prev, self._cache[-2])
+                beta = npc.norm(w)
+            h[k, k + 1] = h[k + 1, k] = beta
+            if abs(beta) < self._cutoff or (k + 1 >= self.N_min and self._converged(k)):
+                break
+        return k + 1
+
+    def _converged(self, k):
+        v0 = self._result_krylov
+        E = self.Es[k, :]
+        ritz_res = abs(v0[k]) * self._h_krylov[k, k + 1]
+        gap = max(E[1] - E[0], self.min_gap)
+        p_err = (ritz_res / gap)**2
+        delta_E0 = self.Es[k - 1, 0] - E[0]
+        return p_err < self.P_tol and delta_E0 < self.E_tol
+
+    def _calc_result_krylov(self, k):
+        h = self._h_krylov
+        if k == 0:
+            self.Es[0, 0] = h[0, 0]
+            self._result_krylov = np.ones(1, np.float64)
+        else:
+            E_kr, v_kr = np.linalg.eigh(h[:k + 1, :k + 1])
+            self.Es[k, :k + 1] = E_kr
+            self._result_krylov = v_kr[:, 0]
+
+    def _to_cache(self, psi):
+        self._cache.append(psi)
+        if len(self._cache) > self.N_cache:
+            self._cache.pop(0)
+
+    def _calc_result_full(self, N):
+        """``psi = sum_k c_k v_k`` over the Krylov ONB; vectors that fell out of the cache are re-generated."""
+        vf = self._result_krylov
+        assert N == len(vf) > 1
+        psif = self.psi0 * vf[0]
+        len_cache = len(self._cache)
+        for k in range(1, min(len_cache + 1, N)):
+            psif.iadd_prefactor_other(vf[N - k], self._cache[-k])
+        self._cache = []
+        self._rebuild_krylov_for_result_full(psif, N - len_cache - 1)
+        nrm = npc.norm(psif)
+        if abs(1. - nrm) > 1.e-5:
+            logger.warning("poorly conditioned H matrix in KrylovBased! |psi_0| = %f", nrm)
+        psif.iscale_prefactor(1. / nrm)
+        return psif
+
+    def _rebuild_krylov_for_result_full(self, psif, N_max):
+        vf, h = self._result_krylov, self._h_krylov
+        w = self.psi0
+        beta = None
+        for k in range(0, N_max):
+            self._to_cache(w)
+            w = self._matvec(w)
+            w.iadd_prefactor_other(-h[k, k], self._cache[-1])
+            if self.reortho:
+                for c in self._cache[:-1]:
+                    w.iadd_prefactor_other(-npc.inner(c, w, axes='range', do_conj=True), c)
+            elif k > 0:
+                w.iadd_prefactor_other(-beta, self._cache[-2])
+            beta = h[k, k + 1]
+            w.iscale_prefactor(1. / beta)
+            psif.iadd_prefactor_other(vf[k + 1], w)
+
+
+def lanczos(H, psi, options={}, orthogonal_to=[]):
+    """Convenience wrapper like the reference's (deprecated) ``lanczos`` function."""
+    if len(orthogonal_to):
+        raise NotImplementedError("tenpy_amd: orthogonal_to")
+    return LanczosGroundState(H, psi, options).run()

@@ -1284,7 +1284,12 @@ class TensordotPlan:
         self.empty = True
 
     def apply(self, a, b, out_arena=None):
-        res = Array(self.legs, self.dtype, self.qtotal, self.labels)
+        # legs / labels / qtotal come from the actual operands: the plan only depends on block structure
+        legs = [a.legs[x] for x in self.keep_a] + [b.legs[x] for x in self.keep_b]
+        la, lb = [a._labels[x] for x in self.keep_a], [b._labels[x] for x in self.keep_b]
+        labels = [(l if (l is None or l not in lb) else None) for l in la] + \
+            [(l if (l is None or l not in la) else None) for l in lb]
+        res = Array(legs, self.dtype, a.chinfo.make_valid(a.qtotal + b.qtotal), labels)
         if self.empty:
             return res
         res._qdata = self.res_qdata
@@ -1409,8 +1414,7 @@ def plan_tensordot(a, b, axes=2):
         b_use = b.transpose(cb + keep_b)
         cb = list(range(nc))
         fb = 'lead'
-    key = (a_use._struct_key(), b_use._struct_key(), tuple(ca), tuple(cb), a.dtype.str, b.dtype.str,
-           tuple(a_use._labels), tuple(b_use._labels), a.qtotal.tobytes(), b.qtotal.tobytes())
+    key = (a_use._struct_key(), b_use._struct_key(), tuple(ca), tuple(cb), a.dtype.str, b.dtype.str)
     plan = _plan_cache.get(key)
     if plan is not None:
         _plan_cache.move_to_end(key)
@@ -1428,12 +1432,8 @@ def _build_plan(a, b, ca, cb, fa, fb):
     keep_b = [x for x in range(b.rank) if x not in cb]
     plan = TensordotPlan()
     plan.dtype = _calc_dtype(a.dtype, b.dtype)
-    plan.legs = [a.legs[x] for x in keep_a] + [b.legs[x] for x in keep_b]
-    la, lb = [a._labels[x] for x in keep_a], [b._labels[x] for x in keep_b]
-    plan.labels = [(l if (l is None or l not in lb) else None) for l in la] + \
-        [(l if (l is None or l not in la) else None) for l in lb]
-    plan.qtotal = a.chinfo.make_valid(a.qtotal + b.qtotal)
-    if len(plan.legs) == 0:
+    plan.keep_a, plan.keep_b = keep_a, keep_b
+    if len(keep_a) + len(keep_b) == 0:
         raise ValueError("full contraction: use inner()")
     if a.stored_blocks == 0 or b.stored_blocks == 0:
         return plan
@@ -1458,7 +1458,7 @@ def _build_plan(a, b, ca, cb, fa, fb):
     plan.res_qdata = np.ascontiguousarray(res_q, dtype=np.intp)
     plan.res_offsets = offs[:-1].astype(np.int64)
     plan.res_total = int(offs[-1])
-    tmp = Array(plan.legs, plan.dtype, plan.qtotal)
+    tmp = Array([a.legs[x] for x in keep_a] + [b.legs[x] for x in keep_b], plan.dtype)
     tmp._qdata, tmp._offsets = plan.res_qdata, plan.res_offsets
     plan.res_skey = tmp._struct_key()
     # links

@@ -1,0 +1,117 @@
+"""Minimal finite MPS holding device-resident site tensors -- the *caller side* of the hot path.
+
+This is NOT a re-implementation of ``tenpy/networks/mps.py`` (7.6k lines, out of scope); it
+holds exactly what a two-site sweep touches (reference ``MPS.get_theta`` :3041, ``get_B`` / ``set_B`` /
+``set_SR``, ``from_product_state``) with the same leg labels ``('vL', 'p', 'vR')`` and the same
+canonical-form convention ``B = S**nuL  Gamma  S**nuR`` ('A' = (1,0), 'B' = (0,1), 'Th' = (1,1)), so that the
+bench/parity harness exercises the npc calls of a real sweep in the reference's order.
+"""
+import numpy as np
+
+from ..linalg import np_conserved as npc
+from ..linalg.charges import LegCharge
+
+__all__ = ['MPS']
+
+_FORMS = {'A': (1., 0.), 'B': (0., 1.), 'C': (0.5, 0.5), 'G': (0., 0.), 'Th': (1., 1.), None: None}
+
+
+class MPS:
+    def __init__(self, p_legs, Bs, SVs, form='B'):
+        self.p_legs = list(p_legs)          # physical leg of each site
+        self.L = len(Bs)
+        self._B = list(Bs)
+        self._S = [np.asarray(s, dtype=np.float64) for s in SVs]   # L+1 Schmidt spectra, host
+        self.form = [_FORMS[form]] * self.L
+        self.chinfo = Bs[0].chinfo
+        self.dtype = Bs[0].dtype
+        self.finite = True
+        self.bc = 'finite'
+
+    @classmethod
+    def from_product_state(cls, p_legs, p_state, dtype=np.float64):
+        """Product state; ``p_state[i]`` is the flat physical index occupied on site i."""
+        chinfo = p_legs[0].chinfo
+        L = len(p_legs)
+        Bs = []
+        q_left = chinfo.make_valid()
+        for i in range(L):
+            leg_p = p_legs[i]
+            qi, _ = leg_p.get_qindex(int(p_state[i]))
+            q_right = chinfo.make_valid(q_left + leg_p.get_charge(qi))
+            vL = LegCharge.from_qflat(chinfo, [q_left], qconj=+1)
+            vR = LegCharge.from_qflat(chinfo, [q_right], qconj=-1)
+            dense = np.zeros((1, leg_p.ind_len, 1), dtype=dtype)
+            dense[0, int(p_state[i]), 0] = 1.
+            Bs.append(npc.Array.from_ndarray(dense, [vL, leg_p, vR], dtype=dtype, labels=['vL', 'p', 'vR']))
+            q_left = q_right
+        return cls(p_legs, Bs, [np.ones(1)] * (L + 1), form='B')
+
+    @property
+    def chi(self):
+        return [len(s) for s in self._S[1:-1]]
+
+    def get_SL(self, i):
+        return self._S[i]
+
+    def get_SR(self, i):
+        return self._S[i + 1]
+
+    def set_SL(self, i, S):
+        self._S[i] = np.asarray(S)
+
+    def set_SR(self, i, S):
+        self._S[i + 1] = np.asarray(S)
+
+    def set_B(self, i, B, form='B'):
+        self._B[i] = B.transpose(['vL', 'p', 'vR']) if B._labels != ['vL', 'p', 'vR'] else B
+        self.form[i] = _FORMS[form] if not isinstance(form, tuple) else form
+
+    @staticmethod
+    def _scale_axis_B(B, S, power, axis):
+        if power == 0.:
+            return B
+        if power == 1.:
+            return B.scale_axis(S, axis)
+        return B.scale_axis(S**power, axis)
+
+    def get_B(self, i, form='B', copy=False):
+        """Site tensor converted to ``form``; ``form=None`` returns the stored tensor."""
+        want = _FORMS[form] if not isinstance(form, tuple) else form
+        B = self._B[i]
+        if want is not None and want != self.form[i]:
+            have = self.form[i]
+            B = self._scale_axis_B(B, self._S[i], want[0] - have[0], 'vL')
+            B = self._scale_axis_B(B, self._S[i + 1], want[1] - have[1], 'vR')
+        elif copy:
+            B = B.copy(deep=True)
+        return B
+
+    def get_theta(self, i, n=2, formL=1., formR=1.):
+        """Two-site wave function with labels ``'vL', 'p0', 'p1', 'vR'`` (reference mps.py:3041)."""
+        assert n == 2
+        B0 = self._B[i]
+        B0 = self._scale_axis_B(B0, self._S[i], formL - self.form[i][0], 'vL')
+        B0 = self._scale_axis_B(B0, self._S[i + 1], 1. - self.form[i][1] - self.form[i + 1][0], 'vR')
+        B1 = self._B[i + 1]
+        B1 = self._scale_axis_B(B1, self._S[i + 2], formR - self.form[i + 1][1], 'vR')
+        B0 = B0.replace_label('p', 'p0')
+        B1 = B1.replace_label('p', 'p1')
+        return npc.tensordot(B0, B1, axes=['vR', 'vL'])
+
+    def entanglement_entropy(self):
+        res = []
+        for s in self._S[1:-1]:
+            p = s[s > 1e-30]**2
+            res.append(float(-np.sum(p * np.log(p))))
+        return np.array(res)
+
+    def norm_test(self):
+        """|<psi|psi>| computed by contracting the transfer matrices (device tensordots)."""
+        B = self.get_B(0, 'B')
+        E = npc.tensordot(B.conj(), B, axes=(['vL*', 'p*'], ['vL', 'p']))
+        for i in range(1, self.L):
+            B = self.get_B(i, 'B')
+            E = npc.tensordot(E, B, axes=['vR', 'vL'])
+            E = npc.tensordot(B.conj(), E, axes=(['vL*', 'p*'], ['vR*', 'p']))
+        return E.to_ndarray().reshape(-1)[0]
