@@ -1,0 +1,31 @@
+"""Run the two-site DMRG harness on the GPU: python scripts/run_dmrg.py L chi n_sweeps [model]"""
+import sys
+import time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from tenpy_amd.models.spin_chains import xxz_chain_mpo, tfi_chain_mpo, spin_half_leg
+from tenpy_amd.networks.mps import MPS
+from tenpy_amd.algorithms.dmrg import TwoSiteDMRGEngine
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+chi = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ns = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+model = sys.argv[4] if len(sys.argv) > 4 else 'xxz'
+if model == 'xxz':
+    H = xxz_chain_mpo(L, 1., 1., 0.)
+    chinfo, p = spin_half_leg('Sz')
+    psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
+else:
+    H = tfi_chain_mpo(L, 1., 1., None)
+    chinfo, p = spin_half_leg(None)
+    psi = MPS.from_product_state([p] * L, [1] * L)
+eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': chi, 'svd_min': 1e-10}, 'lanczos_params': {}, 'profile': True})
+for s in range(ns):
+    torch.cuda.synchronize()
+    t = time.time()
+    eng.sweep()
+    torch.cuda.synchronize()
+    print("sweep %d E=%.13f chi=%d t=%.3fs" % (s, eng.sweep_stats['E'][-1], eng.sweep_stats['max_chi'][-1], time.time() - t), {k: round(v, 3) for k, v in eng.phase_time.items()}, 'N_lanczos', int(np.sum(eng.update_stats['N_lanczos'][-2*(L-2):])), flush=True)
+    eng.phase_time = {k: 0. for k in eng.phase_time}

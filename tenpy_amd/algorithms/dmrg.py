@@ -38,6 +38,8 @@ class TwoSiteDMRGEngine:
         self.log_matvec = options.get('log_matvec', False)
         self.matvec_log = []
         self.hooks = {}
+        self.profile = options.get('profile', False)
+        self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
 
     def get_sweep_schedule(self):
         L = self.psi.L
@@ -72,23 +74,30 @@ class TwoSiteDMRGEngine:
     def update_bond(self, i0, move_right=True, update_LP=True, update_RP=False):
         t0 = time.time()
         psi = self.psi
+        tick = self._tick
+        tick(None)
         eff_H = TwoSiteH(self.env, i0, combine=True, move_right=move_right)
         theta = psi.get_theta(i0, n=2)
         theta = eff_H.combine_theta(theta)
+        tick('heff')
         lanczos = LanczosGroundState(eff_H, theta, self.lanczos_params)
         E0, theta, N = lanczos.run()
+        tick('lanczos')
         i1 = i0 + 1
         qtotal_i0 = psi.get_B(i0, None).qtotal
         U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[qtotal_i0, None], inner_labels=['vR', 'vL'])
+        tick('svd')
         if update_LP:
             eff_H.update_LP(self.env, i1, U)
         if update_RP:
             eff_H.update_RP(self.env, i0, VH)
+        tick('env')
         A = U.split_legs(['(vL.p0)']).ireplace_label('p0', 'p')
         B = VH.split_legs(['(p1.vR)']).ireplace_label('p1', 'p')
         psi.set_B(i0, A, form='A')
         psi.set_B(i1, B, form='B')
         psi.set_SR(i0, S)
+        tick('setB')
         # environments that depended on the old tensors are stale now
         for j in range(i1 + 1, psi.L):
             if self.env._LP[j] is None:
@@ -114,6 +123,17 @@ class TwoSiteDMRGEngine:
         if self.log_matvec:
             self.matvec_log.append((i0, N, eff_H.flops_per_matvec, eff_H.bytes_per_matvec, theta.shape))
         return err
+
+    def _tick(self, phase):
+        """Phase timer (mirrors the reference's DEBUG_PRINT phases); synchronises only when profiling."""
+        if not self.profile:
+            return
+        from ..linalg import _device as dev
+        dev.torch().cuda.synchronize()
+        now = time.time()
+        if phase is not None:
+            self.phase_time[phase] += now - self._t_phase
+        self._t_phase = now
 
     def run(self):
         """Sweep until converged (``max_E_err``) or ``max_sweeps``; returns ``(E, psi)``."""

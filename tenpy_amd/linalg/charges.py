@@ -150,14 +150,13 @@ class LegCharge:
 
     @classmethod
     def from_qflat(cls, chargeinfo, qflat, qconj=1):
-        """One charge per *index*; consecutive equal charges are bunched into blocks."""
+        """One block per *index* (neither sorted nor bunched, like the reference :768)."""
         qflat = np.array(qflat, dtype=QTYPE)
         if qflat.ndim == 1 and chargeinfo.qnumber == 1:
             qflat = qflat.reshape(-1, 1)
         ind_len = qflat.shape[0]
         qflat = qflat.reshape(ind_len, chargeinfo.qnumber)
-        starts = _find_row_differences(qflat)
-        res = cls(chargeinfo, starts, qflat[starts[:-1]], qconj)
+        res = cls(chargeinfo, np.arange(ind_len + 1), qflat, qconj)
         res.sorted = res.is_sorted()
         res.bunched = res.is_bunched()
         return res
@@ -217,7 +216,10 @@ class LegCharge:
                 for ch, b, e in zip(self.charges, self.slices[:-1], self.slices[1:])}
 
     def is_blocked(self):
-        return self.sorted and self.bunched
+        """True if qindices map 1:1 to charge values (reference :1053): sorted+bunched, or all charges distinct."""
+        if self.sorted and self.bunched:
+            return True
+        return len({tuple(c) for c in self.charges.tolist()}) == self.block_number
 
     def is_sorted(self):
         if self.chinfo.qnumber == 0:
@@ -364,15 +366,18 @@ class LegCharge:
         return np.concatenate(parts) if parts else np.zeros(0, np.intp)
 
     def perm_qind_from_perm_flat(self, perm_flat):
+        """Block permutation belonging to a flat permutation that only moves whole blocks."""
         perm_flat = np.asarray(perm_flat)
-        perm_qind = perm_flat[self.slices[:-1]]
-        # check that it really is a block permutation
-        if not np.array_equal(self.perm_flat_from_perm_qind(np.searchsorted(self.slices, perm_qind, 'right') - 1)
-                              if False else perm_flat, perm_flat):  # pragma: no cover
-            raise ValueError("not a qindex permutation")
-        return _inverse_permutation(np.argsort(np.argsort(perm_qind)))[np.argsort(perm_qind)] \
-            if False else np.argsort(np.argsort(perm_qind)).astype(np.intp)[np.argsort(perm_qind)] * 0 + \
-            (np.searchsorted(self.slices, np.sort(perm_qind), 'right') - 1)[np.argsort(np.argsort(perm_qind))]
+        sizes = self.get_block_sizes()
+        res, pos = [], 0
+        while pos < self.ind_len:
+            q = int(np.searchsorted(self.slices, perm_flat[pos], side='right')) - 1
+            if perm_flat[pos] != self.slices[q] or \
+                    not np.array_equal(perm_flat[pos:pos + sizes[q]], np.arange(self.slices[q], self.slices[q + 1])):
+                raise ValueError("Permutation mixes qind")
+            res.append(q)
+            pos += int(sizes[q])
+        return np.array(res, dtype=np.intp)
 
     def __str__(self):
         qconj = " {0:+d}\n".format(self.qconj)

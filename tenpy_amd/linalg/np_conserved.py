@@ -1720,6 +1720,7 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
     label_Q, label_R = inner_labels
     piped_axes, a = a.as_completely_blocked()
     chinfo = a.chinfo
+    qtotal_Q_given = qtotal_Q is not None
     qtotal_Q = chinfo.make_valid(qtotal_Q)
     qtotal_R = chinfo.make_valid(a.qtotal - qtotal_Q)
     if a.stored_blocks == 0:
@@ -1736,13 +1737,25 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
     R_arena = dev.empty(int(r_offs[-1]), a.dtype)
     dev.check(dev.lib().tpa_qr_batch(dev.code(a.dtype), jobs.ctypes.data, nblk, a._arena.data_ptr(), Q_arena.data_ptr(),
                                      R_arena.data_ptr(), dev.stream()), "qr_batch")
+    # inner leg = leg 0 projected onto the first k indices of every block row (reference :4186-4232)
+    a_leg0 = a.legs[0]
     qi_L, qi_R = a._qdata[:, 0], a._qdata[:, 1]
-    inner_charges = chinfo.make_valid((qtotal_R - a.legs[1].get_charge(qi_R)) * inner_qconj)
-    inner_leg_R = LegCharge.from_qind(chinfo, k_offs, inner_charges, inner_qconj)
-    inner_leg_Q = inner_leg_R.conj()
-    qi_C = np.arange(nblk, dtype=np.intp)
-    Q = Array([a.legs[0], inner_leg_Q], a.dtype, qtotal_Q)
-    R = Array([inner_leg_R, a.legs[1]], a.dtype, qtotal_R)
+    mask = np.zeros(a_leg0.ind_len, dtype=np.bool_)
+    for q1, k in zip(qi_L, ks):
+        i0 = a_leg0.slices[q1]
+        mask[i0:i0 + k] = True
+    inner_leg = a_leg0.to_LegCharge() if isinstance(a_leg0, LegPipe) else a_leg0.copy()
+    map_qind, _, inner_leg = inner_leg.project(mask)
+    if qtotal_Q_given:
+        inner_leg.charges = chinfo.make_valid(inner_leg.charges - inner_leg.qconj * qtotal_Q)
+        inner_leg.sorted = False
+    if inner_leg.qconj != inner_qconj:
+        inner_leg.charges = chinfo.make_valid(-inner_leg.charges)
+        inner_leg.sorted = False
+        inner_leg.qconj = inner_qconj
+    qi_C = map_qind[qi_L]
+    Q = Array([a_leg0, inner_leg.conj()], a.dtype, qtotal_Q)
+    R = Array([inner_leg, a.legs[1]], a.dtype, qtotal_R)
     Q._qdata = np.ascontiguousarray(np.stack([qi_L, qi_C], axis=1), dtype=np.intp)
     Q._offsets, Q._arena, Q._qdata_sorted = q_offs[:-1].astype(np.int64), Q_arena, False
     R._qdata = np.ascontiguousarray(np.stack([qi_C, qi_R], axis=1), dtype=np.intp)
@@ -1751,15 +1764,20 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
         # phases of diag(R) per block: tiny D2H of the diagonals, then two axis scalings on the device
         diag_idx = np.concatenate([r_offs[b] + np.arange(ks[b]) * (ns[b] + 1) for b in range(nblk)])
         d = dev.to_host(dev.take(R_arena, diag_idx))
-        ph = np.where(np.abs(d) > 0, d / np.where(np.abs(d) > 0, np.abs(d), 1.), 1.)
+        phb = np.where(np.abs(d) > 0, d / np.where(np.abs(d) > 0, np.abs(d), 1.), 1.)
         if a.dtype.kind != 'c':
-            ph = ph.real
+            phb = phb.real
+        # block order -> flat index order of the inner leg
+        ph = np.ones(inner_leg.ind_len, dtype=phb.dtype)
+        for b in range(nblk):
+            i0 = inner_leg.slices[qi_C[b]]
+            ph[i0:i0 + ks[b]] = phb[k_offs[b]:k_offs[b + 1]]
         Q.iscale_axis(ph, 1)
         R.iscale_axis(np.conj(ph), 0)
     if 0 in piped_axes:
         Q = Q.split_legs(0)
     if 1 in piped_axes:
-        R = R.split_legs(1)
+        R = R.split_legs(-1)
     Q.iset_leg_labels([a_labels[0], label_Q])
     R.iset_leg_labels([label_R, a_labels[1]])
     return Q, R
@@ -1778,6 +1796,7 @@ def eigh(a, UPLO='L', sort=None):
         raise ValueError("Non-trivial qtotal -> Nilpotent. Not diagonizable!?")
     if sort is not None:
         raise NotImplementedError("tenpy_amd: eigh(sort=...)")
+    a_labels = a._labels
     piped_axes, a = a.as_completely_blocked()
     leg = a.legs[0]
     n_all = leg.get_block_sizes().astype(np.int64)
@@ -1815,4 +1834,5 @@ def eigh(a, UPLO='L', sort=None):
             resw[leg.get_slice(qi)] = W_host[w_offs[b]:w_offs[b + 1]]
     if len(piped_axes) > 0:
         V = V.split_legs(0)
+    V.iset_leg_labels([a_labels[0], 'eig'])
     return resw, V

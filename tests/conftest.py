@@ -25,3 +25,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(params=["mock", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    """'mock': host logic on the numpy emulation of the C-ABI device calls (CPU container);
+    'gpu': the real HIP kernels on an MI355X."""
+    from tenpy_amd.linalg import np_conserved as npc
+    npc._plan_cache.clear()
+    if request.param == "mock":
+        import mock_device
+        mock_device.install(monkeypatch)
+    else:
+        from tenpy_amd import _lib
+        _lib.require_gpu()
+    yield request.param
+    npc._plan_cache.clear()

@@ -1,0 +1,283 @@
+"""Generate golden fixtures from the REFERENCE implementation (TeNPy, pure-Python path).
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    TENPY_NO_CYTHON=1 PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+Outputs (committed): ``tests/golden/*.pkl`` -- plain dict / list / numpy content only (no tenpy classes),
+so the tests can load them anywhere.  What is pinned:
+
+* ``charges.pkl``    LegCharge.sort/bunch/project and LegPipe (slices, charges, q_map, q_map_slices)
+* ``tensordot.pkl``  operands + results of npc.tensordot / inner / outer for several axes / dtypes
+* ``reshape.pkl``    combine_legs / split_legs / transpose results
+* ``linalg.pkl``     svd (S per block, U/VH qdata + legs), qr, eigh, iadd_prefactor_other with union of blocks, norm
+* ``lanczos.pkl``    LanczosGroundState on a small TwoSiteH-like dense-backed operator: E0, N, alpha/beta
+* ``truncate.pkl``   truncation.truncate on assorted spectra / options
+* ``dmrg.pkl``       per-sweep energies, chi, centre-bond Schmidt values of reference two-site DMRG runs
+                     (XXZ Sz-conserving L=16 chi=32, TFI L=32 chi=30 = examples/d_dmrg.py config,
+                     TFI parity L=12) with Lanczos always used (max_N_for_ED=0, mixer off)
+"""
+import os
+import pickle
+import sys
+import warnings
+
+import numpy as np
+
+sys.path.insert(0, '/root/reference')
+os.environ.setdefault('TENPY_NO_CYTHON', '1')
+import tenpy  # noqa: E402
+import tenpy.linalg.np_conserved as npc  # noqa: E402
+from tenpy.linalg import charges, krylov_based, truncation  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+rng = np.random.RandomState(20260925)
+
+
+def dump_leg(leg):
+    d = dict(slices=np.array(leg.slices), charges=np.array(leg.charges), qconj=int(leg.qconj),
+             mod=np.array(leg.chinfo.mod), sorted=bool(leg.sorted), bunched=bool(leg.bunched))
+    if isinstance(leg, charges.LegPipe):
+        d['pipe'] = dict(legs=[dump_leg(l) for l in leg.legs], q_map=np.array(leg.q_map),
+                         q_map_slices=np.array(leg.q_map_slices))
+    return d
+
+
+def dump_array(a):
+    return dict(legs=[dump_leg(l) for l in a.legs], qtotal=np.array(a.qtotal), qdata=np.array(a._qdata),
+                qdata_sorted=bool(a._qdata_sorted), blocks=[np.array(b) for b in a._data], labels=list(a._labels),
+                dtype=str(a.dtype), dense=a.to_ndarray())
+
+
+def rand_leg(chinfo, n, qconj=1, bunch=True):
+    qflat = []
+    for mod in chinfo.mod:
+        if mod > 1:
+            qflat.append(rng.randint(0, mod, size=n))
+        else:
+            r = max(2, n // 4)
+            qflat.append(rng.randint(-r, r + 1, size=n))
+    qflat = np.array(qflat, dtype=np.int64).T.reshape(n, chinfo.qnumber)
+    leg = charges.LegCharge.from_qflat(chinfo, qflat, qconj)
+    return leg.bunch()[1] if bunch else leg
+
+
+def rand_array(legs, qtotal=None, cplx=False, labels=None):
+    def f(size):
+        x = rng.standard_normal(size)
+        if cplx:
+            x = x + 1.j * rng.standard_normal(size)
+        return x
+    a = npc.Array.from_func(f, legs, dtype=np.complex128 if cplx else np.float64, qtotal=qtotal, shape_kw='size')
+    if labels is not None:
+        a.iset_leg_labels(labels)
+    return a
+
+
+def save(name, obj):
+    with open(os.path.join(HERE, name), 'wb') as f:
+        pickle.dump(obj, f, protocol=4)
+    print("wrote", name, os.path.getsize(os.path.join(HERE, name)), "bytes")
+
+
+# ---------------------------------------------------------------------------------------------------
+def gen_charges():
+    out = []
+    for mod in ([1], [2], [1, 3], [3, 1, 2]):
+        ch = charges.ChargeInfo(mod)
+        for n in (1, 5, 12):
+            leg = rand_leg(ch, n, qconj=rng.choice([-1, 1]), bunch=False)
+            perm, sl = leg.sort(bunch=True)
+            idx, bl = leg.bunch()
+            mask = rng.rand(n) > 0.4
+            if not mask.any():
+                mask[0] = True
+            map_qind, block_masks, pl = leg.project(mask)
+            out.append(dict(kind='leg', leg=dump_leg(leg), sort_perm=np.array(perm), sorted=dump_leg(sl), bunch_idx=np.array(idx),
+                            bunched=dump_leg(bl), mask=mask, map_qind=np.array(map_qind), projected=dump_leg(pl),
+                            qflat=leg.to_qflat()))
+        for shape in ((3, 4), (5, 2, 3), (1, 1), (6,)):
+            legs = [rand_leg(ch, n, qconj=rng.choice([-1, 1])) for n in shape]
+            for sort, bunch in ((True, True), (False, True), (True, False), (False, False)):
+                for qconj in (1, -1):
+                    pipe = charges.LegPipe(legs, qconj=qconj, sort=sort, bunch=bunch)
+                    out.append(dict(kind='pipe', legs=[dump_leg(l) for l in legs], qconj=qconj, sort=sort, bunch=bunch,
+                                    pipe=dump_leg(pipe),
+                                    flat_map=[pipe.map_incoming_flat([rng.randint(0, l.ind_len) for l in legs]) for _ in range(0)]))
+    save('charges.pkl', out)
+
+
+def gen_tensordot():
+    out = []
+    for mod, cplx in (([1], False), ([1], True), ([2], False), ([1, 3], False), ([], False)):
+        ch = charges.ChargeInfo(mod)
+        la, lb, lc, ld, le = [rand_leg(ch, n) for n in (7, 6, 5, 4, 8)]
+        a = rand_array([la, lb, lc.conj()], labels=['a', 'b', 'c'], cplx=cplx)
+        qt = [1] * len(mod) if len(mod) else None
+        b = rand_array([lc, lb.conj(), ld], qtotal=qt, labels=['c*', 'b*', 'd'], cplx=cplx)
+        for axes in ((['c'], ['c*']), (['b', 'c'], ['b*', 'c*']), (['b'], ['b*']), ([2, 1], [0, 1])):
+            r = npc.tensordot(a, b, axes=axes)
+            out.append(dict(op='tensordot', a=dump_array(a), b=dump_array(b), axes=axes, res=dump_array(r)))
+        r = npc.outer(a, b)
+        out.append(dict(op='outer', a=dump_array(a), b=dump_array(b), res=dump_array(r)))
+        a2 = rand_array([la, lb, lc.conj()], labels=['a', 'b', 'c'], cplx=cplx)
+        out.append(dict(op='inner', a=dump_array(a), b=dump_array(a2), do_conj=True,
+                        res=npc.inner(a, a2, axes='range', do_conj=True)))
+        bc = rand_array([lc, lb.conj(), la.conj()], labels=['c*', 'b*', 'a*'], cplx=cplx)
+        out.append(dict(op='inner', a=dump_array(a), b=dump_array(bc), do_conj=False, axes='labels',
+                        res=npc.inner(a, bc, axes='labels', do_conj=False)))
+        if cplx:
+            # mixed real x complex
+            ar = rand_array([la, lb, lc.conj()], labels=['a', 'b', 'c'])
+            r = npc.tensordot(ar, b, axes=(['b', 'c'], ['b*', 'c*']))
+            out.append(dict(op='tensordot', a=dump_array(ar), b=dump_array(b), axes=(['b', 'c'], ['b*', 'c*']), res=dump_array(r)))
+    save('tensordot.pkl', out)
+
+
+def gen_reshape():
+    out = []
+    for mod, cplx in (([1], False), ([2, 1], True)):
+        ch = charges.ChargeInfo(mod)
+        legs = [rand_leg(ch, n, qconj=q) for n, q in ((4, 1), (5, -1), (3, 1), (6, -1))]
+        a = rand_array(legs, labels=['a', 'b', 'c', 'd'], cplx=cplx)
+        for cl, new_axes in (([['a', 'b']], None), ([['a', 'c'], ['d', 'b']], None), ([['c', 'a']], [1]),
+                             ([['b', 'd'], ['a']], [1, 0]), ([['a', 'b', 'c', 'd']], None)):
+            c = a.combine_legs(cl, new_axes=new_axes)
+            s = c.split_legs()
+            out.append(dict(op='combine', a=dump_array(a), combine_legs=cl, new_axes=new_axes, res=dump_array(c),
+                            split=dump_array(s)))
+        for perm in ([3, 1, 0, 2], [1, 0, 2, 3]):
+            t = a.transpose(perm)
+            out.append(dict(op='transpose', a=dump_array(a), perm=perm, res=dump_array(t)))
+        s = rng.standard_normal(legs[1].ind_len)
+        out.append(dict(op='scale_axis', a=dump_array(a), s=s, axis=1, res=dump_array(a.scale_axis(s, 1))))
+        mask = rng.rand(legs[3].ind_len) > 0.5
+        mask[0] = True
+        p = a.copy(deep=True)
+        p.iproject(mask, 3)
+        out.append(dict(op='project', a=dump_array(a), mask=mask, axis=3, res=dump_array(p)))
+    save('reshape.pkl', out)
+
+
+def gen_linalg():
+    out = []
+    for mod, cplx in (([1], False), ([1], True), ([3], False)):
+        ch = charges.ChargeInfo(mod)
+        for m, n in ((6, 6), (9, 5), (4, 11)):
+            l0, l1 = rand_leg(ch, m), rand_leg(ch, n, qconj=-1)
+            a = rand_array([l0, l1], labels=['L', 'R'], cplx=cplx, qtotal=[1] * len(mod))
+            U, S, VH = npc.svd(a, inner_labels=['vR', 'vL'])
+            out.append(dict(op='svd', a=dump_array(a), U=dump_array(U), S=np.array(S), VH=dump_array(VH)))
+            Q, R = npc.qr(a, inner_labels=['q', 'r'], pos_diag_R=True)
+            out.append(dict(op='qr', a=dump_array(a), Q=dump_array(Q), R=dump_array(R)))
+        l0 = rand_leg(ch, 9)
+        h = rand_array([l0, l0.conj()], labels=['p', 'p*'], cplx=cplx)
+        h = h + h.conj().itranspose()
+        W, V = npc.eigh(h)
+        out.append(dict(op='eigh', a=dump_array(h), W=np.array(W), V=dump_array(V)))
+        # axpy with different sparsity patterns
+        la, lb = rand_leg(ch, 6), rand_leg(ch, 7, qconj=-1)
+        x = rand_array([la, lb], cplx=cplx)
+        y = rand_array([la, lb], cplx=cplx)
+        x._data = x._data[::2]
+        x._qdata = x._qdata[::2]
+        y._data = y._data[1:]
+        y._qdata = y._qdata[1:]
+        z = x.copy(deep=True)
+        z.iadd_prefactor_other(-0.7, y)
+        out.append(dict(op='axpy', a=dump_array(x), b=dump_array(y), prefactor=-0.7, res=dump_array(z),
+                        norm=npc.norm(z)))
+    save('linalg.pkl', out)
+
+
+def gen_truncate():
+    out = []
+    for n in (1, 5, 40):
+        S = np.abs(rng.standard_normal(n)) * np.exp(-rng.rand(n) * 12)
+        S = S / np.linalg.norm(S)
+        for opts in ({'chi_max': 10, 'svd_min': 1e-8}, {'chi_max': 3, 'chi_min': 2}, {'chi_max': None, 'trunc_cut': 1e-3},
+                     {'chi_max': 7, 'degeneracy_tol': 0.5, 'svd_min': None}, {}):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                mask, norm_new, err = truncation.truncate(S, dict(opts))
+            out.append(dict(S=S, options=opts, mask=np.array(mask), norm_new=float(norm_new), eps=float(err.eps)))
+    save('truncate.pkl', out)
+
+
+def gen_dmrg():
+    from tenpy.algorithms import dmrg
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+
+    def run(model, psi, chi, n_sweeps, name, extra):
+        eng = dmrg.TwoSiteDMRGEngine(psi, model, {
+            'mixer': None, 'combine': True, 'max_N_for_ED': 0,
+            'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10},
+            'lanczos_params': {}, 'max_sweeps': n_sweeps})
+        Es, chis = [], []
+        for s in range(n_sweeps):
+            eng.sweep()
+            Es.append(float(eng.sweep_stats['E'][-1]) if len(eng.sweep_stats['E']) else float(eng.update_stats['E_total'][-1]))
+            chis.append(int(max(psi.chi)))
+        Es = [float(e) for e in Es]
+        upd_E = [float(e) for e in eng.update_stats['E_total']]
+        mid = psi.L // 2
+        rec = dict(name=name, E_sweeps=Es, chi_sweeps=chis, E_updates=upd_E, N_lanczos=list(eng.update_stats['N_lanczos']),
+                   S_mid=np.array(psi.get_SL(mid)), S_ent=np.array(psi.entanglement_entropy()), chi=chi, n_sweeps=n_sweeps,
+                   E_mpo=float(np.real(model.H_MPO.expectation_value(psi))) if hasattr(model, 'H_MPO') else None)
+        rec.update(extra)
+        out.append(rec)
+        print(name, Es[-1], chis[-1])
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 16
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        run(M, psi, 32, 6, 'xxz_L16_chi32', dict(L=L, Jxx=1., Jz=1., hz=0., conserve='Sz', init='neel_updown'))
+        L = 12
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.5, 'hz': 0.1, 'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        run(M, psi, 20, 5, 'xxz_L12_chi20_hz', dict(L=L, Jxx=1., Jz=0.5, hz=0.1, conserve='Sz', init='neel_updown'))
+        L = 32
+        M = TFIChain({'L': L, 'J': 1., 'g': 1., 'bc_MPS': 'finite', 'conserve': None})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+        run(M, psi, 30, 5, 'tfi_L32_chi30', dict(L=L, J=1., g=1., conserve=None, init='all_up'))
+        L = 12
+        M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': 'parity', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+        run(M, psi, 16, 5, 'tfi_parity_L12_chi16', dict(L=L, J=1., g=1.5, conserve='parity', init='all_up'))
+    save('dmrg.pkl', out)
+
+
+def gen_lanczos():
+    """Lanczos on a random hermitian block matrix with Z2 charge, like tests/test_krylov_based.py:32."""
+    from tenpy.linalg.sparse import FlatLinearOperator
+    out = []
+    ch = charges.ChargeInfo([2])
+    for n, cplx in ((20, False), (30, True)):
+        leg = charges.LegCharge.from_qflat(ch, rng.randint(0, 2, size=n).reshape(n, 1)).bunch()[1]
+        H = rand_array([leg, leg.conj()], cplx=cplx, labels=['a', 'a*'])
+        H = H + H.conj().itranspose()
+        psi0 = rand_array([leg], qtotal=[rng.randint(2)], cplx=cplx, labels=['a'])
+
+        class Op:
+            def matvec(self, v):
+                return npc.tensordot(H, v, axes=['a*', 'a'])
+        for opts in ({}, {'N_min': 5, 'N_max': 5}, {'N_max': 40, 'N_cache': 3, 'P_tol': 1e-20}):
+            E0, psi, N = krylov_based.LanczosGroundState(Op(), psi0, dict(opts)).run()
+            out.append(dict(H=dump_array(H), psi0=dump_array(psi0), options=opts, E0=float(E0), N=int(N), psi=dump_array(psi)))
+    save('lanczos.pkl', out)
+
+
+if __name__ == '__main__':
+    print("reference:", tenpy.__version__, tenpy.__file__)
+    gen_charges()
+    gen_tensordot()
+    gen_reshape()
+    gen_linalg()
+    gen_truncate()
+    gen_lanczos()
+    gen_dmrg()

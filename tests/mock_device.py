@@ -12,6 +12,7 @@ shared library.
 """
 import bisect
 import ctypes
+import weakref
 
 import numpy as np
 import scipy.linalg
@@ -24,20 +25,29 @@ MAXD = 6
 
 
 class _Registry:
-    """Maps raw addresses back to the CPU tensors that own them."""
+    """Maps raw addresses back to the (still alive) CPU tensors that own them."""
 
     def __init__(self):
-        self.starts, self.tensors = [], []
+        self.starts, self.refs = [], []
+        self.n_add = 0
+
+    def _purge(self):
+        alive = [(s, r) for s, r in zip(self.starts, self.refs) if r() is not None]
+        self.starts = [s for s, _ in alive]
+        self.refs = [r for _, r in alive]
 
     def add(self, t):
         if t.numel() == 0:
             return t
+        self.n_add += 1
+        if self.n_add % 2000 == 0:
+            self._purge()
         p = t.data_ptr()
         i = bisect.bisect_left(self.starts, p)
+        while i < len(self.starts) and self.starts[i] == p:   # a dead tensor used to live here
+            del self.starts[i], self.refs[i]
         self.starts.insert(i, p)
-        self.tensors.insert(i, t)
-        if len(self.starts) > 20000:
-            self.starts, self.tensors = self.starts[-10000:], self.tensors[-10000:]
+        self.refs.insert(i, weakref.ref(t))
         return t
 
     def view(self, ptr, np_dtype):
@@ -46,13 +56,14 @@ class _Registry:
             return None
         i = bisect.bisect_right(self.starts, ptr) - 1
         while i >= 0:
-            t = self.tensors[i]
-            nbytes = t.numel() * t.element_size()
-            if self.starts[i] <= ptr < self.starts[i] + nbytes:
-                raw = t.reshape(-1).view(torch.uint8).numpy()
-                raw = raw[ptr - self.starts[i]:]
-                isz = np.dtype(np_dtype).itemsize
-                return raw[:len(raw) // isz * isz].view(np_dtype)
+            t = self.refs[i]()
+            if t is not None:
+                nbytes = t.numel() * t.element_size()
+                if self.starts[i] <= ptr < self.starts[i] + nbytes:
+                    raw = t.reshape(-1).view(torch.uint8).numpy()
+                    raw = raw[ptr - self.starts[i]:]
+                    isz = np.dtype(np_dtype).itemsize
+                    return raw[:len(raw) // isz * isz].view(np_dtype)
             i -= 1
         raise KeyError("mock_device: pointer %x not owned by a registered tensor" % ptr)
 
