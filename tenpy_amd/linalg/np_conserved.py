@@ -1304,14 +1304,62 @@ class TensordotPlan:
             a_arena = a.astype(self.dtype)._arena
         if b.dtype != self.dtype:
             b_arena = b.astype(self.dtype)._arena
+        ev = gemm_timer.begin()
         dev.check(dev.lib().tpa_gemm_chain(dev.code(self.dtype), self.tasks_dev.data_ptr(), self.links_dev.data_ptr(),
                                            self.tiles_dev.data_ptr(), self.n_tiles, a_arena.data_ptr(),
                                            b_arena.data_ptr(), out_arena.data_ptr(), dev.stream()), "gemm_chain")
+        gemm_timer.end(ev, self)
         return res
 
 
 _plan_cache = OrderedDict()
 _PLAN_CACHE_SIZE = 512
+
+
+class KernelTimer:
+    """Measures the grouped-GEMM launches with HIP events recorded on the stream the kernel is launched
+    on (bench.py's roofline figure).  Disabled by default: two event records per launch otherwise."""
+
+    def __init__(self):
+        self.enabled = False
+        self.reset()
+
+    def reset(self):
+        self.pending = []
+        self.n_launch = 0
+        self.flops = 0
+        self.bytes_min = 0
+        self.ms = 0.
+
+    def begin(self):
+        if not self.enabled:
+            return None
+        ev = dev.torch().cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, ev0, plan):
+        if ev0 is None:
+            return
+        ev1 = dev.torch().cuda.Event(enable_timing=True)
+        ev1.record()
+        self.pending.append((ev0, ev1))
+        self.n_launch += 1
+        self.flops += plan.flops
+        self.bytes_min += plan.bytes_min
+        if len(self.pending) > 4000:
+            self.collect()
+
+    def collect(self):
+        """Resolve pending event pairs (synchronises)."""
+        if self.pending:
+            self.pending[-1][1].synchronize()
+            self.ms += sum(a.elapsed_time(b) for a, b in self.pending)
+            self.pending = []
+        return self.ms
+
+
+gemm_timer = KernelTimer()
 _tile_shapes = {}
 
 
