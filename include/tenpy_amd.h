@@ -123,6 +123,10 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
                   void *u_base, double *s_dev, void *vh_base, void *work_dev, int64_t work_bytes,
                   int max_sweeps, double tol, int *sweeps_done, void *stream);
 
+/* Algorithm switch for real data: 0 (default) = block Jacobi (16-row MFMA Gram + in-LDS eigen-solve),
+ * 1 = one wavefront per row pair (always used for complex). */
+int tpa_svd_set_algorithm(int pairwise);
+
 /* ---- K6: batched Householder QR (np.linalg.qr per block, np_conserved.py:4190) ----------
  * jobs : int64[n_jobs][8] = {a_off, m, n, q_off, r_off, 0,0,0} (HOST); reduced mode:
  *   Q_b m x k row-major, R_b k x n row-major, k = min(m,n).  A not overwritten. */

@@ -9,6 +9,9 @@ from tenpy_amd.models.spin_chains import xxz_chain_mpo, tfi_chain_mpo, spin_half
 from tenpy_amd.networks.mps import MPS
 from tenpy_amd.algorithms.dmrg import TwoSiteDMRGEngine
 
+from tenpy_amd import _lib
+if os.environ.get('SVD_ALG'):
+    _lib.load().tpa_svd_set_algorithm(int(os.environ['SVD_ALG']))
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 chi = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 4

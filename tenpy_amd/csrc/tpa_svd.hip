@@ -19,6 +19,8 @@
 #include <numeric>
 #include <vector>
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int NT = 256;  // 4 wavefronts = 4 row pairs per workgroup
@@ -55,11 +57,38 @@ __global__ __launch_bounds__(NT) void svd_init_kernel(const SvdJob *__restrict__
     }
 }
 
+// ||A||_F^2 per job (invariant under the rotations): the scale of the absolute part of the stopping rule
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void svd_fro_kernel(const SvdJob *__restrict__ jobs,
+                                                     const double *__restrict__ A, double *__restrict__ fro2) {
+    __shared__ double red[NT / 64];
+    const SvdJob J = jobs[blockIdx.x];
+    const int64_t tot = J.m * J.n * (CPLX ? 2 : 1);
+    const double *a = A + (CPLX ? 2 : 1) * J.a_off;
+    double s = 0;
+    for (int64_t e = threadIdx.x; e < tot; e += NT) s = fma(a[e], a[e], s);
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) fro2[blockIdx.x] = s;
+}
+
+// Stopping rule for a row pair with alpha=|x|^2 >= beta=|y|^2 (either order), gamma = x.conj(y):
+//     |gamma| <= tol * sqrt(min(alpha,beta)) * max( sqrt(max(alpha,beta)), rho * ||A||_F )
+// rho = 0 is the purely relative Hestenes/de Rijk criterion (cosine of the angle <= tol); rho > 0 adds
+// an absolute floor: couplings that can change a singular value by less than ~tol*rho*||A||_F are left
+// alone.  Without the floor the iteration keeps rotating rounding noise among rows whose norm is below
+// ~eps*||A||_F/tol (strongly graded spectra, e.g. DMRG wave functions) and needs 5x more sweeps.
+__device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2, double tol, double floor2) {
+    if (!(a > 0.0) || !(b > 0.0)) return false;
+    const double mn = fmin(a, b), mx = fmax(fmax(a, b), floor2);
+    return g2 > tol * tol * mn * mx;
+}
+
 template <bool CPLX>
 __global__ __launch_bounds__(NT) void svd_round_kernel(const SvdJob *__restrict__ jobs,
                                                        const int2 *__restrict__ pairs, int round,
                                                        double *__restrict__ W, double *__restrict__ G,
-                                                       unsigned int *__restrict__ n_rot) {
+                                                       unsigned int *__restrict__ n_rot,
+                                                       const double *__restrict__ fro2, double rho) {
     const int gw = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int2 jp = pairs[gw];
@@ -110,7 +139,7 @@ __global__ __launch_bounds__(NT) void svd_round_kernel(const SvdJob *__restrict_
     if (CPLX) gi = wave_sum(gi);
     const double g2 = gr * gr + gi * gi;
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    if (!(g2 > tol * tol * a * b) || a == 0.0 || b == 0.0) return;  // already orthogonal (or NaN)
+    if (!svd_needs_rotation(a, b, g2, tol, rho * rho * fro2[jp.x])) return;  // already orthogonal (or NaN)
     const double gabs = sqrt(g2);
     const double zeta = (b - a) / (2.0 * gabs);
     const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -149,6 +178,225 @@ __global__ __launch_bounds__(NT) void svd_round_kernel(const SvdJob *__restrict_
         rot(reinterpret_cast<double2 *>(G) + J.g_off + p * R, reinterpret_cast<double2 *>(G) + J.g_off + q * R, R);
     }
     if (lane == 0) atomicAdd(n_rot, 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Block one-sided Jacobi round (real): one workgroup owns a PAIR of row blocks (2 x 8 rows of W and of G).
+//   phase 1  S = X X^T (16 x 16 Gram of the 16 rows) on the fp64 MFMA, K split over the 4 wavefronts,
+//            row chunks staged through LDS with coalesced 512-B row segments;
+//   phase 2  the 16 x 16 symmetric eigenproblem is solved completely inside the workgroup by cyclic
+//            two-sided Jacobi (one matrix element per thread, round-robin pairs), accumulating the
+//            row transform Q;  rotation angles are the Hestenes angles of the Gram entries;
+//   phase 3  X <- Q X for the rows of W and of G, again as 16x16x4 MFMAs over LDS-staged chunks.
+// Compared with one wavefront per row pair this needs 8x fewer rounds (launches) per sweep and converges
+// in fewer sweeps (every 16-row subproblem is diagonalised exactly).  The Gram matrix is recomputed from
+// the data in every round, so rounding errors of the in-LDS updates do not accumulate.
+constexpr int BRJ = 8;            // rows per block
+constexpr int TRJ = 2 * BRJ;      // rows per workgroup
+constexpr int CHJ = 64;           // columns per staged chunk
+constexpr int CHP = CHJ + 1;      // LDS row pitch of a chunk
+constexpr int NTB = 512;          // 8 wavefronts stream the row panels; 256 threads solve the 16x16 problem
+constexpr int NWB = NTB / 64;
+
+__global__ __launch_bounds__(NTB) void svd_block_round_kernel(const SvdJob *__restrict__ jobs,
+                                                              const int2 *__restrict__ bpairs, int round,
+                                                              double *__restrict__ W, double *__restrict__ G,
+                                                              unsigned int *__restrict__ n_rot,
+                                                              const double *__restrict__ fro2, double rho,
+                                                              int local_sweeps) {
+    __shared__ double Xs[NWB][TRJ][CHP];
+    __shared__ double Sm[TRJ][TRJ + 1], Tm[TRJ][TRJ + 1], Qm[TRJ][TRJ + 1], Qt[TRJ][TRJ + 1];
+    __shared__ int any_flag, sweep_flag;
+    const int2 jp = bpairs[blockIdx.x];
+    if (jp.x < 0) return;
+    const SvdJob J = jobs[jp.x];
+    const int64_t R = J.R, L = J.L;
+    const int64_t NB = (R + BRJ - 1) / BRJ;
+    const int64_t NBp = (NB + 1) / 2 * 2;
+    const int64_t mod = NBp - 1;
+    int64_t bi, bj;
+    {
+        const int64_t r = (mod > 0) ? (round % mod) : 0;
+        const int64_t i = jp.y;
+        if (i == 0) {
+            bi = NBp - 1;
+            bj = r;
+        } else {
+            bi = (r + i) % mod;
+            bj = (r - i + mod) % mod;
+        }
+        if (bi > bj) {
+            const int64_t t = bi;
+            bi = bj;
+            bj = t;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // global row of local row t (or -1)
+    auto grow = [&](int t) -> int64_t {
+        const int64_t b = (t < BRJ) ? bi : bj;
+        const int64_t r = b * BRJ + (t % BRJ);
+        return (b < NB && r < R) ? r : -1;
+    };
+    if (grow(0) < 0 && grow(BRJ) < 0) return;
+    int64_t rowoff[TRJ];  // element offset of each local row inside a row-major (rows x len) matrix / len
+#pragma unroll
+    for (int t = 0; t < TRJ; ++t) rowoff[t] = grow(t);
+
+    // ---- phase 1: Gram -------------------------------------------------------------------------
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    const int64_t nchunk = (L + CHJ - 1) / CHJ;
+    {
+        const double *Wb = W + J.w_off;
+        double reg[TRJ];
+        int64_t c = wave;
+        if (c < nchunk) {
+            const int64_t col = c * CHJ + lane;
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < L) ? Wb[rowoff[t] * L + col] : 0.0;
+        }
+        for (; c < nchunk; c += NWB) {
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
+            const int64_t cn = c + NWB;
+            if (cn < nchunk) {  // prefetch the next chunk while the MFMAs of this one run
+                const int64_t col = cn * CHJ + lane;
+#pragma unroll
+                for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < L) ? Wb[rowoff[t] * L + col] : 0.0;
+            }
+#pragma unroll
+            for (int ks = 0; ks < CHJ / 4; ks += 2) {
+                const double a0 = Xs[wave][l15][ks * 4 + l4];
+                const double a1 = Xs[wave][l15][ks * 4 + 4 + l4];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+            }
+        }
+    }
+    // partial Gram of this wave -> Xs[wave] (reuse) ; rows (l4 + 4 r), col l15
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[wave][l4 + 4 * r][l15] = acc0[r] + acc1[r];
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const int ei = (tid >> 4) & 15, ej = tid & 15;
+    const bool solver = tid < TRJ * TRJ;
+    if (solver) {
+        double sacc = 0;
+#pragma unroll
+        for (int w = 0; w < NWB; ++w) sacc += Xs[w][ei][ej];
+        Sm[ei][ej] = sacc;
+        Qm[ei][ej] = (ei == ej) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+
+    // ---- phase 2: cyclic two-sided Jacobi on the 16 x 16 Gram matrix, one element per thread -----
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[jp.x];
+    // Convergence is judged on the FRESH Gram matrix only (the exact Hestenes criterion on the data);
+    // the in-LDS updates below carry rounding noise and must not decide whether the sweep "rotated".
+    if (solver && ei < ej) {
+        const double a = Sm[ei][ei], b = Sm[ej][ej], g = Sm[ei][ej];
+        if (svd_needs_rotation(a, b, g * g, tol, floor2)) any_flag = 1;
+    }
+    __syncthreads();
+    if (any_flag == 0) return;  // these 16 rows are already mutually orthogonal
+    // rotation of the pair that contains index i in round rr (computed redundantly by every thread that
+    // needs it: no serial section, one barrier less per round).  Returns partner and (c_self, c_partner)
+    // of the row update  x_i' = c_self x_i + c_part x_partner.
+    auto rot_of = [&](int i, int rr, int &pi, double &cs, double &cp) -> bool {
+        if (i == TRJ - 1)
+            pi = rr;
+        else if (i == rr)
+            pi = TRJ - 1;
+        else
+            pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1);
+        const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
+        const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
+        double c = 1.0, s = 0.0;
+        bool did = false;
+        if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
+            const double zeta = (b - a) / (2.0 * g);
+            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = c * t;
+            did = true;
+        }
+        cs = c;
+        cp = (i == p) ? -s : s;  // row p: x' = c x - s y ; row q: y' = s x + c y
+        return did;
+    };
+    for (int sweep = 0; sweep < local_sweeps; ++sweep) {
+        if (tid == 0) sweep_flag = 0;
+        __syncthreads();
+        for (int rr = 0; rr < TRJ - 1; ++rr) {
+            int pi = 0, pj = 0;
+            double csi = 1, cpi = 0, csj = 1, cpj = 0;
+            if (solver) {
+                const bool d1 = rot_of(ei, rr, pi, csi, cpi);
+                rot_of(ej, rr, pj, csj, cpj);
+                if (d1 && ej == 0) sweep_flag = 1;
+                Tm[ei][ej] = csi * Sm[ei][ej] + cpi * Sm[pi][ej];
+                Qt[ei][ej] = csi * Qm[ei][ej] + cpi * Qm[pi][ej];
+            }
+            __syncthreads();
+            if (solver) {
+                Sm[ei][ej] = csj * Tm[ei][ej] + cpj * Tm[ei][pj];
+                Qm[ei][ej] = Qt[ei][ej];
+            }
+            __syncthreads();
+        }
+        if (sweep_flag == 0) break;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) atomicAdd(n_rot, 1u);
+
+    // ---- phase 3: X <- Q X on the rows of W, then of G --------------------------------------------
+    double qa[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qa[kk] = Qm[l15][kk * 4 + l4];  // A fragment of Q for k-step kk
+    for (int pass = 0; pass < 2; ++pass) {
+        double *M = (pass == 0) ? (W + J.w_off) : (G + J.g_off);
+        const int64_t len = (pass == 0) ? L : R;
+        const int64_t nch = (len + CHJ - 1) / CHJ;
+        double reg[TRJ];
+        int64_t c = wave;
+        if (c < nch) {
+            const int64_t col = c * CHJ + lane;
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
+        }
+        for (; c < nch; c += NWB) {
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
+            const int64_t cn = c + NWB;
+            if (cn < nch) {
+                const int64_t col = cn * CHJ + lane;
+#pragma unroll
+                for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
+            }
+            d4 o[CHJ / 16];
+#pragma unroll
+            for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int tile = 0; tile < CHJ / 16; ++tile) {
+                    const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
+                    o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
+                }
+#pragma unroll
+            for (int tile = 0; tile < CHJ / 16; ++tile) {
+                const int64_t oc = c * CHJ + tile * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gr = rowoff[l4 + 4 * r];
+                    if (gr >= 0 && oc < len) M[gr * len + oc] = o[tile][r];
+                }
+            }
+        }
+    }
 }
 
 template <bool CPLX>
@@ -215,14 +463,19 @@ __global__ __launch_bounds__(NT) void svd_finish_kernel(const SvdJob *__restrict
     }
 }
 
+int tpa_svd_local_sweeps = 1;
+int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
+
 struct Layout {
     std::vector<SvdJob> jobs;
     std::vector<int2> rows;   // (job,row) per wavefront, padded to multiple of 4 with (-1,-1)
     std::vector<int2> pairs;  // (job,pair)
+    std::vector<int2> bpairs; // (job, block pair) for the block-Jacobi rounds
+    int64_t nb_max_pad = 0;
     int64_t w_elems = 0, g_elems = 0, sig_elems = 0, rmax_pad = 0;
     // byte offsets inside work buffer
     int64_t off_w = 0, off_g = 0, off_sig = 0, off_perm = 0, off_jobs = 0, off_rows = 0, off_pairs = 0,
-            off_cnt = 0, total = 0;
+            off_bpairs = 0, off_cnt = 0, off_fro = 0, total = 0;
 };
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -251,6 +504,11 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         lay.rmax_pad = std::max(lay.rmax_pad, J.Rpad);
         for (int64_t r = 0; r < J.R; ++r) lay.rows.push_back(int2{b, (int)r});
         for (int64_t p = 0; p < J.Rpad / 2; ++p) lay.pairs.push_back(int2{b, (int)p});
+        {
+            const int64_t NB = (J.R + 7) / 8, NBp = (NB + 1) / 2 * 2;
+            for (int64_t p = 0; p < NBp / 2; ++p) lay.bpairs.push_back(int2{b, (int)p});
+            lay.nb_max_pad = std::max(lay.nb_max_pad, NBp);
+        }
         lay.jobs.push_back(J);
     }
     while (lay.rows.size() % (NT / 64)) lay.rows.push_back(int2{-1, -1});
@@ -270,15 +528,19 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.rows.size() * sizeof(int2), 256);
     lay.off_pairs = o;
     o = align_up(o + (int64_t)lay.pairs.size() * sizeof(int2), 256);
+    lay.off_bpairs = o;
+    o = align_up(o + (int64_t)lay.bpairs.size() * sizeof(int2), 256);
     lay.off_cnt = o;
     o = align_up(o + 256, 256);
+    lay.off_fro = o;
+    o = align_up(o + (int64_t)lay.jobs.size() * 8, 256);
     lay.total = o;
     return lay;
 }
 
 template <bool CPLX>
 int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, double *s_dev,
-            void *vh_base, char *work, int max_sweeps, int *sweeps_done, hipStream_t st) {
+            void *vh_base, char *work, int max_sweeps, int *sweeps_done, hipStream_t st, double rho) {
     double *W = (double *)(work + lay.off_w);
     double *G = (double *)(work + lay.off_g);
     double *sig = (double *)(work + lay.off_sig);
@@ -290,6 +552,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     TPA_HIP_CHECK(hipMemcpyAsync(jobs, lay.jobs.data(), lay.jobs.size() * sizeof(SvdJob), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(rows, lay.rows.data(), lay.rows.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(pairs, lay.pairs.data(), lay.pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    int2 *bpairs = (int2 *)(work + lay.off_bpairs);
+    TPA_HIP_CHECK(hipMemcpyAsync(bpairs, lay.bpairs.data(), lay.bpairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     // pageable host memory: the copies above are staged before returning, vectors may die later.
     const int g_rows = (int)(lay.rows.size() / (NT / 64));
     const int g_pairs = (int)(lay.pairs.size() / (NT / 64));
@@ -299,13 +563,21 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     }
     svd_init_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, (const double *)a_base, W, G);
     TPA_LAUNCH_CHECK();
+    double *fro2 = (double *)(work + lay.off_fro);
+    svd_fro_kernel<CPLX><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, fro2);
+    TPA_LAUNCH_CHECK();
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
-    const int rounds = (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
+    const bool use_block = !CPLX && !tpa_svd_force_pairwise;
+    const int rounds = use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1)
+                                 : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
-            svd_round_kernel<CPLX><<<g_pairs, NT, 0, st>>>(jobs, pairs, r, W, G, cnt);
+            if (use_block)
+                svd_block_round_kernel<<<(int)lay.bpairs.size(), NTB, 0, st>>>(jobs, bpairs, r, W, G, cnt, fro2, rho, tpa_svd_local_sweeps);
+            else
+                svd_round_kernel<CPLX><<<g_pairs, NT, 0, st>>>(jobs, pairs, r, W, G, cnt, fro2, rho);
         }
         TPA_LAUNCH_CHECK();
         unsigned int h = 0;
@@ -357,7 +629,7 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
                              void *u_base, double *s_dev, void *vh_base, void *work_dev,
                              int64_t work_bytes, int max_sweeps, double tol, int *sweeps_done,
                              void *stream) {
-    (void)tol;
+    TPA_ARG_CHECK(tol >= 0.0 && tol <= 1.0);
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
     for (int b = 0; b < n_jobs; ++b) TPA_ARG_CHECK(jobs_host[8 * b + 1] > 0 && jobs_host[8 * b + 2] > 0);
@@ -365,8 +637,8 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
     TPA_ARG_CHECK(work_bytes >= lay.total);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == TPA_F64)
-        return svd_run<false>(lay, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st);
-    return svd_run<true>(lay, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st);
+        return svd_run<false>(lay, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
+    return svd_run<true>(lay, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
 }
 
 // ================================================================================================
@@ -507,18 +779,24 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
         eigh_shift_kernel<false><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, (double *)(work + lay.off_ap), mu);
         TPA_LAUNCH_CHECK();
         rc = svd_run<false>(slay, n_jobs, work + lay.off_ap, work + lay.off_u, (double *)(work + lay.off_s),
-                            work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st);
+                            work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st, 0.0);
         if (rc != 0) return rc;
         eigh_finish_kernel<false><<<n_jobs, NT, 0, st>>>(jobs, (const double *)(work + lay.off_u), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base);
     } else {
         eigh_shift_kernel<true><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, (double *)(work + lay.off_ap), mu);
         TPA_LAUNCH_CHECK();
         rc = svd_run<true>(slay, n_jobs, work + lay.off_ap, work + lay.off_u, (double *)(work + lay.off_s),
-                           work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st);
+                           work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st, 0.0);
         if (rc != 0) return rc;
         eigh_finish_kernel<true><<<n_jobs, NT, 0, st>>>(jobs, (const double *)(work + lay.off_u), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base);
     }
     TPA_LAUNCH_CHECK();
     TPA_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int tpa_svd_set_algorithm(int pairwise) {
+    tpa_svd_force_pairwise = (pairwise & 1) ? 1 : 0;
+    if (pairwise >= 16) tpa_svd_local_sweeps = pairwise >> 4;   // test hook: local sweeps in bits 4..
     return 0;
 }
