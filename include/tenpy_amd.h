@@ -46,12 +46,12 @@ const char *tpa_last_error(void);
  *          (one of a_rs/a_ks and one of b_ks/b_ns should be 1 for coalescing; any strides are legal)
  *          flags bit0: conj(A), bit1: conj(B)   (complex only)
  * tasks  : int64[n_tasks][8]  = {c_off, m, n, ldc, link_begin, link_count, accumulate, 0}
- * tiles  : int32[n_tiles][4]  = {task, tile_row, tile_col, 0}   (tile = TPA_GEMM_BM x TPA_GEMM_BN)
+ * tiles  : int32[n_tiles][4]  = {task, tile_row, tile_col, 0}   (tile shape: tpa_gemm_tile_shape(dtype, cfg))
+ * cfg    : 0 = large tiles (128 x 128 real), 1 = small tiles (64 x 64 real) -- chosen per plan by the host
+ *          so that the launch has enough workgroups for 256 CUs.
  * All three tables live on the DEVICE (uploaded once per cached contraction plan).
  */
-#define TPA_GEMM_BM 128
-#define TPA_GEMM_BN 128
-int tpa_gemm_chain(int dtype, const int64_t *tasks_dev, const int64_t *links_dev,
+int tpa_gemm_chain(int dtype, int cfg, const int64_t *tasks_dev, const int64_t *links_dev,
                    const int32_t *tiles_dev, int n_tiles, const void *Abase, const void *Bbase,
                    void *Cbase, void *stream);
 
@@ -106,8 +106,10 @@ int tpa_gather_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_
  * iconj's complex_conj (np_conserved.py:2202-2235).  c128->f64 keeps the real part. */
 int tpa_convert(int from_dtype, int to_dtype, int64_t n, const void *src_dev, void *dst_dev, int conj,
                 void *stream);
-/* Tile shape (rows, cols of C per workgroup) the GEMM kernel of `dtype` was built with. */
-int tpa_gemm_tile_shape(int dtype, int *bm, int *bn);
+/* Tile shape (rows, cols of C per workgroup) of GEMM configuration `cfg` for `dtype`. */
+int tpa_gemm_tile_shape(int dtype, int cfg, int *bm, int *bn);
+/* Tuning hook: variant of the large-tile real kernel (0: 4 waves x 64x64, 1: 8 waves x 64x32). */
+int tpa_gemm_set_variant(int v);
 
 /* ---- K5: batched block SVD, one-sided (Hestenes) Jacobi -- replaces svd_flat / LAPACK gesdd
  *      per charge block (np_conserved.py:4970-4980 via svd_robust.py:36-75) ---------------

@@ -23,8 +23,9 @@ _SIGS = {
     "tpa_version": (ctypes.c_int, []),
     "tpa_last_error": (ctypes.c_char_p, []),
     "tpa_device_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _i64p]),
-    "tpa_gemm_tile_shape": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
-    "tpa_gemm_chain": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "tpa_gemm_tile_shape": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "tpa_gemm_set_variant": (ctypes.c_int, [ctypes.c_int]),
+    "tpa_gemm_chain": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "tpa_axpy": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _vp, _vp, _vp]),
     "tpa_scal": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "tpa_dot": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),

@@ -45,6 +45,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN>::NT)) void gemm_chain_ke
     const double *__restrict__ Abase, const double *__restrict__ Bbase, double *__restrict__ Cbase) {
     using C = Cfg<CPLX, BM, BN, TM, TN>;
     constexpr int NT = C::NT, EA = C::EA, EB = C::EB, PL = C::PLANES;
+    constexpr int ES = CPLX ? 2 : 1;  // doubles per element
     __shared__ double lds[PL * (C::A_LDS + C::B_LDS)];
     double *As = lds;
     double *Bs = lds + PL * C::A_LDS;
@@ -65,135 +66,122 @@ __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN>::NT)) void gemm_chain_ke
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[p][i][j] = d4{0, 0, 0, 0};
 
-    // ---- chain iteration state: (link index, k0) --------------------------------------------
-    int li = 0;
     const int nl = (int)tk.link_count;
     const Link *lk = links + tk.link_begin;
-    // skip empty links
-    while (li < nl && lk[li].k <= 0) ++li;
-    int k0 = 0;
 
-    double ra[PL][EA], rb[PL][EB];
-    int lsa_i = 0, lsa_k = 0, lsb_k = 0, lsb_j = 0;  // LDS strides of the *staged* tile
-
-    auto load_global = [&](int li_, int k0_, int &sa_i, int &sa_k, int &sb_k, int &sb_j) {
-        const Link L = lk[li_];
-        const int kk_tot = (int)L.k;
+    for (int li = 0; li < nl; ++li) {
+        const Link L = lk[li];
+        const int K = (int)L.k;
+        if (K <= 0) continue;
+        // ---- per-link setup: everything that does not depend on k0 ----------------------------
         const bool a_kfast = (L.a_ks == 1);
         const bool b_kfast = (L.b_ks == 1) && (L.b_ns != 1);
         const double sgn_a = (CPLX && (L.flags & 1)) ? -1.0 : 1.0;
         const double sgn_b = (CPLX && (L.flags & 2)) ? -1.0 : 1.0;
-        sa_i = a_kfast ? (BK + 1) : 1;
-        sa_k = a_kfast ? 1 : (BM + C::PADA);
-        sb_j = b_kfast ? (BK + 1) : 1;
-        sb_k = b_kfast ? 1 : (BN + C::PADB);
-        const double *Ap = Abase + (CPLX ? 2 : 1) * L.a_off;
-        const double *Bp = Bbase + (CPLX ? 2 : 1) * L.b_off;
+        const int sa_i = a_kfast ? (BK + 1) : 1, sa_k = a_kfast ? 1 : (BM + C::PADA);
+        const int sb_j = b_kfast ? (BK + 1) : 1, sb_k = b_kfast ? 1 : (BN + C::PADB);
+        const double *Ap = Abase + ES * (L.a_off + (int64_t)row0 * L.a_rs);
+        const double *Bp = Bbase + ES * (L.b_off + (int64_t)col0 * L.b_ns);
+        const int64_t a_kstep = ES * (int64_t)BK * L.a_ks, b_kstep = ES * (int64_t)BK * L.b_ks;
+        int64_t offA[EA], offB[EB];   // element offsets (in doubles) of this thread's staged elements
+        int ldA[EA], ldB[EB];         // LDS positions
+        int kkA[EA], kkB[EB];         // k index inside the tile (for the tail k-tile)
+        bool okA[EA], okB[EB];        // row / column inside the block
 #pragma unroll
         for (int r = 0; r < EA; ++r) {
             const int e = tid + r * NT;
             const int i = a_kfast ? (e / BK) : (e % BM);
             const int kk = a_kfast ? (e % BK) : (e / BM);
-            const bool ok = (row0 + i < m) && (k0_ + kk < kk_tot);
-            const int64_t g = (int64_t)(row0 + i) * L.a_rs + (int64_t)(k0_ + kk) * L.a_ks;
-            if (CPLX) {
-                double2 v = ok ? *reinterpret_cast<const double2 *>(Ap + 2 * g) : double2{0, 0};
-                ra[0][r] = v.x;
-                ra[PL - 1][r] = sgn_a * v.y;
-            } else {
-                ra[0][r] = ok ? Ap[g] : 0.0;
-            }
+            offA[r] = ES * ((int64_t)i * L.a_rs + (int64_t)kk * L.a_ks);
+            ldA[r] = i * sa_i + kk * sa_k;
+            kkA[r] = kk;
+            okA[r] = (row0 + i < m);
         }
 #pragma unroll
         for (int r = 0; r < EB; ++r) {
             const int e = tid + r * NT;
             const int j = b_kfast ? (e / BK) : (e % BN);
             const int kk = b_kfast ? (e % BK) : (e / BN);
-            const bool ok = (col0 + j < n) && (k0_ + kk < kk_tot);
-            const int64_t g = (int64_t)(k0_ + kk) * L.b_ks + (int64_t)(col0 + j) * L.b_ns;
-            if (CPLX) {
-                double2 v = ok ? *reinterpret_cast<const double2 *>(Bp + 2 * g) : double2{0, 0};
-                rb[0][r] = v.x;
-                rb[PL - 1][r] = sgn_b * v.y;
-            } else {
-                rb[0][r] = ok ? Bp[g] : 0.0;
+            offB[r] = ES * ((int64_t)kk * L.b_ks + (int64_t)j * L.b_ns);
+            ldB[r] = kk * sb_k + j * sb_j;
+            kkB[r] = kk;
+            okB[r] = (col0 + j < n);
+        }
+        const double *Aw = As + (wr * TM * 16 + l15) * sa_i + l4 * sa_k;
+        const double *Bw = Bs + (wc * TN * 16 + l15) * sb_j + l4 * sb_k;
+
+        double ra[PL][EA], rb[PL][EB];
+        auto load_tile = [&](int k0) {
+            const int krem = K - k0;  // >= 1
+            const bool full = (krem >= BK);
+#pragma unroll
+            for (int r = 0; r < EA; ++r) {
+                const bool ok = okA[r] && (full || kkA[r] < krem);
+                if (CPLX) {
+                    double2 v = ok ? *reinterpret_cast<const double2 *>(Ap + offA[r]) : double2{0, 0};
+                    ra[0][r] = v.x;
+                    ra[PL - 1][r] = sgn_a * v.y;
+                } else {
+                    ra[0][r] = ok ? Ap[offA[r]] : 0.0;
+                }
             }
-        }
-    };
+#pragma unroll
+            for (int r = 0; r < EB; ++r) {
+                const bool ok = okB[r] && (full || kkB[r] < krem);
+                if (CPLX) {
+                    double2 v = ok ? *reinterpret_cast<const double2 *>(Bp + offB[r]) : double2{0, 0};
+                    rb[0][r] = v.x;
+                    rb[PL - 1][r] = sgn_b * v.y;
+                } else {
+                    rb[0][r] = ok ? Bp[offB[r]] : 0.0;
+                }
+            }
+            Ap += a_kstep;
+            Bp += b_kstep;
+        };
 
-    auto store_lds = [&](int sa_i, int sa_k, int sb_k, int sb_j) {
-        const bool a_kfast = (sa_k == 1);
-        const bool b_kfast = (sb_k == 1);
+        load_tile(0);
+        for (int k0 = 0; k0 < K; k0 += BK) {
 #pragma unroll
-        for (int r = 0; r < EA; ++r) {
-            const int e = tid + r * NT;
-            const int i = a_kfast ? (e / BK) : (e % BM);
-            const int kk = a_kfast ? (e % BK) : (e / BM);
+            for (int r = 0; r < EA; ++r)
 #pragma unroll
-            for (int p = 0; p < PL; ++p) As[p * C::A_LDS + i * sa_i + kk * sa_k] = ra[p][r];
-        }
+                for (int p = 0; p < PL; ++p) As[p * C::A_LDS + ldA[r]] = ra[p][r];
 #pragma unroll
-        for (int r = 0; r < EB; ++r) {
-            const int e = tid + r * NT;
-            const int j = b_kfast ? (e / BK) : (e % BN);
-            const int kk = b_kfast ? (e % BK) : (e / BN);
+            for (int r = 0; r < EB; ++r)
 #pragma unroll
-            for (int p = 0; p < PL; ++p) Bs[p * C::B_LDS + kk * sb_k + j * sb_j] = rb[p][r];
-        }
-    };
-
-    bool have = (li < nl);
-    if (have) load_global(li, k0, lsa_i, lsa_k, lsb_k, lsb_j);
-
-    while (have) {
-        // stage the prefetched registers
-        const int ca_i = lsa_i, ca_k = lsa_k, cb_k = lsb_k, cb_j = lsb_j;
-        store_lds(ca_i, ca_k, cb_k, cb_j);
-        __syncthreads();
-        // advance and prefetch next k-tile into registers
-        k0 += BK;
-        if (k0 >= (int)lk[li].k) {
-            k0 = 0;
-            ++li;
-            while (li < nl && lk[li].k <= 0) ++li;
-        }
-        have = (li < nl);
-        if (have) load_global(li, k0, lsa_i, lsa_k, lsb_k, lsb_j);
-
-        // MFMA on the staged tile
-        const double *Aw = As + (wr * TM * 16 + l15) * ca_i + l4 * ca_k;
-        const double *Bw = Bs + (wc * TN * 16 + l15) * cb_j + l4 * cb_k;
+                for (int p = 0; p < PL; ++p) Bs[p * C::B_LDS + ldB[r]] = rb[p][r];
+            __syncthreads();
+            if (k0 + BK < K) load_tile(k0 + BK);  // prefetch the next k-tile into registers
 #pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            double a[PL][TM], b[PL][TN];
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                double a[PL][TM], b[PL][TN];
 #pragma unroll
-            for (int p = 0; p < PL; ++p) {
+                for (int p = 0; p < PL; ++p) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[p][i] = Aw[p * C::A_LDS + i * 16 * sa_i + ks * 4 * sa_k];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[p][j] = Bw[p * C::B_LDS + j * 16 * sb_j + ks * 4 * sb_k];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    a[p][i] = Aw[p * C::A_LDS + i * 16 * ca_i + ks * 4 * ca_k];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b[p][j] = Bw[p * C::B_LDS + j * 16 * cb_j + ks * 4 * cb_k];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (CPLX) {
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[PL - 1][i], b[PL - 1][j], acc[0][i][j], 0, 0, 0);
-                        acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[PL - 1][j], acc[PL - 1][i][j], 0, 0, 0);
-                        acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[PL - 1][i], b[0][j], acc[PL - 1][i][j], 0, 0, 0);
-                    } else {
-                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if (CPLX) {
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[PL - 1][i], b[PL - 1][j], acc[0][i][j], 0, 0, 0);
+                            acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[PL - 1][j], acc[PL - 1][i][j], 0, 0, 0);
+                            acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[PL - 1][i], b[0][j], acc[PL - 1][i][j], 0, 0, 0);
+                        } else {
+                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
+                        }
                     }
-                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- epilogue: C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
-    double *Cp = Cbase + (CPLX ? 2 : 1) * tk.c_off;
+    double *Cp = Cbase + ES * tk.c_off;
     const bool accum = tk.accumulate != 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -225,33 +213,54 @@ __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN>::NT)) void gemm_chain_ke
 
 }  // namespace
 
-extern "C" int tpa_gemm_tile_shape(int dtype, int *bm, int *bn) {
+static int g_large_variant = 1;  // 0: 4 waves x (64x64), 1: 8 waves x (64x32); test/tuning hook
+
+extern "C" int tpa_gemm_set_variant(int v) {
+    g_large_variant = v;
+    return 0;
+}
+
+// cfg 0: 128 x 128 tiles (large blocks), cfg 1: 64 x 64 tiles (many small blocks / not enough tiles to
+// fill 256 CUs).  complex: 128 x 64 and 64 x 32.
+extern "C" int tpa_gemm_tile_shape(int dtype, int cfg, int *bm, int *bn) {
     if (dtype == TPA_F64) {
-        *bm = 128;
-        *bn = 128;
+        *bm = cfg ? 64 : 128;
+        *bn = cfg ? 64 : 128;
     } else {
-        *bm = 128;
-        *bn = 64;
+        *bm = cfg ? 64 : 128;
+        *bn = cfg ? 32 : 64;
     }
     return 0;
 }
 
-extern "C" int tpa_gemm_chain(int dtype, const int64_t *tasks_dev, const int64_t *links_dev,
+template <bool CPLX, int BM, int BN, int TM, int TN>
+static void launch(const int64_t *tasks_dev, const int64_t *links_dev, const int32_t *tiles_dev, int n_tiles,
+                   const void *Abase, const void *Bbase, void *Cbase, hipStream_t st) {
+    using C = Cfg<CPLX, BM, BN, TM, TN>;
+    gemm_chain_kernel<CPLX, BM, BN, TM, TN><<<n_tiles, C::NT, 0, st>>>(
+        (const Task *)tasks_dev, (const Link *)links_dev, (const int4 *)tiles_dev, (const double *)Abase,
+        (const double *)Bbase, (double *)Cbase);
+}
+
+extern "C" int tpa_gemm_chain(int dtype, int cfg, const int64_t *tasks_dev, const int64_t *links_dev,
                               const int32_t *tiles_dev, int n_tiles, const void *Abase,
                               const void *Bbase, void *Cbase, void *stream) {
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    TPA_ARG_CHECK(cfg == 0 || cfg == 1);
     if (n_tiles <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == TPA_F64) {
-        using C = Cfg<false, 128, 128, 4, 4>;
-        gemm_chain_kernel<false, 128, 128, 4, 4><<<n_tiles, C::NT, 0, st>>>(
-            (const Task *)tasks_dev, (const Link *)links_dev, (const int4 *)tiles_dev,
-            (const double *)Abase, (const double *)Bbase, (double *)Cbase);
+        if (cfg == 1)
+            launch<false, 64, 64, 2, 2>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (g_large_variant == 1)
+            launch<false, 128, 128, 4, 2>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else
+            launch<false, 128, 128, 4, 4>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
     } else {
-        using C = Cfg<true, 128, 64, 4, 2>;
-        gemm_chain_kernel<true, 128, 64, 4, 2><<<n_tiles, C::NT, 0, st>>>(
-            (const Task *)tasks_dev, (const Link *)links_dev, (const int4 *)tiles_dev,
-            (const double *)Abase, (const double *)Bbase, (double *)Cbase);
+        if (cfg == 1)
+            launch<true, 64, 32, 2, 1>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else
+            launch<true, 128, 64, 4, 2>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
     }
     TPA_LAUNCH_CHECK();
     return 0;

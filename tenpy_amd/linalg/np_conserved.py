@@ -1305,7 +1305,7 @@ class TensordotPlan:
         if b.dtype != self.dtype:
             b_arena = b.astype(self.dtype)._arena
         ev = gemm_timer.begin()
-        dev.check(dev.lib().tpa_gemm_chain(dev.code(self.dtype), self.tasks_dev.data_ptr(), self.links_dev.data_ptr(),
+        dev.check(dev.lib().tpa_gemm_chain(dev.code(self.dtype), self.cfg, self.tasks_dev.data_ptr(), self.links_dev.data_ptr(),
                                            self.tiles_dev.data_ptr(), self.n_tiles, a_arena.data_ptr(),
                                            b_arena.data_ptr(), out_arena.data_ptr(), dev.stream()), "gemm_chain")
         gemm_timer.end(ev, self)
@@ -1363,13 +1363,17 @@ gemm_timer = KernelTimer()
 _tile_shapes = {}
 
 
-def _gemm_tile(dtype):
-    c = dev.code(dtype)
+def _gemm_tile(dtype, cfg):
+    c = (dev.code(dtype), cfg)
     if c not in _tile_shapes:
         bm, bn = dev.c_int(), dev.c_int()
-        dev.lib().tpa_gemm_tile_shape(c, dev.byref(bm), dev.byref(bn))
+        dev.lib().tpa_gemm_tile_shape(c[0], cfg, dev.byref(bm), dev.byref(bn))
         _tile_shapes[c] = (bm.value, bn.value)
     return _tile_shapes[c]
+
+
+FORCE_GEMM_CFG = None           # tuning hook
+GEMM_MIN_LARGE_TILES = 2048    # below this many 128x128 tiles the 64x64 configuration fills the 256 CUs better
 
 
 def _plan_host(a_qdata, b_qdata, ncontr, contr_nblocks):
@@ -1527,10 +1531,20 @@ def _build_plan(a, b, ca, cb, fa, fb):
     tasks[:, 1], tasks[:, 2], tasks[:, 3] = m_res, n_res, n_res
     tasks[:, 4], tasks[:, 5] = first, counts
     # tiles, heaviest chains first
-    bm, bn = _gemm_tile(plan.dtype)
     ksum = np.add.reduceat(K[ga], first)
-    tm, tn = (m_res + bm - 1) // bm, (n_res + bn - 1) // bn
-    ntile = tm * tn
+    plan.cfg = 0
+    for cfg in (0, 1):
+        bm, bn = _gemm_tile(plan.dtype, cfg)
+        tm, tn = (m_res + bm - 1) // bm, (n_res + bn - 1) // bn
+        ntile = tm * tn
+        plan.cfg = cfg
+        if int(np.sum(ntile)) >= GEMM_MIN_LARGE_TILES or FORCE_GEMM_CFG == 0:
+            break
+    if FORCE_GEMM_CFG is not None and plan.cfg != FORCE_GEMM_CFG:
+        plan.cfg = FORCE_GEMM_CFG
+        bm, bn = _gemm_tile(plan.dtype, plan.cfg)
+        tm, tn = (m_res + bm - 1) // bm, (n_res + bn - 1) // bn
+        ntile = tm * tn
     t_task = np.repeat(np.arange(nres), ntile)
     local = np.arange(int(np.sum(ntile))) - np.repeat(np.cumsum(ntile) - ntile, ntile)
     t_row = local // np.repeat(tn, ntile)

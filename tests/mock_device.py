@@ -89,14 +89,14 @@ class MockLib:
         return getattr(self.real, name)
 
     # ---- K1 --------------------------------------------------------------------------------------
-    def tpa_gemm_chain(self, code, tasks_p, links_p, tiles_p, n_tiles, A_p, B_p, C_p, stream):
+    def tpa_gemm_chain(self, code, cfg, tasks_p, links_p, tiles_p, n_tiles, A_p, B_p, C_p, stream):
         dt = _npdt(code)
         tiles = REG.view(tiles_p, np.int32)[:4 * n_tiles].reshape(n_tiles, 4)
         tasks_all = REG.view(tasks_p, np.int64)
         links_all = REG.view(links_p, np.int64)
         A, B, C = REG.view(A_p, dt), REG.view(B_p, dt), REG.view(C_p, dt)
         bm, bn = ctypes.c_int(), ctypes.c_int()
-        self.real.tpa_gemm_tile_shape(code, ctypes.byref(bm), ctypes.byref(bn))
+        self.real.tpa_gemm_tile_shape(code, cfg, ctypes.byref(bm), ctypes.byref(bn))
         bm, bn = bm.value, bn.value
         for t, tr, tc, _ in tiles:
             c_off, m, n, ldc, lb, lc, acc, _ = tasks_all[8 * t:8 * t + 8]

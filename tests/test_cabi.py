@@ -58,5 +58,6 @@ def test_tile_shape():
     lib = _lib.load()
     bm, bn = ctypes.c_int(), ctypes.c_int()
     for code in (0, 1):
-        assert lib.tpa_gemm_tile_shape(code, ctypes.byref(bm), ctypes.byref(bn)) == 0
-        assert bm.value % 16 == 0 and bn.value % 16 == 0
+        for cfg in (0, 1):
+            assert lib.tpa_gemm_tile_shape(code, cfg, ctypes.byref(bm), ctypes.byref(bn)) == 0
+            assert bm.value % 16 == 0 and bn.value % 16 == 0

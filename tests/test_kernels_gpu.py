@@ -20,9 +20,9 @@ def _dev(torch, arr):
     return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
 
 
-def _run_gemm(torch, lib, _lib, dtype, tasks, links, A, B, C):
+def _run_gemm(torch, lib, _lib, dtype, tasks, links, A, B, C, cfg=0):
     bm, bn = ctypes.c_int(), ctypes.c_int()
-    lib.tpa_gemm_tile_shape(dtype, ctypes.byref(bm), ctypes.byref(bn))
+    lib.tpa_gemm_tile_shape(dtype, cfg, ctypes.byref(bm), ctypes.byref(bn))
     tiles = []
     for t, tk in enumerate(tasks):
         m, n = tk[1], tk[2]
@@ -33,15 +33,16 @@ def _run_gemm(torch, lib, _lib, dtype, tasks, links, A, B, C):
     links_d = _dev(torch, np.array(links, np.int64))
     tiles_d = _dev(torch, np.array(tiles, np.int32))
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.tpa_gemm_chain(dtype, tasks_d.data_ptr(), links_d.data_ptr(), tiles_d.data_ptr(), len(tiles),
+    _lib.check(lib.tpa_gemm_chain(dtype, cfg, tasks_d.data_ptr(), links_d.data_ptr(), tiles_d.data_ptr(), len(tiles),
                                   A.data_ptr(), B.data_ptr(), C.data_ptr(), st), "gemm")
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("cfg", [0, 1])
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("shape", [(1, 1, 1), (3, 5, 7), (16, 16, 16), (37, 129, 65), (128, 128, 64), (130, 131, 17),
                                    (300, 257, 290), (543, 545, 1086)])
-def test_gemm_single(env, cplx, shape):
+def test_gemm_single(env, cplx, shape, cfg):
     torch, lib, _lib = env
     m, n, k = shape
     g = torch.Generator(device="cpu").manual_seed(m * 1000 + n * 10 + k)
@@ -51,14 +52,15 @@ def test_gemm_single(env, cplx, shape):
     C = torch.full((m, n), float("nan"), dtype=dt).cuda()
     links = [[0, 0, k, k, 1, n, 1, 0]]
     tasks = [[0, m, n, n, 0, 1, 0, 0]]
-    _run_gemm(torch, lib, _lib, int(cplx), tasks, links, A, B, C)
+    _run_gemm(torch, lib, _lib, int(cplx), tasks, links, A, B, C, cfg)
     ref = A @ B
     err = (C - ref).abs().max().item()
     assert err <= 1e-13 * k * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("cfg", [0, 1])
 @pytest.mark.parametrize("cplx", [False, True])
-def test_gemm_strided_chain_accumulate(env, cplx):
+def test_gemm_strided_chain_accumulate(env, cplx, cfg):
     """transposed operands (m-fast A, k-fast B), conj flags, a 3-link chain and accumulate=1."""
     torch, lib, _lib = env
     g = torch.Generator(device="cpu").manual_seed(7)
@@ -83,7 +85,7 @@ def test_gemm_strided_chain_accumulate(env, cplx):
              [a_offs[1], b_offs[1], ks[1], 1, m, 1, ks[1], fl[1]],
              [a_offs[2], b_offs[2], ks[2], ks[2], 1, n, 1, fl[2]]]
     tasks = [[0, m, n, n, 0, 3, 1, 0]]
-    _run_gemm(torch, lib, _lib, int(cplx), tasks, links, Aar, Bar, C)
+    _run_gemm(torch, lib, _lib, int(cplx), tasks, links, Aar, Bar, C, cfg)
 
     def cj(x, f):
         return x.conj() if f else x
