@@ -6,7 +6,7 @@
 Workload (config["workload"]): spin-1/2 Heisenberg chain (XXZ, Jxx=Jz=1, hz=0, Sz conserved), L=100,
 two-site DMRG at bond dimension chi (default 2048, BASELINE.json's headline configuration; fits one
 GPU), Lanczos with N_min=N_max=8 (fixed work per bond, as tests/benchmark/dmrg_infinite.py:36 of the
-reference does), svd_min=1e-12, no mixer.  A "step" is ONE FULL SWEEP = 2(L-2) = 196 two-site bond
+reference does), svd_min=1e-14 (the reference's default, so that the bond dimension really saturates at chi), no mixer.  A "step" is ONE FULL SWEEP = 2(L-2) = 196 two-site bond
 updates (effective-H build, 8-step Lanczos, block SVD + truncation, environment update).
 
 The MPS is synthetic in the sense of the contract: there is no checkpoint to load, so the state is grown
@@ -52,7 +52,6 @@ def oracle_tensor(arr):
     """Device Array -> oracle OTensor (host copies of the blocks)."""
     from oracle import npc_oracle as orc
     legs = [orc.OLeg(l.slices, l.charges, l.qconj, arr.chinfo.mod) for l in arr.legs]
-    a = arr.copy(deep=False)
     return orc.OTensor(legs, arr.qtotal, arr._qdata, arr._data)
 
 
@@ -120,7 +119,7 @@ def main():
     H = xxz_chain_mpo(L, 1., 1., 0.)
     _, p = spin_half_leg('Sz')
     psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
-    eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': min(64, chi), 'svd_min': 1.e-12},
+    eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': min(64, chi), 'svd_min': 1.e-14},
                                      'lanczos_params': {'N_min': 2, 'N_max': 20}})
     # ---- untimed: grow the state (two quick sweeps at small chi, then double chi per sweep)
     t_prep = time.time()
@@ -181,7 +180,7 @@ def main():
                "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic (state grown on-device from the Neel product state by an untimed chi ramp; no dataset/checkpoint)",
                "config": {"workload": "two-site DMRG sweep, spin-1/2 Heisenberg chain (XXZ Jxx=Jz=1, Sz conserved), L=%d, "
-                                      "chi_max=%d (reached %d), Lanczos N=%d per bond, svd_min=1e-12, no mixer; 1 step = 1 sweep = %d bond updates"
+                                      "chi_max=%d (reached %d), Lanczos N=%d per bond, svd_min=1e-14, no mixer; 1 step = 1 sweep = %d bond updates"
                                       % (L, chi, chi_reached, args.lanczos_N, 2 * (L - 2)),
                           "parallelism": "1 GPU" if world == 1 else "%d replicas (round 1: no sharding)" % world},
                "E": E, "chi_reached": chi_reached, "prep_s": t_prep, "roofline": roof}

@@ -24,7 +24,14 @@ else:
     H = tfi_chain_mpo(L, 1., 1., None)
     chinfo, p = spin_half_leg(None)
     psi = MPS.from_product_state([p] * L, [1] * L)
-eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': chi, 'svd_min': 1e-10}, 'lanczos_params': {}, 'profile': True})
+chi_list = {0: 64}
+_c, _s = 64, 2
+while _c < chi:
+    _c = min(2 * _c, chi)
+    chi_list[_s] = _c
+    _s += 1
+print('chi_list', chi_list)
+eng = TwoSiteDMRGEngine(psi, H, {'chi_list': chi_list, 'trunc_params': {'chi_max': chi, 'svd_min': float(os.environ.get('SVD_MIN', 1e-10))}, 'lanczos_params': {}, 'profile': True})
 for s in range(ns):
     torch.cuda.synchronize()
     t = time.time()
