@@ -14,8 +14,10 @@ on the device from the Neel product state by an (untimed) chi ramp of single swe
 chi = 64, 128, ..., chi/2, followed by W warm-up sweeps at the target chi; then exactly K sweeps are
 timed between barrier + torch.cuda.synchronize() on both sides.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): round 1 runs the sweep as N replicas
-("replicas only") -- the value is the max over ranks of the time per sweep.
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU over RCCL): the Lanczos matvec is
+sharded over the ranks by rows of theta' (tenpy_amd/algorithms/sharded.py: row panels of both tensordots +
+one all-gather per matvec); SVD, environment update and the Lanczos vector kernels are replicated (DESIGN.md
+section 5).  Total work is fixed -> "scaling": "strong"; the value is the max over ranks of the time per sweep.
 
 One JSON line on rank 0; `roofline` is for the grouped MFMA GEMM (tensordot / Lanczos matvec kernel),
 `cpu_baseline` is the numpy oracle (oracle/npc_oracle.py) timed on the host cores on a bounded sample.
@@ -120,7 +122,7 @@ def main():
     _, p = spin_half_leg('Sz')
     psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
     eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': min(64, chi), 'svd_min': 1.e-14},
-                                     'lanczos_params': {'N_min': 2, 'N_max': 20}})
+                                     'lanczos_params': {'N_min': 2, 'N_max': 20}, 'shard_matvec': world > 1})
     # ---- untimed: grow the state (two quick sweeps at small chi, then double chi per sweep)
     t_prep = time.time()
     c = min(64, chi)
@@ -182,7 +184,7 @@ def main():
                "config": {"workload": "two-site DMRG sweep, spin-1/2 Heisenberg chain (XXZ Jxx=Jz=1, Sz conserved), L=%d, "
                                       "chi_max=%d (reached %d), Lanczos N=%d per bond, svd_min=1e-14, no mixer; 1 step = 1 sweep = %d bond updates"
                                       % (L, chi, chi_reached, args.lanczos_N, 2 * (L - 2)),
-                          "parallelism": "1 GPU" if world == 1 else "%d replicas (round 1: no sharding)" % world},
+                          "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD/env replicated" % world},
                "E": E, "chi_reached": chi_reached, "prep_s": t_prep, "roofline": roof}
         if not args.no_cpu_baseline:
             try:

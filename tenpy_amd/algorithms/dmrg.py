@@ -38,6 +38,7 @@ class TwoSiteDMRGEngine:
         self.log_matvec = options.get('log_matvec', False)
         self.matvec_log = []
         self.hooks = {}
+        self.shard_matvec = options.get('shard_matvec', False)
         self.profile = options.get('profile', False)
         self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
 
@@ -76,7 +77,11 @@ class TwoSiteDMRGEngine:
         psi = self.psi
         tick = self._tick
         tick(None)
-        eff_H = TwoSiteH(self.env, i0, combine=True, move_right=move_right)
+        if self.shard_matvec:
+            from .sharded import ShardedTwoSiteH
+            eff_H = ShardedTwoSiteH(self.env, i0, combine=True, move_right=move_right)
+        else:
+            eff_H = TwoSiteH(self.env, i0, combine=True, move_right=move_right)
         theta = psi.get_theta(i0, n=2)
         theta = eff_H.combine_theta(theta)
         tick('heff')

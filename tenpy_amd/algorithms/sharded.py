@@ -1,0 +1,199 @@
+"""Multi-GPU sharding of the Lanczos matvec over the rows of theta' (SURVEY 8(e)).
+
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI; ``gloo`` in the CPU tests).
+The reference has no distributed code at all (its only parallelism precedent is the ``+h.c.`` worker thread
+of ``algorithms/dmrg_parallel.py:30``); this is the MI355X-native addition.
+
+Partition: the flat index range of the fused leg ``(vL.p0)`` (= the rows of theta') is cut into
+``world_size`` contiguous ranges of equal *flop* weight -- charge sectors are Gaussian-sized, one sector
+carries ~45 % of the flops, so sectors are split by rows, not assigned whole.  Rank r
+
+  1. computes T_r = LHeff[rows_r] . theta            (row panel of LHeff, replicated theta),
+  2. computes theta'_r = T_r . RHeff                 (RHeff replicated; no exchange between the steps),
+  3. takes part in ONE all-gather of the row panels  (the only collective on the data path).
+
+Every rank then holds the full theta' and executes the (HBM-bound, cheap) Lanczos vector kernels and the
+tridiagonal eigen-solve redundantly on identical data, so alpha/beta need no scalar all-reduce and the
+control flow is identical on all ranks by construction.  SVD and environment update are replicated.
+"""
+import numpy as np
+
+from ..linalg import _device as dev
+from ..linalg import np_conserved as npc
+from .mps_common import TwoSiteH
+
+__all__ = ['ShardedTwoSiteH', 'row_partition', 'restrict_plan_rows']
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def row_partition(row_weights, world):
+    """Cut ``range(len(row_weights))`` into ``world`` contiguous ranges of (nearly) equal total weight.
+    Returns the ``world + 1`` boundaries."""
+    w = np.asarray(row_weights, dtype=np.float64)
+    n = len(w)
+    csum = np.concatenate([[0.], np.cumsum(w)])
+    total = csum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        b = int(np.searchsorted(csum, target, side='left'))
+        bounds.append(min(max(b, bounds[-1]), n))
+    bounds.append(n)
+    return np.array(bounds, dtype=np.int64)
+
+
+def restrict_plan_rows(plan, res_leg0, lo, hi):
+    """Copy of a TensordotPlan whose tasks only compute the result rows with flat leg-0 index in
+    ``[lo, hi)``.  Works on the host tables: ``c_off += r0*ldc``, ``m = r1-r0``, ``a_off += r0*a_rs``."""
+    sub = npc.TensordotPlan()
+    sub.__dict__.update(plan.__dict__)
+    if plan.empty:
+        return sub
+    tasks, links = plan.tasks_host, plan.links_host
+    new_tasks, new_links, segs = [], [], []
+    for t in range(len(tasks)):
+        c_off, m, n, ldc, lb, lc = (int(x) for x in tasks[t][:6])
+        q = int(plan.res_qdata[t, 0])
+        s0 = int(res_leg0.slices[q])
+        lead = int(res_leg0.slices[q + 1]) - s0        # rows of the leading leg inside this block
+        inner = m // lead                               # further kept legs of `a` fused into m
+        r0, r1 = max(lo, s0) - s0, min(hi, s0 + lead) - s0
+        if r1 <= r0:
+            continue
+        r0m, r1m = r0 * inner, r1 * inner
+        row = tasks[t].copy()
+        row[0] = c_off + r0m * ldc
+        row[1] = r1m - r0m
+        row[4] = len(new_links)
+        row[5] = lc
+        for l in range(lb, lb + lc):
+            lk = links[l].copy()
+            lk[0] += r0m * lk[3]
+            new_links.append(lk)
+        new_tasks.append(row)
+        segs.append((c_off + r0m * ldc, (r1m - r0m) * ldc))
+    sub.segments = segs                                 # contiguous pieces of the result arena this plan writes
+    if not new_tasks:
+        sub.n_tiles = 0
+        sub.local_empty = True
+        return sub
+    sub.local_empty = False
+    new_tasks = np.array(new_tasks, dtype=np.int64)
+    new_links = np.array(new_links, dtype=np.int64)
+    bm, bn = npc._gemm_tile(plan.dtype, plan.cfg)
+    tm, tn = (new_tasks[:, 1] + bm - 1) // bm, (new_tasks[:, 2] + bn - 1) // bn
+    ntile = tm * tn
+    t_task = np.repeat(np.arange(len(new_tasks)), ntile)
+    local = np.arange(int(np.sum(ntile))) - np.repeat(np.cumsum(ntile) - ntile, ntile)
+    tiles = np.zeros((len(t_task), 4), dtype=np.int32)
+    tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task, local // np.repeat(tn, ntile), local % np.repeat(tn, ntile)
+    sub.n_tiles = len(tiles)
+    sub.tasks_dev, sub.links_dev, sub.tiles_dev = dev.to_device(new_tasks), dev.to_device(new_links), dev.to_device(tiles)
+    return sub
+
+
+class ShardedTwoSiteH(TwoSiteH):
+    """TwoSiteH whose matvec is sharded over ``torch.distributed`` ranks by rows of theta'."""
+
+    def __init__(self, env, i0, combine=True, move_right=True, group=None):
+        super().__init__(env, i0, combine, move_right)
+        d = _dist()
+        self.group = group
+        self.world = d.get_world_size(group)
+        self.rank = d.get_rank(group)
+        self._sharded = None
+
+    def _build_sharded(self, theta):
+        p1, _, _ = npc.plan_tensordot(self.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])
+        tmp_full = npc.Array([self.LHeff.legs[0], self.LHeff.legs[1], theta.legs[1]], p1.dtype)
+        if p1.empty:
+            return None
+        tmp_full._qdata, tmp_full._offsets = p1.res_qdata, p1.res_offsets
+        tmp_full._arena = dev.empty(p1.res_total, p1.dtype)
+        tmp_full.iset_leg_labels(['(vR*.p0)', 'wR', '(p1.vR)'])
+        p2, _, _ = npc.plan_tensordot(tmp_full, self.RHeff, axes=(['wR', '(p1.vR)'], ['wL', '(p1*.vL)']))
+        if p2.empty:
+            return None
+        leg0 = self.LHeff.legs[0]
+        # flop weight per flat row of leg 0: sum over tasks of (chain K) * n per row, both steps
+        weights = np.zeros(leg0.ind_len)
+        for plan in (p1, p2):
+            tasks, links = plan.tasks_host, plan.links_host
+            for t in range(len(tasks)):
+                q = int(plan.res_qdata[t, 0])
+                s0, s1 = int(leg0.slices[q]), int(leg0.slices[q + 1])
+                ksum = float(np.sum(links[int(tasks[t][4]):int(tasks[t][4]) + int(tasks[t][5]), 2]))
+                inner = int(tasks[t][1]) // (s1 - s0)
+                weights[s0:s1] += ksum * float(tasks[t][2]) * inner
+        bounds = row_partition(weights, self.world)
+        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        sp1 = restrict_plan_rows(p1, leg0, lo, hi)
+        sp2 = restrict_plan_rows(p2, leg0, lo, hi)
+        # segments of theta' written by each rank (needed for the gather)
+        all_segs = []
+        for r in range(self.world):
+            all_segs.append(restrict_plan_rows_segments(p2, leg0, int(bounds[r]), int(bounds[r + 1])))
+        maxlen = max(sum(n for _, n in segs) for segs in all_segs)
+        return dict(p1=p1, p2=p2, sp1=sp1, sp2=sp2, segs=all_segs, maxlen=max(maxlen, 1), tmp=tmp_full,
+                    key=(theta._struct_key(), theta.dtype), bounds=bounds)
+
+    def matvec(self, theta):
+        if self.world == 1:
+            return super().matvec(theta)
+        if self._sharded is None or self._sharded['key'] != (theta._struct_key(), theta.dtype):
+            self._sharded = self._build_sharded(theta)
+            if self._sharded is None:
+                return super().matvec(theta)
+            s = self._sharded
+            self.flops_per_matvec = s['p1'].flops + s['p2'].flops
+            self.bytes_per_matvec = s['p1'].bytes_min + s['p2'].bytes_min
+        s = self._sharded
+        tmp = s['tmp']
+        if not s['sp1'].local_empty:
+            s['sp1'].apply(self.LHeff, theta, out_arena=tmp._arena)
+        out_arena = dev.empty(s['p2'].res_total, s['p2'].dtype)
+        res = None
+        if not s['sp2'].local_empty:
+            res = s['sp2'].apply(tmp, self.RHeff, out_arena=out_arena)
+        if res is None:
+            res = npc.Array([self.LHeff.legs[0], self.RHeff.legs[2]], s['p2'].dtype, theta.qtotal)
+            res._qdata, res._offsets, res._arena = s['p2'].res_qdata, s['p2'].res_offsets, out_arena
+            res._qdata_sorted = True
+        # ---- the one collective: all-gather of the row panels (padded to the largest share) ----------
+        t = dev.torch()
+        send = dev.empty(s['maxlen'], s['p2'].dtype)
+        at = 0
+        for off, n in s['segs'][self.rank]:
+            send[at:at + n].copy_(out_arena[off:off + n])
+            at += n
+        recv = dev.empty(s['maxlen'] * self.world, s['p2'].dtype)
+        _dist().all_gather_into_tensor(recv, send, group=self.group)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            at = r * s['maxlen']
+            for off, n in s['segs'][r]:
+                out_arena[off:off + n].copy_(recv[at:at + n])
+                at += n
+        res.iset_leg_labels(['(vL.p0)', '(p1.vR)'])
+        return res
+
+
+def restrict_plan_rows_segments(plan, res_leg0, lo, hi):
+    """Only the (offset, length) segments that ``restrict_plan_rows(plan, leg, lo, hi)`` would write."""
+    segs = []
+    tasks = plan.tasks_host
+    for t in range(len(tasks)):
+        c_off, m, n, ldc = (int(x) for x in tasks[t][:4])
+        q = int(plan.res_qdata[t, 0])
+        s0 = int(res_leg0.slices[q])
+        lead = int(res_leg0.slices[q + 1]) - s0
+        inner = m // lead
+        r0, r1 = max(lo, s0) - s0, min(hi, s0 + lead) - s0
+        if r1 > r0:
+            segs.append((c_off + r0 * inner * ldc, (r1 - r0) * inner * ldc))
+    return segs

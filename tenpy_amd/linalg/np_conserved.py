@@ -1554,6 +1554,7 @@ def _build_plan(a, b, ca, cb, fa, fb):
     tiles = np.zeros((len(t_task), 4), dtype=np.int32)
     tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task[order], t_row[order], t_col[order]
     plan.n_tiles = len(tiles)
+    plan.tasks_host, plan.links_host = tasks, links
     plan.tasks_dev = dev.to_device(tasks)
     plan.links_dev = dev.to_device(links)
     plan.tiles_dev = dev.to_device(tiles)
