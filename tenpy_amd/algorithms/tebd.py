@@ -1,0 +1,82 @@
+"""Second-order TEBD bond update -- harness for BASELINE config 5 (complex128, block-SVD bound).
+
+Mirrors ``TEBDEngine.update_bond`` (``tenpy/algorithms/tebd.py:416-483``) and the order-2 Suzuki-Trotter
+step of ``evolve_step`` (:374): the same npc call sequence (``get_theta(formL=0)`` -> ``tensordot`` with the
+bond gate -> ``scale_axis`` -> ``combine_legs`` -> ``svd_theta`` -> ``split_legs`` -> ``tensordot`` with
+``V.conj()``), so that no inverse Schmidt values are needed.  Bond gates ``exp(-i dt h)`` are d^2 x d^2
+matrices built once on the host (``_calc_U_bond`` :585 does the same through ``npc.expm``).
+"""
+import numpy as np
+import scipy.linalg  # host-side d^2 x d^2 gate construction only (setup, not the hot path)
+
+from ..linalg import np_conserved as npc
+from ..linalg.truncation import svd_theta, TruncationError
+
+__all__ = ['TEBDEngine', 'bond_gate']
+
+
+def bond_gate(h_bond_dense, p_leg, dt, imaginary=False):
+    """``U = exp(-i dt h)`` (or ``exp(-dt h)``) as an npc Array with labels p0, p1, p0*, p1*.
+    ``h_bond_dense`` has shape (d, d, d, d) = [p0, p1, p0*, p1*]."""
+    d = p_leg.ind_len
+    h = np.asarray(h_bond_dense).reshape(d * d, d * d)
+    U = scipy.linalg.expm((-dt if imaginary else -1.j * dt) * h).reshape(d, d, d, d)
+    return npc.Array.from_ndarray(U, [p_leg, p_leg, p_leg.conj(), p_leg.conj()], dtype=U.dtype,
+                                  labels=['p0', 'p1', 'p0*', 'p1*'], cutoff=1e-14, raise_wrong_sector=True)
+
+
+class TEBDEngine:
+    def __init__(self, psi, h_bonds_dense, options):
+        """``h_bonds_dense[i]`` couples sites (i-1, i) (``None`` for i = 0), shape (d, d, d, d)."""
+        self.psi = psi
+        self.h_bonds = h_bonds_dense
+        self.options = dict(options)
+        self.trunc_params = dict(self.options.get('trunc_params', {}))
+        self.dt = self.options.get('dt', 0.1)
+        self.trunc_err = TruncationError()
+        self.norm = 1.
+        self._U = {}
+        self.evolved_time = 0.
+
+    def _gates(self, frac):
+        key = round(frac, 12)
+        if key not in self._U:
+            p = self.psi.p_legs[0]
+            self._U[key] = [None if h is None else bond_gate(h, p, self.dt * frac) for h in self.h_bonds]
+        return self._U[key]
+
+    def update_bond(self, i, U_bond):
+        i0, i1 = i - 1, i
+        psi = self.psi
+        C = psi.get_theta(i0, n=2, formL=0.)
+        C = npc.tensordot(U_bond, C, axes=(['p0*', 'p1*'], ['p0', 'p1']))
+        C.itranspose(['vL', 'p0', 'p1', 'vR'])
+        theta = C.scale_axis(psi.get_SL(i0), 'vL')
+        theta = theta.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])
+        U, S, V, err, renorm = svd_theta(theta, self.trunc_params, [psi.get_B(i0, None).qtotal, None],
+                                         inner_labels=['vR', 'vL'])
+        B_R = V.split_legs(1).ireplace_label('p1', 'p')
+        B_L = npc.tensordot(C.combine_legs(('p1', 'vR'), pipes=theta.legs[1]), V.conj(),
+                            axes=['(p1.vR)', '(p1*.vR*)'])
+        B_L.ireplace_labels(['vL*', 'p0'], ['vR', 'p'])
+        B_L.iscale_prefactor(1. / renorm)
+        self.norm *= renorm
+        psi.set_SR(i0, S)
+        psi.set_B(i0, B_L, form='B')
+        psi.set_B(i1, B_R, form='B')
+        self.trunc_err = self.trunc_err + err
+        return err
+
+    def evolve_step_order2(self):
+        """One time step dt: half step on even bonds, full step on odd bonds, half step on even bonds."""
+        L = self.psi.L
+        for frac, parity in ((0.5, 0), (1.0, 1), (0.5, 0)):
+            U = self._gates(frac)
+            for i in range(1, L):
+                if i % 2 == (1 - parity):        # bond (i-1, i) with even i-1 <=> parity 0
+                    self.update_bond(i, U[i])
+        self.evolved_time += self.dt
+
+    def run(self, n_steps):
+        for _ in range(n_steps):
+            self.evolve_step_order2()

@@ -272,7 +272,7 @@ def gen_lanczos():
     save('lanczos.pkl', out)
 
 
-if __name__ == '__main__':
+if __name__ == "__main__" and not os.environ.get("ONLY"):
     print("reference:", tenpy.__version__, tenpy.__file__)
     gen_charges()
     gen_tensordot()
@@ -281,3 +281,36 @@ if __name__ == '__main__':
     gen_truncate()
     gen_lanczos()
     gen_dmrg()
+    gen_tebd()
+
+
+def gen_tebd():
+    """Real-time TEBD after a global quench (config 5 in small): TFI chain, parity conserved, order 2."""
+    from tenpy.algorithms import tebd
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for conserve in ('parity', None):
+            L = 10
+            M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': conserve, 'sort_charge': True})
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+            eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 1,
+                                           'trunc_params': {'chi_max': 16, 'svd_min': 1.e-10}})
+            S_t, chi_t, sz_t = [], [], []
+            for step in range(12):
+                eng.run()
+                S_t.append(np.array(psi.entanglement_entropy()))
+                chi_t.append(int(max(psi.chi)))
+                sz_t.append(np.array(psi.expectation_value('Sigmaz')))
+            out.append(dict(name='tfi_quench_L10_%s' % conserve, L=L, J=1., g=1.5, conserve=conserve, dt=0.05, chi=16,
+                            S_t=np.array(S_t), chi_t=chi_t, sigmaz_t=np.array(sz_t), S_mid=np.array(psi.get_SL(L // 2)),
+                            h_bond=[None if h is None else h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond],
+                            state_labels=list(M.lat.mps_sites()[0].state_labels.items())))
+            print(out[-1]['name'], chi_t[-1], S_t[-1][L // 2 - 1])
+    save('tebd.pkl', out)
+
+
+if __name__ == '__main__' and os.environ.get('ONLY') == 'tebd':
+    gen_tebd()
