@@ -76,6 +76,8 @@ if __name__ == '__main__':
     from tenpy_amd import _lib
     if os.environ.get('GEMM_VARIANT'):
         _lib.load().tpa_gemm_set_variant(int(os.environ['GEMM_VARIANT']))
+    if os.environ.get('XCD_ORDER'):
+        npc.XCD_TILE_ORDER = bool(int(os.environ['XCD_ORDER']))
     if os.environ.get('GEMM_CFG'):
         npc.FORCE_GEMM_CFG = int(os.environ['GEMM_CFG'])
     for n in [int(x) for x in os.environ.get('DENSE', '1024,2048,4096').split(',') if x]:

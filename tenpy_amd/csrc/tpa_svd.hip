@@ -57,17 +57,24 @@ __global__ __launch_bounds__(NT) void svd_init_kernel(const SvdJob *__restrict__
     }
 }
 
-// ||A||_F^2 per job (invariant under the rotations): the scale of the absolute part of the stopping rule
+// ||A||_F^2 per job (invariant under the rotations): the scale of the absolute part of the stopping rule.
+// Two deterministic passes: FRO_PARTS workgroups per job, then one wavefront-sized sum.
+constexpr int FRO_PARTS = 64;
 template <bool CPLX>
 __global__ __launch_bounds__(NT) void svd_fro_kernel(const SvdJob *__restrict__ jobs,
-                                                     const double *__restrict__ A, double *__restrict__ fro2) {
+                                                     const double *__restrict__ A, double *__restrict__ fpart) {
     __shared__ double red[NT / 64];
-    const SvdJob J = jobs[blockIdx.x];
+    const SvdJob J = jobs[blockIdx.y];
     const int64_t tot = J.m * J.n * (CPLX ? 2 : 1);
     const double *a = A + (CPLX ? 2 : 1) * J.a_off;
     double s = 0;
-    for (int64_t e = threadIdx.x; e < tot; e += NT) s = fma(a[e], a[e], s);
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < tot; e += (int64_t)FRO_PARTS * NT) s = fma(a[e], a[e], s);
     s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) fpart[blockIdx.y * FRO_PARTS + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void svd_fro_sum_kernel(const double *__restrict__ fpart, double *__restrict__ fro2) {
+    double s = fpart[blockIdx.x * FRO_PARTS + threadIdx.x];
+    s = wave_sum(s);
     if (threadIdx.x == 0) fro2[blockIdx.x] = s;
 }
 
@@ -316,9 +323,16 @@ __global__ __launch_bounds__(NTB) void svd_block_round_kernel(const SvdJob *__re
         double c = 1.0, s = 0.0;
         bool did = false;
         if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
-            const double zeta = (b - a) / (2.0 * g);
-            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            c = 1.0 / sqrt(1.0 + t * t);
+            // The angle only has to be approximately right (an error eps_t leaves a residual coupling
+            // ~eps_t*gamma, removed at the next visit); what must hold to full precision is c^2 + s^2 = 1.
+            // So zeta and t use the raw hardware reciprocal / sqrt, and only c gets Newton-refined.
+            const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
+            const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
+            const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
+            const double x = fma(t, t, 1.0);
+            double c0 = __builtin_amdgcn_rsq(x);
+            c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
+            c = c0 * fma(-0.5 * x * c0, c0, 1.5);
             s = c * t;
             did = true;
         }
@@ -372,6 +386,276 @@ __global__ __launch_bounds__(NTB) void svd_block_round_kernel(const SvdJob *__re
             for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
             const int64_t cn = c + NWB;
             if (cn < nch) {
+                const int64_t col = cn * CHJ + lane;
+#pragma unroll
+                for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
+            }
+            d4 o[CHJ / 16];
+#pragma unroll
+            for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int tile = 0; tile < CHJ / 16; ++tile) {
+                    const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
+                    o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
+                }
+#pragma unroll
+            for (int tile = 0; tile < CHJ / 16; ++tile) {
+                const int64_t oc = c * CHJ + tile * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gr = rowoff[l4 + 4 * r];
+                    if (gr >= 0 && oc < len) M[gr * len + oc] = o[tile][r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Split block-Jacobi round: the streaming phases of one block pair are spread over `nparts` workgroups
+// (column ranges), because a single CU can only pull ~10-12 B/clk from L2/MALL: one workgroup per pair
+// made the round per-CU-bandwidth bound (measured 19 us of 36 us in the apply phase at R = L = 1086).
+//   kernel G : partial 16x16 Gram of (pair, column part)            -> gpart[entry][256]
+//   kernel A : every (pair, part) workgroup sums the partials of its pair in a FIXED order (deterministic,
+//              identical in all parts), solves the 16x16 problem in ONE wavefront (no workgroup barriers:
+//              the matrix lives in LDS, cross-lane traffic is ordered by the in-order LDS pipe), and applies
+//              Q to its column part of the W rows and of the G rows.
+struct BEntry {  // int32[4]
+    int job, pair, part, nparts;
+};
+
+__device__ __forceinline__ void block_pair_of(const SvdJob &J, int pair, int round, int64_t &bi, int64_t &bj,
+                                              int64_t &NB) {
+    NB = (J.R + BRJ - 1) / BRJ;
+    const int64_t NBp = (NB + 1) / 2 * 2;
+    const int64_t mod = NBp - 1;
+    const int64_t r = (mod > 0) ? (round % mod) : 0;
+    if (pair == 0) {
+        bi = NBp - 1;
+        bj = r;
+    } else {
+        bi = (r + pair) % mod;
+        bj = (r - pair + mod) % mod;
+    }
+    if (bi > bj) {
+        const int64_t t = bi;
+        bi = bj;
+        bj = t;
+    }
+}
+
+constexpr int NTG = 256;  // 4 wavefronts per (pair, part) workgroup
+
+__global__ __launch_bounds__(NTG) void svd_gram_part_kernel(const SvdJob *__restrict__ jobs,
+                                                            const BEntry *__restrict__ entries, int round,
+                                                            const double *__restrict__ W,
+                                                            double *__restrict__ gpart) {
+    __shared__ double Xs[NTG / 64][TRJ][CHP];
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int64_t rowoff[TRJ];
+#pragma unroll
+    for (int t = 0; t < TRJ; ++t) {
+        const int64_t b = (t < BRJ) ? bi : bj;
+        const int64_t r = b * BRJ + (t % BRJ);
+        rowoff[t] = (b < NB && r < R) ? r : -1;
+    }
+    const int64_t nchunk = (L + CHJ - 1) / CHJ;
+    const int64_t c_lo = nchunk * E.part / E.nparts, c_hi = nchunk * (E.part + 1) / E.nparts;
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    const double *Wb = W + J.w_off;
+    double reg[TRJ];
+    int64_t c = c_lo + wave;
+    if (c < c_hi) {
+        const int64_t col = c * CHJ + lane;
+#pragma unroll
+        for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < L) ? Wb[rowoff[t] * L + col] : 0.0;
+    }
+    for (; c < c_hi; c += NTG / 64) {
+#pragma unroll
+        for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
+        const int64_t cn = c + NTG / 64;
+        if (cn < c_hi) {
+            const int64_t col = cn * CHJ + lane;
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < L) ? Wb[rowoff[t] * L + col] : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < CHJ / 4; ks += 2) {
+            const double a0 = Xs[wave][l15][ks * 4 + l4];
+            const double a1 = Xs[wave][l15][ks * 4 + 4 + l4];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[wave][l4 + 4 * r][l15] = acc0[r] + acc1[r];
+    __syncthreads();
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double sacc = 0;
+#pragma unroll
+        for (int w = 0; w < NTG / 64; ++w) sacc += Xs[w][i][j];
+        gpart[(int64_t)blockIdx.x * 256 + tid] = sacc;
+    }
+}
+
+__global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__restrict__ jobs,
+                                                              const BEntry *__restrict__ entries, int round,
+                                                              double *__restrict__ W, double *__restrict__ G,
+                                                              const double *__restrict__ gpart,
+                                                              unsigned int *__restrict__ n_rot,
+                                                              const double *__restrict__ fro2, double rho,
+                                                              int local_sweeps, int full_local) {
+    __shared__ double Xs[NTG / 64][TRJ][CHP];
+    __shared__ double Sm[TRJ][TRJ + 1], Qm[TRJ][TRJ + 1];
+    __shared__ double csA[TRJ], cpA[TRJ];
+    __shared__ int partA[TRJ];
+    __shared__ int any_flag;
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int64_t rowoff[TRJ];
+#pragma unroll
+    for (int t = 0; t < TRJ; ++t) {
+        const int64_t b = (t < BRJ) ? bi : bj;
+        const int64_t r = b * BRJ + (t % BRJ);
+        rowoff[t] = (b < NB && r < R) ? r : -1;
+    }
+    // ---- full Gram = sum of the partials of this pair, fixed order (entries of a pair are consecutive)
+    {
+        const int64_t first = (int64_t)blockIdx.x - E.part;
+        double sacc = 0;
+        for (int p = 0; p < E.nparts; ++p) sacc += gpart[(first + p) * 256 + tid];
+        Sm[tid >> 4][tid & 15] = sacc;
+        Qm[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+    }
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[E.job];
+    {
+        const int ei = tid >> 4, ej = tid & 15;
+        const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
+        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2)) any_flag = 1;
+    }
+    __syncthreads();
+    if (any_flag == 0) return;
+    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
+
+    // ---- local solve: ONE wavefront, 4 matrix elements per lane, no workgroup barriers ---------------
+    // `full` rounds sweep all 120 pairs of the 16 rows (15 local rounds); otherwise only the 64 CROSS pairs
+    // between the two 8-row blocks are rotated (8 local rounds, partner of i<8 is 8 + (i + rr) % 8): pairs
+    // inside a block were orthogonalised when the block last took part in a full round and are only
+    // perturbed at second order since.  The host requests a full round once per sweep for every pair.
+    if (wave == 0) {
+        const int ei = lane >> 2, ej0 = (lane & 3) * 4;
+        const int n_local = full_local ? (TRJ - 1) : BRJ;
+        for (int sweep = 0; sweep < local_sweeps; ++sweep) {
+            bool rotated = false;
+            for (int rr = 0; rr < n_local; ++rr) {
+                if (lane < TRJ) {
+                    const int i = lane;
+                    int pi;
+                    if (full_local) {
+                        if (i == TRJ - 1)
+                            pi = rr;
+                        else if (i == rr)
+                            pi = TRJ - 1;
+                        else
+                            pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1);
+                    } else {
+                        pi = (i < BRJ) ? (BRJ + ((i + rr) & (BRJ - 1))) : (((i - BRJ) - rr) & (BRJ - 1));
+                    }
+                    const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
+                    const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
+                    double c = 1.0, s = 0.0;
+                    if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
+                        const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
+                        const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
+                        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
+                        const double x = fma(t, t, 1.0);
+                        double c0 = __builtin_amdgcn_rsq(x);
+                        c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        c = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        s = c * t;
+                        rotated = true;
+                    }
+                    partA[i] = pi;
+                    csA[i] = c;
+                    cpA[i] = (i == p) ? -s : s;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    const int pi = partA[ei];
+                    const double cs = csA[ei], cp = cpA[ei];
+                    double s_new[4], q_new[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s_new[u] = cs * Sm[ei][ej0 + u] + cp * Sm[pi][ej0 + u];
+                        q_new[u] = cs * Qm[ei][ej0 + u] + cp * Qm[pi][ej0 + u];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        Sm[ei][ej0 + u] = s_new[u];
+                        Qm[ei][ej0 + u] = q_new[u];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    double s_new[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ej = ej0 + u, pj = partA[ej];
+                        s_new[u] = csA[ej] * Sm[ei][ej] + cpA[ej] * Sm[ei][pj];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) Sm[ei][ej0 + u] = s_new[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (!__any(rotated)) break;
+        }
+    }
+    __syncthreads();
+
+    // ---- apply: X <- Q X on this part's columns of the W rows and of the G rows ------------------------
+    double qa[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qa[kk] = Qm[l15][kk * 4 + l4];
+    for (int pass = 0; pass < 2; ++pass) {
+        double *M = (pass == 0) ? (W + J.w_off) : (G + J.g_off);
+        const int64_t len = (pass == 0) ? L : R;
+        const int64_t nch = (len + CHJ - 1) / CHJ;
+        const int64_t c_lo = nch * E.part / E.nparts, c_hi = nch * (E.part + 1) / E.nparts;
+        double reg[TRJ];
+        int64_t c = c_lo + wave;
+        if (c < c_hi) {
+            const int64_t col = c * CHJ + lane;
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
+        }
+        for (; c < c_hi; c += NTG / 64) {
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
+            const int64_t cn = c + NTG / 64;
+            if (cn < c_hi) {
                 const int64_t col = cn * CHJ + lane;
 #pragma unroll
                 for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
@@ -464,6 +748,8 @@ __global__ __launch_bounds__(NT) void svd_finish_kernel(const SvdJob *__restrict
 }
 
 int tpa_svd_local_sweeps = 1;
+int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block pairs
+int tpa_svd_split = 1;  // 1: gram / solve+apply kernels over column parts, 0: one fused workgroup per block pair
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
 
 struct Layout {
@@ -471,11 +757,12 @@ struct Layout {
     std::vector<int2> rows;   // (job,row) per wavefront, padded to multiple of 4 with (-1,-1)
     std::vector<int2> pairs;  // (job,pair)
     std::vector<int2> bpairs; // (job, block pair) for the block-Jacobi rounds
+    std::vector<BEntry> bentries;  // (job, pair, part, nparts) for the split rounds
     int64_t nb_max_pad = 0;
     int64_t w_elems = 0, g_elems = 0, sig_elems = 0, rmax_pad = 0;
     // byte offsets inside work buffer
     int64_t off_w = 0, off_g = 0, off_sig = 0, off_perm = 0, off_jobs = 0, off_rows = 0, off_pairs = 0,
-            off_bpairs = 0, off_cnt = 0, off_fro = 0, total = 0;
+            off_bpairs = 0, off_bent = 0, off_gpart = 0, off_cnt = 0, off_fro = 0, off_fpart = 0, total = 0;
 };
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -507,6 +794,11 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         {
             const int64_t NB = (J.R + 7) / 8, NBp = (NB + 1) / 2 * 2;
             for (int64_t p = 0; p < NBp / 2; ++p) lay.bpairs.push_back(int2{b, (int)p});
+            // column parts: >= 4 chunks of 64 columns each, at most 8 parts
+            const int64_t nchunk = (J.L + 63) / 64;
+            int nparts = (int)std::min<int64_t>(8, std::max<int64_t>(1, nchunk / 4));
+            for (int64_t p = 0; p < NBp / 2; ++p)
+                for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
             lay.nb_max_pad = std::max(lay.nb_max_pad, NBp);
         }
         lay.jobs.push_back(J);
@@ -530,10 +822,16 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.pairs.size() * sizeof(int2), 256);
     lay.off_bpairs = o;
     o = align_up(o + (int64_t)lay.bpairs.size() * sizeof(int2), 256);
+    lay.off_bent = o;
+    o = align_up(o + (int64_t)lay.bentries.size() * sizeof(BEntry), 256);
+    lay.off_gpart = o;
+    o = align_up(o + (int64_t)lay.bentries.size() * 256 * 8, 256);
     lay.off_cnt = o;
     o = align_up(o + 256, 256);
     lay.off_fro = o;
     o = align_up(o + (int64_t)lay.jobs.size() * 8, 256);
+    lay.off_fpart = o;
+    o = align_up(o + (int64_t)lay.jobs.size() * 64 * 8, 256);
     lay.total = o;
     return lay;
 }
@@ -553,6 +851,9 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     TPA_HIP_CHECK(hipMemcpyAsync(rows, lay.rows.data(), lay.rows.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(pairs, lay.pairs.data(), lay.pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     int2 *bpairs = (int2 *)(work + lay.off_bpairs);
+    BEntry *bent = (BEntry *)(work + lay.off_bent);
+    double *gpart = (double *)(work + lay.off_gpart);
+    TPA_HIP_CHECK(hipMemcpyAsync(bent, lay.bentries.data(), lay.bentries.size() * sizeof(BEntry), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(bpairs, lay.bpairs.data(), lay.bpairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     // pageable host memory: the copies above are staged before returning, vectors may die later.
     const int g_rows = (int)(lay.rows.size() / (NT / 64));
@@ -564,7 +865,9 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     svd_init_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, (const double *)a_base, W, G);
     TPA_LAUNCH_CHECK();
     double *fro2 = (double *)(work + lay.off_fro);
-    svd_fro_kernel<CPLX><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, fro2);
+    double *fpart = (double *)(work + lay.off_fpart);
+    svd_fro_kernel<CPLX><<<dim3(FRO_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)a_base, fpart);
+    svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(fpart, fro2);
     TPA_LAUNCH_CHECK();
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
@@ -574,7 +877,10 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
-            if (use_block)
+            if (use_block && tpa_svd_split) {
+                svd_gram_part_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, gpart);
+                svd_solve_apply_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
+            } else if (use_block)
                 svd_block_round_kernel<<<(int)lay.bpairs.size(), NTB, 0, st>>>(jobs, bpairs, r, W, G, cnt, fro2, rho, tpa_svd_local_sweeps);
             else
                 svd_round_kernel<CPLX><<<g_pairs, NT, 0, st>>>(jobs, pairs, r, W, G, cnt, fro2, rho);
@@ -797,6 +1103,8 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
 
 extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_force_pairwise = (pairwise & 1) ? 1 : 0;
-    if (pairwise >= 16) tpa_svd_local_sweeps = pairwise >> 4;   // test hook: local sweeps in bits 4..
+    tpa_svd_split = (pairwise & 2) ? 0 : 1;
+    tpa_svd_cross_only = (pairwise & 4) ? 0 : 1;   // bit 2: full 16x16 local sweep in every round   // bit 1: fused single-workgroup block kernel
+    if (pairwise >= 16) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
 }

@@ -1550,7 +1550,7 @@ def _build_plan(a, b, ca, cb, fa, fb):
     t_row = local // np.repeat(tn, ntile)
     t_col = local % np.repeat(tn, ntile)
     work = np.repeat(ksum, ntile)
-    order = np.argsort(-work, kind='stable')
+    order = _xcd_tile_order(t_task, t_row, t_col, work, np.repeat(tm, ntile), np.repeat(tn, ntile))
     tiles = np.zeros((len(t_task), 4), dtype=np.int32)
     tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task[order], t_row[order], t_col[order]
     plan.n_tiles = len(tiles)
@@ -1566,6 +1566,44 @@ def _build_plan(a, b, ca, cb, fa, fb):
     plan.n_gemm = len(gi)
     plan.gemm_shapes = np.stack([M[ga], K[ga], N[gb]], axis=1)
     return plan
+
+
+N_XCD = 8
+XCD_TILE_ORDER = True     # tuning hook
+
+
+def _xcd_tile_order(t_task, t_row, t_col, work, tm, tn):
+    """Order of the tile table.  Workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed only)
+    and every XCD has a private L2, so each XCD gets a compact band of tile ROWS of every C block: the A row
+    panels of a band are then fetched by one XCD only, and neighbouring column tiles (which share the A panel)
+    are resident on that XCD at the same time.  Inside an XCD the heaviest chains go first (LPT)."""
+    n = len(t_task)
+    if not XCD_TILE_ORDER or n < 2 * N_XCD:
+        return np.argsort(-work, kind='stable')
+    xcd = np.where(tm >= N_XCD, (t_row * N_XCD) // np.maximum(tm, 1),
+                   ((t_row * tn + t_col) * N_XCD) // np.maximum(tm * tn, 1)).astype(np.int64)
+    # tasks with fewer than 8 tiles would all land on the low XCDs: rotate by task index
+    xcd = (xcd + t_task) % N_XCD
+    key = np.lexsort((t_col, t_row, t_task, -work, xcd))          # by xcd, then heavy first, then locality
+    lists = [key[xcd[key] == x] for x in range(N_XCD)]
+    # balance the list lengths (the table is consumed round-robin): move tail tiles of long lists to short ones
+    target = -(-n // N_XCD)
+    spill = []
+    for x in range(N_XCD):
+        if len(lists[x]) > target:
+            spill.extend(lists[x][target:])
+            lists[x] = lists[x][:target]
+    for x in range(N_XCD):
+        need = target - len(lists[x])
+        if need > 0 and spill:
+            lists[x] = np.concatenate([lists[x], np.array(spill[:need], dtype=np.int64)])
+            spill = spill[need:]
+    out = np.full(target * N_XCD, -1, dtype=np.int64)
+    for x in range(N_XCD):
+        out[x:x + N_XCD * len(lists[x]):N_XCD] = lists[x]
+    out = out[out >= 0]
+    assert len(out) == n
+    return out
 
 
 def K_of_b(b_shapes, cb, idx):
@@ -1674,6 +1712,14 @@ def trace(a, leg1=0, leg2=1):
 # decompositions
 # ======================================================================================================
 
+# Absolute floor rho of the Jacobi stopping rule (include/tenpy_amd.h, tpa_svd_batch `tol`): row pairs whose
+# larger norm is below rho*||block||_F are judged against rho*||block||_F instead of their own norm, i.e. the
+# numerical null space of a rank-deficient block (DMRG wave functions: rank <= chi of d*chi) is not rotated
+# against itself.  Singular values keep absolute accuracy eps*||A||; singular vectors of sigma < rho*||A||
+# are orthogonal to ~eps*rho*||A||/sigma instead of eps.  0 = purely relative criterion.
+SVD_ABS_FLOOR = 1.e-6
+
+
 def _blocked_matrix_jobs(a):
     """Per stored block of a rank-2 Array: (offset, m, n)."""
     sh = a._block_shapes()
@@ -1725,7 +1771,7 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
     sweeps = dev.c_int()
     dev.check(L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
-                              V_arena.data_ptr(), work.data_ptr(), int(wb), 60, 0.0, dev.byref(sweeps), dev.stream()),
+                              V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
               "svd_batch")
     S_host = dev.to_host(S_dev)
     if np.any(np.isnan(S_host)):
