@@ -39,3 +39,6 @@ for s in range(ns):
     torch.cuda.synchronize()
     print("sweep %d E=%.13f chi=%d t=%.3fs" % (s, eng.sweep_stats['E'][-1], eng.sweep_stats['max_chi'][-1], time.time() - t), {k: round(v, 3) for k, v in eng.phase_time.items()}, 'N_lanczos', int(np.sum(eng.update_stats['N_lanczos'][-2*(L-2):])), flush=True)
     eng.phase_time = {k: 0. for k in eng.phase_time}
+    from tenpy_amd.linalg import np_conserved as _npc
+    print('   svd stats', _npc.svd_stats, flush=True)
+    _npc.svd_stats.update(calls=0, sweeps=0, max_block=0)

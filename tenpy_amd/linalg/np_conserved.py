@@ -1718,6 +1718,7 @@ def trace(a, leg1=0, leg2=1):
 # against itself.  Singular values keep absolute accuracy eps*||A||; singular vectors of sigma < rho*||A||
 # are orthogonal to ~eps*rho*||A||/sigma instead of eps.  0 = purely relative criterion.
 SVD_ABS_FLOOR = 1.e-6
+svd_stats = {'calls': 0, 'sweeps': 0, 'max_block': 0}
 
 
 def _blocked_matrix_jobs(a):
@@ -1773,6 +1774,9 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     dev.check(L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
                               V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
               "svd_batch")
+    svd_stats['calls'] += 1
+    svd_stats['sweeps'] += sweeps.value
+    svd_stats['max_block'] = max(svd_stats['max_block'], int(np.max(ks)))
     S_host = dev.to_host(S_dev)
     if np.any(np.isnan(S_host)):
         raise ValueError("NaN in S: " + str(np.sum(np.isnan(S_host))))
