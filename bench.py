@@ -168,9 +168,17 @@ def main():
         gt = npc.gemm_timer
         tflops = (gt.flops / (gemm_ms * 1e-3)) / 1e12 if gemm_ms > 0 else 0.
         per_launch_ms = gemm_ms / max(gt.n_launch, 1)
+        traffic, traffic_note = None, None
+        try:     # L2-miss traffic of the matvec GEMM measured with rocprofv3 PMC passes (committed profile, not live)
+            with open(os.path.join(ROOT, 'profiles', 'r01_gemm_pmc_matvec_chi2048.json')) as f:
+                pm = json.load(f)
+            if chi == 2048:
+                traffic, traffic_note = pm["traffic_bytes_per_launch"], pm["how"]
+        except Exception:
+            pass
         roof = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-                "kernel": "gemm_chain_kernel<f64,128x128> (grouped chained MFMA GEMM: tensordot / Lanczos matvec / env update)",
+                "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                "kernel": "gemm_chain_kernel<f64, 64x64 | 128x128> (grouped chained MFMA GEMM: tensordot / Lanczos matvec / env update)",
                 "launches": gt.n_launch, "avg_launch_ms": per_launch_ms, "algorithmic_flops_per_launch": gt.flops / max(gt.n_launch, 1),
                 "algorithmic_bytes_per_launch": gt.bytes_min / max(gt.n_launch, 1),
                 "time_share_of_sweep": (gemm_ms * 1e-3) / max(elapsed, 1e-12)}
