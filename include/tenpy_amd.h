@@ -102,6 +102,11 @@ int tpa_fill_zero(void *dst_dev, int64_t n_bytes, void *stream);
  * idx_off, 0}; idx_dev: int64 indices. */
 int tpa_gather_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
                           const int64_t *idx_dev, const void *src_base, void *dst_base, void *stream);
+/* out[o_off + j] = sum_{i,l} |x[i, j, l]|^2 for blocks viewed as (pre, len, post): per-slice squared norms
+ * (np.linalg.norm(block, axis) in _qr_theta_Y0, truncation.py:452).  jobs: int64[n][6] = {x_off, pre, len, post,
+ * o_off, 0}; rows: int32[n_rows][2] = {job, j} (one wavefront each; n_rows padded to a multiple of 4 with job=-1). */
+int tpa_axis_sqnorm_batch(int dtype, const int64_t *jobs_dev, const int32_t *rows_dev, int n_rows,
+                          const void *x_base, double *out_dev, void *stream);
 /* Flat dtype conversion / (complex) conjugation of an arena: astype (np_conserved.py:1865) and
  * iconj's complex_conj (np_conserved.py:2202-2235).  c128->f64 keeps the real part. */
 int tpa_convert(int from_dtype, int to_dtype, int64_t n, const void *src_dev, void *dst_dev, int conj,

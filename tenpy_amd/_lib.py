@@ -35,6 +35,7 @@ _SIGS = {
     "tpa_copy_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]),
     "tpa_scale_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp]),
     "tpa_gather_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    "tpa_axis_sqnorm_batch": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "tpa_convert": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp]),
     "tpa_fill_zero": (ctypes.c_int, [_vp, ctypes.c_int64, _vp]),
     "tpa_svd_worksize": (ctypes.c_int64, [ctypes.c_int, _vp, ctypes.c_int]),

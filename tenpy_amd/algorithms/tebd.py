@@ -10,9 +10,9 @@ import numpy as np
 import scipy.linalg  # host-side d^2 x d^2 gate construction only (setup, not the hot path)
 
 from ..linalg import np_conserved as npc
-from ..linalg.truncation import svd_theta, TruncationError
+from ..linalg.truncation import svd_theta, TruncationError, decompose_theta_qr_based
 
-__all__ = ['TEBDEngine', 'bond_gate']
+__all__ = ['TEBDEngine', 'QRBasedTEBDEngine', 'bond_gate']
 
 
 def bond_gate(h_bond_dense, p_leg, dt, imaginary=False):
@@ -80,3 +80,46 @@ class TEBDEngine:
     def run(self, n_steps):
         for _ in range(n_steps):
             self.evolve_step_order2()
+
+
+class QRBasedTEBDEngine(TEBDEngine):
+    """TEBD with the QR-based truncation (reference ``QRBasedTEBDEngine.update_bond``, tebd.py:685-738; options
+    ``cbe_expand`` (0.1), ``cbe_expand_0``, ``cbe_min_block_increase`` (1), ``use_eig_based_svd``, ``compute_err``)."""
+
+    def _expansion_rate(self, i):
+        expand = self.options.get('cbe_expand', 0.1)
+        expand_0 = self.options.get('cbe_expand_0', None)
+        if expand_0 is None or expand_0 == expand:
+            return expand
+        chi_max = self.trunc_params.get('chi_max', None)
+        if chi_max is None:
+            raise ValueError('Need to specify trunc_params["chi_max"] in order to use cbe_expand_0.')
+        chi = len(self.psi.get_SL(i))
+        return max(expand_0 - chi / chi_max * (expand_0 - expand), expand)
+
+    def update_bond(self, i, U_bond):
+        i0, i1 = i - 1, i
+        psi = self.psi
+        expand = self._expansion_rate(i)
+        C = psi.get_theta(i0, n=2, formL=0.)
+        C = npc.tensordot(U_bond, C, axes=(['p0*', 'p1*'], ['p0', 'p1']))
+        C.itranspose(['vL', 'p0', 'p1', 'vR'])
+        theta = C.scale_axis(psi.get_SL(i0), 'vL')
+        theta = theta.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])
+        old_B_L, old_B_R = psi.get_B(i0, 'B'), psi.get_B(i1, 'B')
+        _, S, B_R, form, err, renorm = decompose_theta_qr_based(
+            old_qtotal_L=old_B_L.qtotal, old_qtotal_R=old_B_R.qtotal, old_bond_leg=old_B_R.get_leg('vL'), theta=theta,
+            move_right=False, expand=expand, min_block_increase=self.options.get('cbe_min_block_increase', 1),
+            use_eig_based_svd=self.options.get('use_eig_based_svd', False), trunc_params=self.trunc_params,
+            compute_err=self.options.get('compute_err', True), return_both_T=False)
+        assert form[1] == 'B'
+        B_L = npc.tensordot(C.combine_legs(('p1', 'vR'), pipes=theta.legs[1]), B_R.conj(), axes=[['(p1.vR)'], ['(p*.vR*)']])
+        B_L.iscale_prefactor(1. / renorm)
+        B_L.ireplace_labels(['p0', 'vL*'], ['p', 'vR'])
+        B_R = B_R.split_legs(1)
+        self.norm *= renorm
+        psi.set_B(i0, B_L, form='B')
+        psi.set_SL(i1, S)
+        psi.set_B(i1, B_R, form='B')
+        self.trunc_err = self.trunc_err + err
+        return err

@@ -100,6 +100,37 @@ __global__ __launch_bounds__(NT) void gather_axis_kernel(const GatherJob *__rest
     }
 }
 
+// out[o_off + j] = sum_{i,l} |x[i, j, l]|^2 for blocks viewed as (pre, len, post): the per-slice norms that
+// _qr_theta_Y0 takes with np.linalg.norm(block, axis=...) (truncation.py:452).  One wavefront per (job, j).
+struct NormJob {  // int64[6]
+    int64_t x_off, pre, len, post, o_off, pad;
+};
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void axis_sqnorm_kernel(const NormJob *__restrict__ jobs,
+                                                         const int2 *__restrict__ rows,
+                                                         const double *__restrict__ x, double *__restrict__ out) {
+    const int gw = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int2 jr = rows[gw];
+    if (jr.x < 0) return;
+    const NormJob J = jobs[jr.x];
+    const int64_t j = jr.y;
+    double s = 0;
+    const int64_t cnt = J.pre * J.post;
+    for (int64_t e = lane; e < cnt; e += 64) {
+        const int64_t i = e / J.post, l = e - i * J.post;
+        const int64_t idx = J.x_off + (i * J.len + j) * J.post + l;
+        if (CPLX) {
+            const double2 v = reinterpret_cast<const double2 *>(x)[idx];
+            s += v.x * v.x + v.y * v.y;
+        } else {
+            s = fma(x[idx], x[idx], s);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[J.o_off + j] = s;
+}
+
 // dtype conversion / conjugation over a flat arena.  MODE 0: f64->f64 copy, 1: f64->c128, 2: c128->f64 (real
 // part), 3: c128->c128 (optionally conjugated)
 template <int MODE>
@@ -193,6 +224,20 @@ extern "C" int tpa_convert(int from_dtype, int to_dtype, int64_t n, const void *
         convert_kernel<2><<<g, NT, 0, st>>>(n, (const double *)src, (double *)dst, 0);
     else
         convert_kernel<3><<<g, NT, 0, st>>>(n, (const double *)src, (double *)dst, conj);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_axis_sqnorm_batch(int dtype, const int64_t *jobs_dev, const int32_t *rows_dev, int n_rows,
+                                     const void *x_base, double *out_dev, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n_rows <= 0) return 0;
+    TPA_ARG_CHECK(n_rows % (NT / 64) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TPA_F64)
+        axis_sqnorm_kernel<false><<<n_rows / (NT / 64), NT, 0, st>>>((const NormJob *)jobs_dev, (const int2 *)rows_dev, (const double *)x_base, out_dev);
+    else
+        axis_sqnorm_kernel<true><<<n_rows / (NT / 64), NT, 0, st>>>((const NormJob *)jobs_dev, (const int2 *)rows_dev, (const double *)x_base, out_dev);
     TPA_LAUNCH_CHECK();
     return 0;
 }

@@ -23,7 +23,7 @@ import numpy as np
 from . import _device as dev
 from .charges import ChargeInfo, LegCharge, LegPipe, QTYPE, _find_row_differences, _partial_qtotal
 
-__all__ = ['QCUTOFF', 'ChargeInfo', 'LegCharge', 'LegPipe', 'Array', 'zeros', 'eye_like', 'diag', 'outer', 'inner',
+__all__ = ['lq', 'eigvalsh', 'QCUTOFF', 'ChargeInfo', 'LegCharge', 'LegPipe', 'Array', 'zeros', 'eye_like', 'diag', 'outer', 'inner',
            'tensordot', 'svd', 'qr', 'eigh', 'norm', 'trace', 'to_iterable_arrays', 'TensordotPlan']
 
 QCUTOFF = np.finfo(np.float64).eps * 10
@@ -928,6 +928,37 @@ class Array:
 
     def __neg__(self):
         return self.copy(deep=True).iscale_prefactor(-1.)
+
+    def axis_sqnorms(self, axis):
+        """Host array ``out[j] = sum |self[..., j, ...]|^2`` over everything but ``axis`` (one device pass)."""
+        axis = self.get_leg_index(axis)
+        res = np.zeros(self.shape[axis])
+        if self.stored_blocks == 0:
+            return res
+        shapes = self._block_shapes()
+        nb = self.stored_blocks
+        lens = shapes[:, axis]
+        o_offs = np.concatenate([[0], np.cumsum(lens)])
+        jobs = np.zeros((nb, 6), dtype=np.int64)
+        jobs[:, 0] = self._offsets
+        jobs[:, 1] = np.prod(shapes[:, :axis], axis=1)
+        jobs[:, 2] = lens
+        jobs[:, 3] = np.prod(shapes[:, axis + 1:], axis=1)
+        jobs[:, 4] = o_offs[:-1]
+        rows = np.stack([np.repeat(np.arange(nb), lens), np.arange(int(o_offs[-1])) - np.repeat(o_offs[:-1], lens)], axis=1)
+        pad = (-len(rows)) % 4
+        if pad:
+            rows = np.concatenate([rows, np.full((pad, 2), -1)], axis=0)
+        out = dev.zeros(int(o_offs[-1]), np.float64)
+        jd, rd = dev.to_device(jobs), dev.to_device(rows.astype(np.int32))
+        dev.check(dev.lib().tpa_axis_sqnorm_batch(dev.code(self.dtype), jd.data_ptr(), rd.data_ptr(), len(rows),
+                                                  self._arena.data_ptr(), out.data_ptr(), dev.stream()), "axis_sqnorm")
+        host = dev.to_host(out)
+        leg = self.legs[axis]
+        for b in range(nb):
+            q = self._qdata[b, axis]
+            res[leg.slices[q]:leg.slices[q + 1]] += host[o_offs[b]:o_offs[b + 1]]
+        return res
 
     def iscale_prefactor(self, prefactor):
         """``self *= prefactor`` (reference :2385 / _npc_helper.pyx:964); 0 drops all blocks."""
@@ -1896,6 +1927,58 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
     return Q, R
 
 
+def _permute_within_blocks(a, perm_flat, axis):
+    """``a`` with the flat indices of ``axis`` permuted inside each charge block: res[.., j, ..] = a[.., perm[j], ..]."""
+    res = a.copy(deep=False)
+    res._qdata, res._offsets = a._qdata.copy(), a._offsets.copy()
+    if a.stored_blocks == 0:
+        return res
+    leg = a.legs[axis]
+    shapes = a._block_shapes()
+    sizes = np.prod(shapes, axis=1)
+    res._arena = dev.empty(a._arena.numel(), a.dtype)
+    jobs = np.zeros((a.stored_blocks, 8), dtype=np.int64)
+    jobs[:, 0] = jobs[:, 1] = a._offsets
+    jobs[:, 2] = np.prod(shapes[:, :axis], axis=1)
+    jobs[:, 3] = jobs[:, 4] = shapes[:, axis]
+    jobs[:, 5] = np.prod(shapes[:, axis + 1:], axis=1)
+    starts = leg.slices[a._qdata[:, axis]]
+    jobs[:, 6] = starts
+    local = np.asarray(perm_flat, dtype=np.int64).copy()
+    for q in range(leg.block_number):
+        local[leg.slices[q]:leg.slices[q + 1]] -= leg.slices[q]
+    jd, idd = dev.to_device(jobs), dev.to_device(local)
+    dev.check(dev.lib().tpa_gather_axis_batch(dev.code(a.dtype), jd.data_ptr(), len(jobs), int(np.max(sizes)), idd.data_ptr(),
+                                              a._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "gather")
+    res._skey = None
+    return res
+
+
+def lq(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_L=False, qtotal_Q=None, inner_qconj=+1):
+    """L-Q decomposition through :func:`qr` of the transpose (reference np_conserved.py:4273)."""
+    q, r = qr(a.transpose(), mode=mode, inner_labels=inner_labels[::-1], cutoff=cutoff, pos_diag_R=pos_diag_L,
+              qtotal_Q=qtotal_Q, inner_qconj=inner_qconj)
+    return r.transpose(), q.transpose()
+
+
+def _argsort(w, sort):
+    """tools.misc.argsort of the reference: 'm>' / 'm<' by magnitude, '>' / '<' by real part."""
+    if sort is None or sort == '<':
+        return np.argsort(w, kind='stable')
+    if sort == '>':
+        return np.argsort(-w, kind='stable')
+    if sort == 'm<':
+        return np.argsort(np.abs(w), kind='stable')
+    if sort == 'm>':
+        return np.argsort(-np.abs(w), kind='stable')
+    raise ValueError("unknown sort option " + repr(sort))
+
+
+def eigvalsh(a, UPLO='L', sort=None):
+    """Eigenvalues of a hermitian block matrix (reference :3972)."""
+    return eigh(a, UPLO, sort)[0]
+
+
 def eigh(a, UPLO='L', sort=None):
     """Block-wise Hermitian eigendecomposition (reference np_conserved.py:3899, worker :5041).
 
@@ -1907,8 +1990,6 @@ def eigh(a, UPLO='L', sort=None):
     a.legs[0].test_contractible(a.legs[1])
     if np.any(a.qtotal != a.chinfo.make_valid()):
         raise ValueError("Non-trivial qtotal -> Nilpotent. Not diagonizable!?")
-    if sort is not None:
-        raise NotImplementedError("tenpy_amd: eigh(sort=...)")
     a_labels = a._labels
     piped_axes, a = a.as_completely_blocked()
     leg = a.legs[0]
@@ -1942,9 +2023,20 @@ def eigh(a, UPLO='L', sort=None):
         dev.check(L.tpa_eigh_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), W_dev.data_ptr(), V_arena.data_ptr(),
                                    work.data_ptr(), int(wb), 60, 0.0, dev.byref(sweeps), dev.stream()), "eigh_batch")
         W_host = dev.to_host(W_dev)
+        perm_full = np.arange(a.shape[0], dtype=np.int64)
+        need_perm = False
         for b in range(nblk):
             qi = a._qdata[b, 0]
-            resw[leg.get_slice(qi)] = W_host[w_offs[b]:w_offs[b + 1]]
+            w = W_host[w_offs[b]:w_offs[b + 1]]
+            if sort is not None and sort != '<':
+                pb = _argsort(w, sort)
+                w = w[pb]
+                sl = leg.get_slice(qi)
+                perm_full[sl] = sl.start + pb
+                need_perm = True
+            resw[leg.get_slice(qi)] = w
+        if need_perm:
+            V = _permute_within_blocks(V, perm_full, 1)
     if len(piped_axes) > 0:
         V = V.split_legs(0)
     V.iset_leg_labels([a_labels[0], 'eig'])

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import np_conserved as npc
 
-__all__ = ['TruncationError', 'truncate', 'svd_theta']
+__all__ = ['TruncationError', 'truncate', 'svd_theta', 'decompose_theta_qr_based']
 
 
 class TruncationError:
@@ -123,3 +123,157 @@ def svd_theta(theta, trunc_par, qtotal_LR=[None, None], inner_labels=['vR', 'vL'
         U.iproject(keep, axes=1)
         VH.iproject(keep, axes=0)
     return U, S, VH, err, renormalization
+
+
+# ======================================================================================================
+# QR-based decomposition of theta (reference truncation.py:370-711), the variant the reference flags as
+# "faster on GPUs" (algorithms/tebd.py:658-661): two tensordots + two block QRs + an SVD (or eigh) of the
+# small bond matrix Xi instead of the SVD of the (d chi) x (d chi) theta.
+# ======================================================================================================
+
+def _eig_based_svd(A, need_U=True, need_Vd=True, inner_labels=[None, None], trunc_params=None):
+    """SVD of a matrix through ``eigh`` of ``A A^dagger`` or ``A^dagger A`` (reference :473).  Only one of U / Vd."""
+    assert A.rank == 2
+    if need_U and need_Vd:
+        raise NotImplementedError
+    U = Vd = None
+    if need_U:
+        L, U = npc.eigh(npc.tensordot(A, A.conj(), [1, 1]), sort='>')
+        S = np.sqrt(np.abs(L))
+        U = U.ireplace_label('eig', inner_labels[0])
+    elif need_Vd:
+        L, V = npc.eigh(npc.tensordot(A.conj(), A, [0, 0]), sort='>')
+        S = np.sqrt(np.abs(L))
+        Vd = V.iconj().itranspose().ireplace_label('eig*', inner_labels[1])
+    else:
+        A2 = npc.tensordot(A, A.conj(), [1, 1]) if A.shape[1] >= A.shape[0] else npc.tensordot(A.conj(), A, [0, 0])
+        S = np.sqrt(np.abs(npc.eigvalsh(A2)))
+    if trunc_params is not None:
+        keep, renormalize, trunc_err = truncate(S, trunc_params)
+        S = S[keep] / renormalize
+        if need_U:
+            U.iproject(keep, 1)
+        if need_Vd:
+            Vd.iproject(keep, 0)
+    else:
+        renormalize = np.linalg.norm(S)
+        S = S / renormalize
+        trunc_err = TruncationError()
+    return U, S, Vd, trunc_err, renormalize
+
+
+def _qr_theta_Y0(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase):
+    """Initial guess Y0 for the isometry: theta with the fused leg restricted to the old bond sectors enlarged by
+    ``expand`` (the slices of largest norm are kept; reference :370-470).  Legs [vL, (p1.vR)] / [(vL.p0), vR]."""
+    assert min_block_increase >= 0 and expand is not None and expand != 0
+    Y0 = theta.copy(deep=False)
+    Y0.legs = list(theta.legs)
+    if move_right:
+        Y0.legs[1] = Y0.legs[1].to_LegCharge()
+        Y0.ireplace_label('(p1.vR)', 'vR')
+        if np.any(np.asarray(old_qtotal_R) != 0):
+            Y0 = Y0.gauge_total_charge('vR', old_qtotal_L)
+        lab, q_axis = 'vR', 1
+    else:
+        Y0.legs[0] = Y0.legs[0].to_LegCharge()
+        Y0.ireplace_label('(vL.p0)', 'vL')
+        if np.any(np.asarray(old_qtotal_L) != 0):
+            Y0 = Y0.gauge_total_charge('vL', old_qtotal_R)
+        lab, q_axis = 'vL', 0
+    Y0._skey = None
+    v_old = old_bond_leg if old_bond_leg.is_blocked() else old_bond_leg.sort()[1]
+    v_new = Y0.get_leg(lab)
+    keep = np.zeros(v_new.ind_len, dtype=bool)
+    increase = max(min_block_increase, int(v_old.ind_len * expand // v_new.block_number))
+    sizes_old, sizes_new = v_old.get_block_sizes(), v_new.get_block_sizes()
+    norms2 = Y0.axis_sqnorms(q_axis)                       # one device pass instead of a norm per block
+    have_block = np.zeros(v_new.block_number, dtype=bool)
+    have_block[Y0._qdata[:, q_axis]] = True
+    j_old = 0
+    for j_new in range(v_new.block_number):
+        if j_old < v_old.block_number and np.array_equal(v_new.charges[j_new], v_old.charges[j_old]):
+            s_new = sizes_old[j_old] + increase
+            j_old += 1
+        else:
+            s_new = increase
+        s_new = min(int(s_new), int(sizes_new[j_new]))
+        if not have_block[j_new]:
+            continue
+        start = v_new.slices[j_new]
+        nb = norms2[start:v_new.slices[j_new + 1]]
+        keep[start + np.argsort(-nb, kind='stable')[:s_new]] = True
+    Y0.iproject(keep, lab)
+    return Y0
+
+
+def decompose_theta_qr_based(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase,
+                             use_eig_based_svd, trunc_params, compute_err, return_both_T):
+    """theta [(vL.p0), (p1.vR)] ~= renormalization * T_Lc . diag(S) . T_Rc via two QRs and the SVD of the bond
+    matrix (reference truncation.py:533-711; same arguments, same returned tuple
+    ``(T_Lc, S, T_Rc, form, trunc_err, renormalization)``)."""
+    if compute_err:
+        return_both_T = True
+    Y0 = _qr_theta_Y0(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase)
+    if move_right:
+        theta_i1 = npc.tensordot(Y0.conj(), theta, ['(vL*.p0*)', '(vL.p0)']).ireplace_label('vR*', 'vL')
+        theta_i1.itranspose(['(p1.vR)', 'vL'])
+        B_R, _ = npc.qr(theta_i1, inner_labels=['vL', 'vR'], inner_qconj=-1)
+        B_R.itranspose(['vL', '(p1.vR)'])
+        theta_i0 = npc.tensordot(theta, B_R.conj(), ['(p1.vR)', '(p1*.vR*)']).ireplace_label('vL*', 'vR')
+        A_L, Xi = npc.qr(theta_i0, inner_labels=['vR', 'vL'])
+    else:
+        theta_i0 = npc.tensordot(theta, Y0.conj(), ['(p1.vR)', '(p1*.vR*)']).ireplace_label('vL*', 'vR')
+        A_L, _ = npc.qr(theta_i0, inner_labels=['vR', 'vL'])
+        theta_i1 = npc.tensordot(A_L.conj(), theta, ['(vL*.p0*)', '(vL.p0)']).ireplace_label('vR*', 'vL')
+        theta_i1.itranspose(['(p1.vR)', 'vL'])
+        B_R, Xi = npc.qr(theta_i1, inner_labels=['vL', 'vR'], inner_qconj=-1)
+        B_R.itranspose(['vL', '(p1.vR)'])
+        Xi.itranspose(['vL', 'vR'])
+    if use_eig_based_svd:
+        U, S, Vd, _, renormalization = _eig_based_svd(Xi, need_U=move_right, need_Vd=(not move_right),
+                                                      inner_labels=['vR', 'vL'], trunc_params=trunc_params)
+    else:
+        U, S, Vd, _, renormalization = svd_theta(Xi, trunc_params)
+    T_Lc = T_Rc = None
+    form = ['A', 'B']
+    if move_right:
+        T_Lc = npc.tensordot(A_L, U, ['vR', 'vL'])
+        if return_both_T:
+            if use_eig_based_svd:
+                T_Rc = npc.tensordot(Xi, B_R, ['vR', 'vL'])
+                T_Rc = npc.tensordot(U.conj(), T_Rc, ['vL*', 'vL']).ireplace_label('vR*', 'vL')
+                T_Rc.iscale_prefactor(1. / npc.norm(T_Rc))
+                form[1] = 'Th'
+            else:
+                T_Rc = npc.tensordot(Vd, B_R, ['vR', 'vL'])
+    else:
+        T_Rc = npc.tensordot(Vd, B_R, ['vR', 'vL'])
+        if return_both_T:
+            if use_eig_based_svd:
+                T_Lc = npc.tensordot(A_L, Xi, ['vR', 'vL'])
+                T_Lc = npc.tensordot(T_Lc, Vd.conj(), ['vR', 'vR*']).ireplace_label('vL*', 'vR')
+                T_Lc.iscale_prefactor(1. / npc.norm(T_Lc))
+                form[0] = 'Th'
+            else:
+                T_Lc = npc.tensordot(A_L, U, ['vR', 'vL'])
+    if compute_err:
+        if use_eig_based_svd:
+            approx = npc.tensordot(T_Lc, T_Rc, ['vR', 'vL'])
+        else:
+            approx = npc.tensordot(T_Lc.scale_axis(S, axis='vR'), T_Rc, ['vR', 'vL'])
+        N_theta = npc.norm(theta)
+        diff = theta * (1. / N_theta)
+        diff.iadd_prefactor_other(-renormalization / N_theta, approx)
+        eps = npc.norm(diff)**2
+        trunc_err = TruncationError(eps, 1. - 2. * eps)
+    else:
+        trunc_err = TruncationError(np.nan, np.nan)
+    if move_right:
+        T_Lc.ireplace_label('(vL.p0)', '(vL.p)')
+        if return_both_T:
+            T_Rc.ireplace_label('(p1.vR)', '(p.vR)')
+    else:
+        T_Rc.ireplace_label('(p1.vR)', '(p.vR)')
+        if return_both_T:
+            T_Lc.ireplace_label('(vL.p0)', '(vL.p)')
+    return T_Lc, S, T_Rc, form, trunc_err, renormalization

@@ -272,16 +272,6 @@ def gen_lanczos():
     save('lanczos.pkl', out)
 
 
-if __name__ == "__main__" and not os.environ.get("ONLY"):
-    print("reference:", tenpy.__version__, tenpy.__file__)
-    gen_charges()
-    gen_tensordot()
-    gen_reshape()
-    gen_linalg()
-    gen_truncate()
-    gen_lanczos()
-    gen_dmrg()
-    gen_tebd()
 
 
 def gen_tebd():
@@ -304,7 +294,15 @@ def gen_tebd():
                 S_t.append(np.array(psi.entanglement_entropy()))
                 chi_t.append(int(max(psi.chi)))
                 sz_t.append(np.array(psi.expectation_value('Sigmaz')))
-            out.append(dict(name='tfi_quench_L10_%s' % conserve, L=L, J=1., g=1.5, conserve=conserve, dt=0.05, chi=16,
+            psi2 = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+            eng2 = tebd.QRBasedTEBDEngine(psi2, M, {'order': 2, 'dt': 0.05, 'N_steps': 1, 'cbe_expand': 0.5,
+                                                    'trunc_params': {'chi_max': 16, 'svd_min': 1.e-10}})
+            S_qr, chi_qr = [], []
+            for step in range(12):
+                eng2.run()
+                S_qr.append(np.array(psi2.entanglement_entropy()))
+                chi_qr.append(int(max(psi2.chi)))
+            out.append(dict(name='tfi_quench_L10_%s' % conserve, S_qr=np.array(S_qr), chi_qr=chi_qr, L=L, J=1., g=1.5, conserve=conserve, dt=0.05, chi=16,
                             S_t=np.array(S_t), chi_t=chi_t, sigmaz_t=np.array(sz_t), S_mid=np.array(psi.get_SL(L // 2)),
                             h_bond=[None if h is None else h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond],
                             state_labels=list(M.lat.mps_sites()[0].state_labels.items())))
@@ -312,5 +310,44 @@ def gen_tebd():
     save('tebd.pkl', out)
 
 
-if __name__ == '__main__' and os.environ.get('ONLY') == 'tebd':
-    gen_tebd()
+
+
+def gen_qr_theta():
+    """decompose_theta_qr_based on a two-site wave function of a small converged DMRG state, all flag combos."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 12
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        dmrg.run(psi, M, {'mixer': None, 'trunc_params': {'chi_max': 24, 'svd_min': 1e-10}, 'max_sweeps': 4})
+        i0 = L // 2 - 1
+        theta = psi.get_theta(i0, n=2).combine_legs([['vL', 'p0'], ['p1', 'vR']], qconj=[+1, -1])
+        pert = rand_array(theta.legs, qtotal=theta.qtotal, labels=theta.get_leg_labels())
+        theta = theta + 1e-3 * pert
+        B_L, B_R = psi.get_B(i0, 'B'), psi.get_B(i0 + 1, 'B')
+        for move_right in (True, False):
+            for eig in (False, True):
+                for both in (False, True):
+                    T_Lc, S, T_Rc, form, err, renorm = truncation.decompose_theta_qr_based(
+                        B_L.qtotal, B_R.qtotal, B_R.get_leg('vL'), theta, move_right, 0.1, 1, eig,
+                        {'chi_max': 20, 'svd_min': 1e-10}, both, both)
+                    out.append(dict(theta=dump_array(theta), old_qtotal_L=np.array(B_L.qtotal), old_qtotal_R=np.array(B_R.qtotal),
+                                    old_bond_leg=dump_leg(B_R.get_leg('vL')), move_right=move_right, eig=eig, both=both,
+                                    T_Lc=None if T_Lc is None else dump_array(T_Lc), T_Rc=None if T_Rc is None else dump_array(T_Rc),
+                                    S=np.array(S), form=list(form), eps=float(err.eps), renorm=float(renorm)))
+    save('qr_theta.pkl', out)
+
+
+GENERATORS = dict(charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+                  truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
+
+if __name__ == '__main__':
+    print("reference:", tenpy.__version__, tenpy.__file__)
+    only = os.environ.get('ONLY')
+    for name, fn in GENERATORS.items():
+        if only is None or name in only.split(','):
+            fn()

@@ -203,6 +203,18 @@ class MockLib:
             dst[d_off:d_off + pre * ld * post] = sb[:, idx[i_off:i_off + ld], :].reshape(-1)
         return 0
 
+    def tpa_axis_sqnorm_batch(self, code, jobs_p, rows_p, n_rows, x_p, out_p, stream):
+        rows = REG.view(rows_p, np.int32)[:2 * n_rows].reshape(n_rows, 2)
+        jobs_all = REG.view(jobs_p, np.int64)
+        x, out = REG.view(x_p, _npdt(code)), REG.view(out_p, np.float64)
+        for jb, j in rows:
+            if jb < 0:
+                continue
+            x_off, pre, ln, post, o_off, _ = jobs_all[6 * jb:6 * jb + 6]
+            blk = x[x_off:x_off + pre * ln * post].reshape(pre, ln, post)
+            out[o_off + j] = float(np.sum(np.abs(blk[:, j, :])**2))
+        return 0
+
     def tpa_convert(self, cf, ct, n, src_p, dst_p, conj, stream):
         src = REG.view(src_p, _npdt(cf))[:n].copy()
         dst = REG.view(dst_p, _npdt(ct))[:n]

@@ -32,3 +32,21 @@ def test_tebd_quench(backend, name):
         ev.append(np.real(np.einsum('apb,pq,aqb->', d.conj(), sz, d)))
     np.testing.assert_allclose(ev, rec['sigmaz_t'][-1], rtol=0, atol=1e-10)
     assert psi.get_B(0, None).dtype == np.complex128
+
+
+@pytest.mark.parametrize("name", ['tfi_quench_L10_parity', 'tfi_quench_L10_None'])
+def test_qr_tebd_quench(backend, name):
+    """QR-based TEBD (two tensordots + two block QRs + SVD of the small bond matrix) vs the reference's
+    QRBasedTEBDEngine on the same quench."""
+    from tenpy_amd.algorithms.tebd import QRBasedTEBDEngine
+    rec = [r for r in golden('tebd.pkl') if r['name'] == name][0]
+    L = rec['L']
+    _, p = spin_half_leg(rec['conserve'])
+    up = dict(rec['state_labels'])['up']
+    psi = MPS.from_product_state([p] * L, [up] * L, dtype=np.complex128)
+    eng = QRBasedTEBDEngine(psi, rec['h_bond'], {'dt': rec['dt'], 'cbe_expand': 0.5,
+                                                 'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}})
+    for step in range(len(rec['chi_qr'])):
+        eng.evolve_step_order2()
+        assert max(psi.chi) == rec['chi_qr'][step]
+        np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_qr'][step], rtol=0, atol=1e-9)
