@@ -7,7 +7,6 @@ bond gate -> ``scale_axis`` -> ``combine_legs`` -> ``svd_theta`` -> ``split_legs
 matrices built once on the host (``_calc_U_bond`` :585 does the same through ``npc.expm``).
 """
 import numpy as np
-import scipy.linalg  # host-side d^2 x d^2 gate construction only (setup, not the hot path)
 
 from ..linalg import np_conserved as npc
 from ..linalg.truncation import svd_theta, TruncationError, decompose_theta_qr_based
@@ -20,7 +19,8 @@ def bond_gate(h_bond_dense, p_leg, dt, imaginary=False):
     ``h_bond_dense`` has shape (d, d, d, d) = [p0, p1, p0*, p1*]."""
     d = p_leg.ind_len
     h = np.asarray(h_bond_dense).reshape(d * d, d * d)
-    U = scipy.linalg.expm((-dt if imaginary else -1.j * dt) * h).reshape(d, d, d, d)
+    lam, V = np.linalg.eigh(h)      # d^2 x d^2 hermitian bond Hamiltonian: host setup, like the tridiagonal eigh of Lanczos
+    U = ((V * np.exp((-dt if imaginary else -1.j * dt) * lam)) @ V.conj().T).reshape(d, d, d, d)
     return npc.Array.from_ndarray(U, [p_leg, p_leg, p_leg.conj(), p_leg.conj()], dtype=U.dtype,
                                   labels=['p0', 'p1', 'p0*', 'p1*'], cutoff=1e-14, raise_wrong_sector=True)
 
