@@ -16,24 +16,29 @@ import numpy as np
 
 from ..linalg import np_conserved as npc
 
-__all__ = ['TwoSiteH']
+__all__ = ['TwoSiteH', 'DensityMatrixMixer']
 
 
 class TwoSiteH:
     length = 2
     acts_on = ['(vL.p0)', '(p1.vR)']
 
-    def __init__(self, env, i0, combine=True, move_right=True):
+    def __init__(self, env, i0, combine=True, move_right=True, tensors=None):
         if not combine:
             raise NotImplementedError("tenpy_amd.TwoSiteH: only combine=True")
         self.i0 = i0
         self.combine = combine
         self.move_right = move_right
-        self.LP = env.get_LP(i0)
-        self.RP = env.get_RP(i0 + 1)
-        self.W0 = env.H.get_W(i0).replace_labels(['p', 'p*'], ['p0', 'p0*'])
-        self.W1 = env.H.get_W(i0 + 1).replace_labels(['p', 'p*'], ['p1', 'p1*'])
-        self.dtype = env.H.dtype
+        if tensors is not None:      # explicit (LP, RP, W0, W1), e.g. replaying a dumped bond
+            self.LP, self.RP, W0, W1 = tensors
+            self.dtype = W0.dtype
+        else:
+            self.LP = env.get_LP(i0)
+            self.RP = env.get_RP(i0 + 1)
+            W0, W1 = env.H.get_W(i0), env.H.get_W(i0 + 1)
+            self.dtype = env.H.dtype
+        self.W0 = W0.replace_labels(['p', 'p*'], ['p0', 'p0*'])
+        self.W1 = W1.replace_labels(['p', 'p*'], ['p1', 'p1*'])
         self.combine_Heff()
         self._plans = None
         self.N = self.pipeL.ind_len * self.pipeR.ind_len
@@ -102,3 +107,96 @@ class TwoSiteH:
         full = full.transpose(0, 3, 1, 2)                    # out_L, out_R, in_L, in_R
         n = full.shape[0] * full.shape[1]
         return full.reshape(n, n)
+
+
+class DensityMatrixMixer:
+    """Density-matrix perturbation ("mixer") of two-site DMRG -- the npc call sequence of the reference's
+    ``DensityMatrixMixer.mix_rho`` / ``svd_from_rho`` (mps_common.py:1972-2079): four tensordots with the
+    effective Hamiltonian halves, ``iscale_axis`` on the MPO leg and two block ``eigh``.
+
+    ``IdL`` / ``IdR`` are the MPO indices on the bond (i0, i0+1) meaning "only identities to the left / right"
+    (``_mix_LR``, :1846).  Returns a general (non-diagonal) bond matrix ``S`` like the reference.
+    """
+
+    def __init__(self, amplitude=1.e-5, IdL=0, IdR=-1, explicit_plus_hc=False):
+        self.amplitude = amplitude
+        self.IdL, self.IdR = IdL, IdR
+        self.explicit_plus_hc = explicit_plus_hc
+
+    def _mix_LR(self, chi_MPO):
+        mix_L = np.full((chi_MPO,), self.amplitude)
+        mix_R = np.full((chi_MPO,), self.amplitude)
+        one = 1. if not self.explicit_plus_hc else 0.5
+        if self.IdL is not None:
+            mix_L[self.IdL] = one
+            mix_R[self.IdL] = 0.
+        if self.IdR is not None:
+            mix_L[self.IdR] = 0.
+            mix_R[self.IdR] = one
+        return mix_L, mix_R
+
+    def mix_rho(self, eff_H, theta, mix_left, mix_right):
+        """``rho_L`` [(vL.p0), (vL*.p0*)] and ``rho_R`` [(p1.vR), (p1*.vR*)], perturbed with H where requested."""
+        chi_MPO = eff_H.LHeff.get_leg('wR').ind_len
+        mix_L, mix_R = self._mix_LR(chi_MPO)
+        if mix_left:
+            rho_L = npc.tensordot(eff_H.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])
+            rho_L.ireplace_label('(vR*.p0)', '(vL.p0)')
+            rho_c = rho_L.conj()
+            rho_L.iscale_axis(mix_L, 'wR')
+            rho_L = npc.tensordot(rho_L, rho_c, axes=[['wR', '(p1.vR)'], ['wR*', '(p1*.vR*)']])
+            if self.explicit_plus_hc:
+                rho_L = rho_L + rho_L.conj().itranspose()
+            if self.IdL is None:
+                rho_L = rho_L + npc.tensordot(theta, theta.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
+        else:
+            rho_L = npc.tensordot(theta, theta.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
+        if mix_right:
+            # RHeff is stored as [wL, (p1*.vL), (p1.vL*)] (matvec-friendly order)
+            rho_R = npc.tensordot(theta, eff_H.RHeff, axes=['(p1.vR)', '(p1*.vL)'])
+            rho_R.ireplace_label('(p1.vL*)', '(p1.vR)')
+            rho_c = rho_R.conj()
+            rho_R.iscale_axis(mix_R, 'wL')
+            rho_R = npc.tensordot(rho_c, rho_R, axes=[['wL*', '(vL*.p0*)'], ['wL', '(vL.p0)']])
+            if self.explicit_plus_hc:
+                rho_R = rho_R + rho_R.conj().itranspose()
+            if self.IdR is None:
+                rho_R = rho_R + npc.tensordot(theta.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
+        else:
+            rho_R = npc.tensordot(theta.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
+        return rho_L, rho_R
+
+    def svd_from_rho(self, rho_L, rho_R, theta, trunc_params, qtotal_LR=None):
+        """Diagonalise rho_L / rho_R and rewrite theta = U S VH with isometric U, VH and a bond MATRIX S."""
+        from ..linalg.truncation import truncate
+        chinfo = theta.chinfo
+        qL, qR = (None, None) if qtotal_LR is None else qtotal_LR
+        if qL is None and qR is None:
+            qL, qR = chinfo.make_valid(), theta.qtotal
+        elif qL is None:
+            qL = chinfo.make_valid(theta.qtotal - qR)
+        elif qR is None:
+            qR = chinfo.make_valid(theta.qtotal - qL)
+        rho_L = rho_L.transpose(['(vL.p0)', '(vL*.p0*)'])
+        rho_R = rho_R.transpose(['(p1.vR)', '(p1*.vR*)'])
+        val_L, U = npc.eigh(rho_L)
+        U.iset_leg_labels(['(vL.p0)', 'vR'])
+        val_L[val_L < 0.] = 0.
+        val_L /= np.sum(val_L)
+        S_a = np.sqrt(val_L)
+        keep_L, _, err_L = truncate(S_a, trunc_params)
+        U.iproject(keep_L, axes='vR')
+        U = U.gauge_total_charge(1, qL)
+        val_R, Vc = npc.eigh(rho_R)
+        Vc.iset_leg_labels(['(p1.vR)', 'vL'])
+        VH = Vc.itranspose(['vL', '(p1.vR)'])
+        val_R[val_R < 0.] = 0.
+        val_R /= np.sum(val_R)
+        keep_R, _, err_R = truncate(np.sqrt(val_R), trunc_params)
+        VH.iproject(keep_R, axes='vL')
+        VH = VH.gauge_total_charge(0, qR)
+        S = npc.tensordot(U.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
+        S = npc.tensordot(S, VH.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
+        S.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
+        S.iscale_prefactor(1. / S.norm())
+        return U, S, VH, err_L + err_R, S_a[keep_L]

@@ -342,7 +342,43 @@ def gen_qr_theta():
     save('qr_theta.pkl', out)
 
 
-GENERATORS = dict(charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_mixer():
+    """DensityMatrixMixer.mix_rho / svd_from_rho of the reference on a dumped bond (LP, RP, W0, W1, theta)."""
+    from tenpy.algorithms import dmrg, mps_common
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 10
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.3, 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': True, 'mixer_params': {'amplitude': 1.e-2, 'decay': 1., 'disable_after': 100},
+                                              'trunc_params': {'chi_max': 12, 'svd_min': 1e-10}, 'combine': True})
+        eng.sweep()
+        eng.sweep()
+        i0 = L // 2 - 1
+        eng.i0 = i0
+        eng.move_right = True
+        eng.make_eff_H()
+        theta = eng.eff_H.combine_theta(psi.get_theta(i0, n=2))
+        theta = theta + 1e-2 * rand_array(theta.legs, qtotal=theta.qtotal, labels=theta.get_leg_labels())
+        H = M.H_MPO
+        for amplitude in (1e-2, 0.3):
+            mixer = mps_common.DensityMatrixMixer({'amplitude': amplitude, 'decay': 1., 'disable_after': 100}, 0)
+            for ml, mr in ((True, True), (True, False), (False, True)):
+                rho_L, rho_R = mixer.mix_rho(eng, theta, i0, ml, mr)
+                qLR = [psi.get_B(i0, None).qtotal, None]
+                U, S, VH, err, S_a = mixer.svd_from_rho(eng, rho_L.copy(deep=True), rho_R.copy(deep=True), theta, qLR)
+                out.append(dict(LP=dump_array(eng.env.get_LP(i0)), RP=dump_array(eng.env.get_RP(i0 + 1)),
+                                W0=dump_array(H.get_W(i0)), W1=dump_array(H.get_W(i0 + 1)), theta=dump_array(theta),
+                                IdL=H.get_IdL(i0 + 1), IdR=H.get_IdR(i0), amplitude=amplitude, mix_left=ml, mix_right=mr,
+                                rho_L=dump_array(rho_L), rho_R=dump_array(rho_R), S=dump_array(S), S_a=np.array(S_a),
+                                qtotal_L=np.array(qLR[0]), eps=float(err.eps), U=dump_array(U), VH=dump_array(VH), chi_max=12))
+    save('mixer.pkl', out)
+
+
+GENERATORS = dict(mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

@@ -1,0 +1,34 @@
+"""DensityMatrixMixer (mix_rho + svd_from_rho) vs the reference on a dumped bond: same LP, RP, W0, W1, theta in,
+rho_L / rho_R compared entry by entry (gauge free), spectra and the projected bond matrix up to the eigenvector gauge."""
+import numpy as np
+
+from helpers import golden, load_array, assert_array_matches
+from tenpy_amd.algorithms.mps_common import DensityMatrixMixer, TwoSiteH
+from tenpy_amd.linalg import np_conserved as npc
+
+
+def test_mixer(backend):
+    recs = golden('mixer.pkl')
+    assert len(recs) == 6
+    for rec in recs:
+        LP, RP, W0, W1, theta = (load_array(rec[k]) for k in ('LP', 'RP', 'W0', 'W1', 'theta'))
+        eff = TwoSiteH(None, 0, tensors=(LP, RP, W0, W1))
+        # theta of the golden already has the pipes (vL.p0), (p1.vR) as legs: they must equal eff_H's pipes
+        eff.pipeL.test_equal(theta.legs[0])
+        eff.pipeR.test_equal(theta.legs[1])
+        mixer = DensityMatrixMixer(rec['amplitude'], rec['IdL'], rec['IdR'])
+        rho_L, rho_R = mixer.mix_rho(eff, theta, rec['mix_left'], rec['mix_right'])
+        assert_array_matches(rho_L.transpose(rec['rho_L']['labels']), rec['rho_L'], rtol=1e-12)
+        assert_array_matches(rho_R.transpose(rec['rho_R']['labels']), rec['rho_R'], rtol=1e-12)
+        U, S, VH, err, S_a = mixer.svd_from_rho(rho_L, rho_R, theta, {'chi_max': rec['chi_max'], 'svd_min': 1e-10},
+                                                [rec['qtotal_L'], None])
+        np.testing.assert_allclose(S_a, rec['S_a'], rtol=0, atol=1e-11)
+        assert abs(err.eps - rec['eps']) < 1e-11
+        assert_array_matches(U, rec['U'], data=False)
+        assert_array_matches(VH, rec['VH'], data=False)
+        # gauge invariant: U S VH
+        mine = npc.tensordot(npc.tensordot(U, S, axes=['vR', 'vL']), VH, axes=['vR', 'vL']).to_ndarray()
+        ref = rec['U']['dense'] @ rec['S']['dense'] @ rec['VH']['dense']
+        np.testing.assert_allclose(mine, ref, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(np.linalg.svd(S.to_ndarray(), compute_uv=False),
+                                   np.linalg.svd(rec['S']['dense'], compute_uv=False), atol=1e-10)
