@@ -20,6 +20,11 @@ if model == 'xxz':
     H = xxz_chain_mpo(L, 1., 1., 0.)
     chinfo, p = spin_half_leg('Sz')
     psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
+elif model == 'hubbard':
+    from tenpy_amd.models.hubbard import hubbard_ladder_mpo, spinful_fermion_leg
+    H = hubbard_ladder_mpo(L // 2, 1., 8., 0.)
+    chinfo, p = spinful_fermion_leg()
+    psi = MPS.from_product_state([p] * L, [1, 2] * (L // 2))
 else:
     H = tfi_chain_mpo(L, 1., 1., None)
     chinfo, p = spin_half_leg(None)

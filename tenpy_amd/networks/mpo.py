@@ -38,7 +38,10 @@ def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64):
     L = len(W_dense_list)
     Ws = []
     q_left = np.zeros((W_dense_list[0].shape[0], chinfo.qnumber), dtype=np.int64)
+    known_left = np.ones(W_dense_list[0].shape[0], dtype=bool)
     for i, Wd in enumerate(W_dense_list):
+        Wd = np.array(Wd)
+        Wd[~known_left] = 0.          # states that cannot be reached from the left never contribute
         Dl, Dr, d, _ = Wd.shape
         p = p_legs[i]
         pq = p.to_qflat() * p.qconj
@@ -60,7 +63,7 @@ def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64):
         W = npc.Array.from_ndarray(Wd, [wL, wR, p, p.conj()], dtype=dtype, qtotal=None if chinfo.qnumber == 0 else chinfo.make_valid(),
                                    labels=['wL', 'wR', 'p', 'p*'])
         Ws.append(W)
-        q_left = q_right
+        q_left, known_left = q_right, known
     return MPO(p_legs, Ws)
 
 

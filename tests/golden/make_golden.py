@@ -378,7 +378,32 @@ def gen_mixer():
     save('mixer.pkl', out)
 
 
-GENERATORS = dict(mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_hubbard():
+    """BASELINE config 4 in small: Fermi-Hubbard 2 x 4 ladder, charges (N, 2Sz), two-site DMRG chi=64."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.hubbard import FermiHubbardModel
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for Lx, chi in ((3, 40), (4, 64)):
+            M = FermiHubbardModel({'lattice': 'Ladder', 'L': Lx, 't': 1., 'U': 8., 'mu': 0., 'cons_N': 'N', 'cons_Sz': 'Sz',
+                                   'bc_MPS': 'finite', 'sort_charge': True})
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * Lx, bc='finite')
+            eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
+                                                  'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}})
+            Es, chis = [], []
+            for s in range(6):
+                eng.sweep()
+                Es.append(float(eng.update_stats['E_total'][-1]))
+                chis.append(int(max(psi.chi)))
+            out.append(dict(name='hubbard_ladder_2x%d' % Lx, Lx=Lx, chi=chi, t=1., U=8., mu=0., E_sweeps=Es, chi_sweeps=chis,
+                            S_ent=np.array(psi.entanglement_entropy()), D_mpo=max(M.H_MPO.chi)))
+            print(out[-1]['name'], Es[-1], chis[-1], 'MPO D', max(M.H_MPO.chi))
+    save('hubbard.pkl', out)
+
+
+GENERATORS = dict(hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
