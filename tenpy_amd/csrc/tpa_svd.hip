@@ -683,6 +683,272 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Complex (Hermitian) version of the split block-Jacobi round.  Same structure; chunks are 32 complex columns
+// (512 B per row segment), re / im planes in LDS, 4 real MFMAs per complex product.
+//   S = X X^H :  Re S = Xr Xr^T + Xi Xi^T ,  Im S = Xi Xr^T - Xr Xi^T
+//   rotation of rows (p, q) with gamma = S_pq = |gamma| e^{i phi}:
+//       x_p' = c x_p - s e^{i phi} x_q ,   x_q' = s e^{-i phi} x_p + c x_q          (same as svd_round_kernel<true>)
+constexpr int CHC = 32;
+constexpr int CHCP = CHC + 1;
+
+__global__ __launch_bounds__(NTG) void svd_gram_part_kernel_c(const SvdJob *__restrict__ jobs,
+                                                              const BEntry *__restrict__ entries, int round,
+                                                              const double2 *__restrict__ W,
+                                                              double *__restrict__ gpart) {
+    __shared__ double Xr[NTG / 64][TRJ][CHCP], Xi[NTG / 64][TRJ][CHCP];
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int half = lane >> 5, l31 = lane & 31;  // two rows per load instruction: lanes 0-31 row t, 32-63 row t+1
+    int64_t rowoff[TRJ];
+#pragma unroll
+    for (int t = 0; t < TRJ; ++t) {
+        const int64_t b = (t < BRJ) ? bi : bj;
+        const int64_t r = b * BRJ + (t % BRJ);
+        rowoff[t] = (b < NB && r < R) ? r : -1;
+    }
+    const int64_t nchunk = (L + CHC - 1) / CHC;
+    const int64_t c_lo = nchunk * E.part / E.nparts, c_hi = nchunk * (E.part + 1) / E.nparts;
+    d4 ar0 = {0, 0, 0, 0}, ai0 = {0, 0, 0, 0};
+    const double2 *Wb = W + J.w_off;
+    for (int64_t c = c_lo + wave; c < c_hi; c += NTG / 64) {
+        const int64_t col = c * CHC + l31;
+#pragma unroll
+        for (int t = 0; t < TRJ; t += 2) {
+            const int64_t ro = half ? rowoff[t + 1] : rowoff[t];
+            const double2 v = (ro >= 0 && col < L) ? Wb[ro * L + col] : double2{0, 0};
+            Xr[wave][t + half][l31] = v.x;
+            Xi[wave][t + half][l31] = v.y;
+        }
+#pragma unroll
+        for (int ks = 0; ks < CHC / 4; ++ks) {
+            const double xr = Xr[wave][l15][ks * 4 + l4], xi = Xi[wave][l15][ks * 4 + l4];
+            ar0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, ar0, 0, 0, 0);
+            ar0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, ar0, 0, 0, 0);
+            ai0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xr, ai0, 0, 0, 0);
+            ai0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, xi, ai0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Xr[wave][l4 + 4 * r][l15] = ar0[r];
+        Xi[wave][l4 + 4 * r][l15] = ai0[r];
+    }
+    __syncthreads();
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double sr = 0, si = 0;
+#pragma unroll
+        for (int w = 0; w < NTG / 64; ++w) {
+            sr += Xr[w][i][j];
+            si += Xi[w][i][j];
+        }
+        gpart[(int64_t)blockIdx.x * 512 + tid] = sr;
+        gpart[(int64_t)blockIdx.x * 512 + 256 + tid] = si;
+    }
+}
+
+__global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__restrict__ jobs,
+                                                                const BEntry *__restrict__ entries, int round,
+                                                                double2 *__restrict__ W, double2 *__restrict__ G,
+                                                                const double *__restrict__ gpart,
+                                                                unsigned int *__restrict__ n_rot,
+                                                                const double *__restrict__ fro2, double rho,
+                                                                int local_sweeps, int full_local) {
+    __shared__ double Xr[NTG / 64][TRJ][CHCP], Xi[NTG / 64][TRJ][CHCP];
+    __shared__ double Sr[TRJ][TRJ + 1], Si[TRJ][TRJ + 1], Qr[TRJ][TRJ + 1], Qi[TRJ][TRJ + 1];
+    __shared__ double csA[TRJ], cprA[TRJ], cpiA[TRJ];
+    __shared__ int partA[TRJ];
+    __shared__ int any_flag;
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int half = lane >> 5, l31 = lane & 31;
+    int64_t rowoff[TRJ];
+#pragma unroll
+    for (int t = 0; t < TRJ; ++t) {
+        const int64_t b = (t < BRJ) ? bi : bj;
+        const int64_t r = b * BRJ + (t % BRJ);
+        rowoff[t] = (b < NB && r < R) ? r : -1;
+    }
+    {
+        const int64_t first = (int64_t)blockIdx.x - E.part;
+        double sr = 0, si = 0;
+        for (int p = 0; p < E.nparts; ++p) {
+            sr += gpart[(first + p) * 512 + tid];
+            si += gpart[(first + p) * 512 + 256 + tid];
+        }
+        Sr[tid >> 4][tid & 15] = sr;
+        Si[tid >> 4][tid & 15] = si;
+        Qr[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+        Qi[tid >> 4][tid & 15] = 0.0;
+    }
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[E.job];
+    {
+        const int ei = tid >> 4, ej = tid & 15;
+        const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
+        if (relevant && svd_needs_rotation(Sr[ei][ei], Sr[ej][ej], Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej], tol, floor2))
+            any_flag = 1;
+    }
+    __syncthreads();
+    if (any_flag == 0) return;
+    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
+
+    if (wave == 0) {
+        const int ei = lane >> 2, ej0 = (lane & 3) * 4;
+        const int n_local = full_local ? (TRJ - 1) : BRJ;
+        for (int sweep = 0; sweep < local_sweeps; ++sweep) {
+            bool rotated = false;
+            for (int rr = 0; rr < n_local; ++rr) {
+                if (lane < TRJ) {
+                    const int i = lane;
+                    int pi;
+                    if (full_local) {
+                        if (i == TRJ - 1)
+                            pi = rr;
+                        else if (i == rr)
+                            pi = TRJ - 1;
+                        else
+                            pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1);
+                    } else {
+                        pi = (i < BRJ) ? (BRJ + ((i + rr) & (BRJ - 1))) : (((i - BRJ) - rr) & (BRJ - 1));
+                    }
+                    const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
+                    const double a = Sr[p][p], b = Sr[q][q], gr = Sr[p][q], gi = Si[p][q];
+                    const double g2 = gr * gr + gi * gi;
+                    double c = 1.0, sre = 0.0, sim = 0.0;   // s e^{i phi}
+                    if (svd_needs_rotation(a, b, g2, tol, floor2)) {
+                        const double gabs = sqrt(g2);
+                        const double ig = __builtin_amdgcn_rcp(gabs);
+                        const double zeta = (b - a) * 0.5 * ig;
+                        const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
+                        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
+                        const double x = fma(t, t, 1.0);
+                        double c0 = __builtin_amdgcn_rsq(x);
+                        c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        c = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        const double s = c * t;
+                        // unit phase to full precision: (gr, gi) / |gamma| with a Newton-refined reciprocal
+                        double ig2 = ig * (2.0 - gabs * ig);
+                        ig2 = ig2 * (2.0 - gabs * ig2);
+                        sre = s * gr * ig2;
+                        sim = s * gi * ig2;
+                        rotated = true;
+                    }
+                    partA[i] = pi;
+                    csA[i] = c;
+                    // row p: x' = c x - s e^{i phi} y ; row q: y' = s e^{-i phi} x + c y
+                    cprA[i] = (i == p) ? -sre : sre;
+                    cpiA[i] = (i == p) ? -sim : -sim;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    const int pi = partA[ei];
+                    const double cs = csA[ei], cr = cprA[ei], ci = cpiA[ei];
+                    double nsr[4], nsi[4], nqr[4], nqi[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ej = ej0 + u;
+                        const double yr = Sr[pi][ej], yi = Si[pi][ej];
+                        nsr[u] = cs * Sr[ei][ej] + (cr * yr - ci * yi);
+                        nsi[u] = cs * Si[ei][ej] + (cr * yi + ci * yr);
+                        const double zr = Qr[pi][ej], zi = Qi[pi][ej];
+                        nqr[u] = cs * Qr[ei][ej] + (cr * zr - ci * zi);
+                        nqi[u] = cs * Qi[ei][ej] + (cr * zi + ci * zr);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        Sr[ei][ej0 + u] = nsr[u];
+                        Si[ei][ej0 + u] = nsi[u];
+                        Qr[ei][ej0 + u] = nqr[u];
+                        Qi[ei][ej0 + u] = nqi[u];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    // columns: S <- S J^H : S[.][j] = S[.][j] conj(cs_j) + S[.][pj] conj(cp_j)
+                    double nsr[4], nsi[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ej = ej0 + u, pj = partA[ej];
+                        const double cr = cprA[ej], ci = -cpiA[ej];
+                        const double yr = Sr[ei][pj], yi = Si[ei][pj];
+                        nsr[u] = csA[ej] * Sr[ei][ej] + (cr * yr - ci * yi);
+                        nsi[u] = csA[ej] * Si[ei][ej] + (cr * yi + ci * yr);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        Sr[ei][ej0 + u] = nsr[u];
+                        Si[ei][ej0 + u] = nsi[u];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (!__any(rotated)) break;
+        }
+    }
+    __syncthreads();
+
+    // ---- apply X <- Q X (complex): Xr' = Qr Xr - Qi Xi ; Xi' = Qr Xi + Qi Xr
+    double qar[4], qai[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qar[kk] = Qr[l15][kk * 4 + l4];
+        qai[kk] = Qi[l15][kk * 4 + l4];
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        double2 *M = (pass == 0) ? (W + J.w_off) : (G + J.g_off);
+        const int64_t len = (pass == 0) ? L : R;
+        const int64_t nch = (len + CHC - 1) / CHC;
+        const int64_t c_lo = nch * E.part / E.nparts, c_hi = nch * (E.part + 1) / E.nparts;
+        for (int64_t c = c_lo + wave; c < c_hi; c += NTG / 64) {
+            const int64_t col = c * CHC + l31;
+#pragma unroll
+            for (int t = 0; t < TRJ; t += 2) {
+                const int64_t ro = half ? rowoff[t + 1] : rowoff[t];
+                const double2 v = (ro >= 0 && col < len) ? M[ro * len + col] : double2{0, 0};
+                Xr[wave][t + half][l31] = v.x;
+                Xi[wave][t + half][l31] = v.y;
+            }
+#pragma unroll
+            for (int tile = 0; tile < CHC / 16; ++tile) {
+                d4 orr = {0, 0, 0, 0}, oii = {0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double br = Xr[wave][kk * 4 + l4][tile * 16 + l15], bim = Xi[wave][kk * 4 + l4][tile * 16 + l15];
+                    orr = __builtin_amdgcn_mfma_f64_16x16x4f64(qar[kk], br, orr, 0, 0, 0);
+                    orr = __builtin_amdgcn_mfma_f64_16x16x4f64(-qai[kk], bim, orr, 0, 0, 0);
+                    oii = __builtin_amdgcn_mfma_f64_16x16x4f64(qar[kk], bim, oii, 0, 0, 0);
+                    oii = __builtin_amdgcn_mfma_f64_16x16x4f64(qai[kk], br, oii, 0, 0, 0);
+                }
+                const int64_t oc = c * CHC + tile * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gr = rowoff[l4 + 4 * r];
+                    if (gr >= 0 && oc < len) M[gr * len + oc] = double2{orr[r], oii[r]};
+                }
+            }
+        }
+    }
+}
+
 template <bool CPLX>
 __global__ __launch_bounds__(NT) void svd_norms_kernel(const SvdJob *__restrict__ jobs,
                                                        const int2 *__restrict__ rows,
@@ -795,7 +1061,7 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
             const int64_t NB = (J.R + 7) / 8, NBp = (NB + 1) / 2 * 2;
             for (int64_t p = 0; p < NBp / 2; ++p) lay.bpairs.push_back(int2{b, (int)p});
             // column parts: >= 4 chunks of 64 columns each, at most 8 parts
-            const int64_t nchunk = (J.L + 63) / 64;
+            const int64_t nchunk = (J.L + 63) / 64;   // (complex kernels use 32-column chunks: twice as many)
             int nparts = (int)std::min<int64_t>(8, std::max<int64_t>(1, nchunk / 4));
             for (int64_t p = 0; p < NBp / 2; ++p)
                 for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
@@ -825,7 +1091,7 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     lay.off_bent = o;
     o = align_up(o + (int64_t)lay.bentries.size() * sizeof(BEntry), 256);
     lay.off_gpart = o;
-    o = align_up(o + (int64_t)lay.bentries.size() * 256 * 8, 256);
+    o = align_up(o + (int64_t)lay.bentries.size() * 512 * 8, 256);
     lay.off_cnt = o;
     o = align_up(o + 256, 256);
     lay.off_fro = o;
@@ -871,13 +1137,16 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     TPA_LAUNCH_CHECK();
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
-    const bool use_block = !CPLX && !tpa_svd_force_pairwise;
+    const bool use_block = !tpa_svd_force_pairwise && (!CPLX || tpa_svd_split);
     const int rounds = use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1)
                                  : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
-            if (use_block && tpa_svd_split) {
+            if (use_block && tpa_svd_split && CPLX) {
+                svd_gram_part_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (const double2 *)W, gpart);
+                svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
+            } else if (use_block && tpa_svd_split) {
                 svd_gram_part_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, gpart);
                 svd_solve_apply_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
             } else if (use_block)
