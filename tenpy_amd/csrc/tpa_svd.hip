@@ -949,6 +949,255 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Wide" real block-Jacobi round: blocks of 16 rows, 32 rows per pair.  Half as many rounds (launches) per
+// sweep as the 8-row version; the 32 x 32 local problem is still solved by one wavefront (16 elements per
+// lane), and the streaming phases are spread over column parts, so a round costs about the same.
+constexpr int BRW = 16;
+constexpr int TRW = 32;
+constexpr int CHW = 32;           // columns per staged chunk
+constexpr int CHWP = CHW + 1;
+
+__device__ __forceinline__ void block_pair_of_w(const SvdJob &J, int pair, int round, int64_t &bi, int64_t &bj,
+                                                int64_t &NB) {
+    NB = (J.R + BRW - 1) / BRW;
+    const int64_t NBp = (NB + 1) / 2 * 2;
+    const int64_t mod = NBp - 1;
+    const int64_t r = (mod > 0) ? (round % mod) : 0;
+    if (pair == 0) {
+        bi = NBp - 1;
+        bj = r;
+    } else {
+        bi = (r + pair) % mod;
+        bj = (r - pair + mod) % mod;
+    }
+    if (bi > bj) {
+        const int64_t t = bi;
+        bi = bj;
+        bj = t;
+    }
+}
+
+__global__ __launch_bounds__(NTG) void svd_gram_part_kernel_w(const SvdJob *__restrict__ jobs,
+                                                              const BEntry *__restrict__ entries, int round,
+                                                              const double *__restrict__ W,
+                                                              double *__restrict__ gpart) {
+    __shared__ double Xs[NTG / 64][TRW][CHWP];
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of_w(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int64_t nchunk = (L + CHW - 1) / CHW;
+    const int64_t c_lo = nchunk * E.part / E.nparts, c_hi = nchunk * (E.part + 1) / E.nparts;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0, 0, 0, 0};
+    const double *Wb = W + J.w_off;
+    // this lane's row for load instruction t (t = 0..15): local row 2t + half
+    for (int64_t c = c_lo + wave; c < c_hi; c += NTG / 64) {
+        const int64_t col = c * CHW + l31;
+#pragma unroll
+        for (int t = 0; t < TRW / 2; ++t) {
+            const int lr = 2 * t + half;
+            const int64_t b = (lr < BRW) ? bi : bj;
+            const int64_t r = b * BRW + (lr & (BRW - 1));
+            Xs[wave][lr][l31] = (b < NB && r < R && col < L) ? Wb[r * L + col] : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < CHW / 4; ++ks) {
+            const double f0 = Xs[wave][l15][ks * 4 + l4], f1 = Xs[wave][16 + l15][ks * 4 + l4];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, acc[1][1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // partial 32 x 32 of this wave -> Xs[wave][row][col]  (row = a*16 + l4 + 4r, col = b*16 + l15)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[wave][a * 16 + l4 + 4 * r][b * 16 + l15] = acc[a][b][r];
+    __syncthreads();
+    for (int e = tid; e < TRW * TRW; e += NTG) {
+        const int i = e >> 5, j = e & 31;
+        double sacc = 0;
+#pragma unroll
+        for (int w = 0; w < NTG / 64; ++w) sacc += Xs[w][i][j];
+        gpart[(int64_t)blockIdx.x * 1024 + e] = sacc;
+    }
+}
+
+__global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_w(const SvdJob *__restrict__ jobs,
+                                                                const BEntry *__restrict__ entries, int round,
+                                                                double *__restrict__ W, double *__restrict__ G,
+                                                                const double *__restrict__ gpart,
+                                                                unsigned int *__restrict__ n_rot,
+                                                                const double *__restrict__ fro2, double rho,
+                                                                int local_sweeps, int full_local) {
+    __shared__ double Xs[NTG / 64][TRW][CHWP];
+    __shared__ double Sm[TRW][TRW + 1], Qm[TRW][TRW + 1];
+    __shared__ double csA[TRW], cpA[TRW];
+    __shared__ int partA[TRW];
+    __shared__ int any_flag;
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of_w(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int half = lane >> 5, l31 = lane & 31;
+    {
+        const int64_t first = (int64_t)blockIdx.x - E.part;
+        for (int e = tid; e < TRW * TRW; e += NTG) {
+            double sacc = 0;
+            for (int p = 0; p < E.nparts; ++p) sacc += gpart[(first + p) * 1024 + e];
+            Sm[e >> 5][e & 31] = sacc;
+            Qm[e >> 5][e & 31] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;
+        }
+    }
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[E.job];
+    for (int e = tid; e < TRW * TRW; e += NTG) {
+        const int ei = e >> 5, ej = e & 31;
+        const bool relevant = full_local ? (ei < ej) : (ei < BRW && ej >= BRW);
+        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2)) any_flag = 1;
+    }
+    __syncthreads();
+    if (any_flag == 0) return;
+    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
+
+    if (wave == 0) {
+        const int ei = lane >> 1, ej0 = (lane & 1) * 16;   // 2 lanes per row, 16 elements per lane
+        const int n_local = full_local ? (TRW - 1) : BRW;
+        for (int sweep = 0; sweep < local_sweeps; ++sweep) {
+            bool rotated = false;
+            for (int rr = 0; rr < n_local; ++rr) {
+                if (lane < TRW) {
+                    const int i = lane;
+                    int pi;
+                    if (full_local) {
+                        if (i == TRW - 1)
+                            pi = rr;
+                        else if (i == rr)
+                            pi = TRW - 1;
+                        else
+                            pi = (2 * rr - i + 2 * (TRW - 1)) % (TRW - 1);
+                    } else {
+                        pi = (i < BRW) ? (BRW + ((i + rr) & (BRW - 1))) : (((i - BRW) - rr) & (BRW - 1));
+                    }
+                    const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
+                    const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
+                    double c = 1.0, s = 0.0;
+                    if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
+                        const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
+                        const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
+                        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
+                        const double x = fma(t, t, 1.0);
+                        double c0 = __builtin_amdgcn_rsq(x);
+                        c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        c = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        s = c * t;
+                        rotated = true;
+                    }
+                    partA[i] = pi;
+                    csA[i] = c;
+                    cpA[i] = (i == p) ? -s : s;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    const int pi = partA[ei];
+                    const double cs = csA[ei], cp = cpA[ei];
+                    double s_new[16], q_new[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        s_new[u] = cs * Sm[ei][ej0 + u] + cp * Sm[pi][ej0 + u];
+                        q_new[u] = cs * Qm[ei][ej0 + u] + cp * Qm[pi][ej0 + u];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        Sm[ei][ej0 + u] = s_new[u];
+                        Qm[ei][ej0 + u] = q_new[u];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    double s_new[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int ej = ej0 + u, pj = partA[ej];
+                        s_new[u] = csA[ej] * Sm[ei][ej] + cpA[ej] * Sm[ei][pj];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) Sm[ei][ej0 + u] = s_new[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (!__any(rotated)) break;
+        }
+    }
+    __syncthreads();
+
+    // ---- apply: X <- Q X, Q is 32 x 32: two output row tiles, K = 32 (8 MFMA k-steps)
+    double qa[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qa[a][kk] = Qm[a * 16 + l15][kk * 4 + l4];
+    for (int pass = 0; pass < 2; ++pass) {
+        double *M = (pass == 0) ? (W + J.w_off) : (G + J.g_off);
+        const int64_t len = (pass == 0) ? L : R;
+        const int64_t nch = (len + CHW - 1) / CHW;
+        const int64_t c_lo = nch * E.part / E.nparts, c_hi = nch * (E.part + 1) / E.nparts;
+        for (int64_t c = c_lo + wave; c < c_hi; c += NTG / 64) {
+            const int64_t col = c * CHW + l31;
+#pragma unroll
+            for (int t = 0; t < TRW / 2; ++t) {
+                const int lr = 2 * t + half;
+                const int64_t b = (lr < BRW) ? bi : bj;
+                const int64_t r = b * BRW + (lr & (BRW - 1));
+                Xs[wave][lr][l31] = (b < NB && r < R && col < len) ? M[r * len + col] : 0.0;
+            }
+#pragma unroll
+            for (int tile = 0; tile < CHW / 16; ++tile) {
+                d4 o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
+                    o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0][kk], bb, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[1][kk], bb, o1, 0, 0, 0);
+                }
+                const int64_t oc = c * CHW + tile * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int lr = a * 16 + l4 + 4 * r;
+                        const int64_t b = (lr < BRW) ? bi : bj;
+                        const int64_t gr = b * BRW + (lr & (BRW - 1));
+                        if (b < NB && gr < R && oc < len) M[gr * len + oc] = (a == 0) ? o0[r] : o1[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool CPLX>
 __global__ __launch_bounds__(NT) void svd_norms_kernel(const SvdJob *__restrict__ jobs,
                                                        const int2 *__restrict__ rows,
@@ -1015,6 +1264,8 @@ __global__ __launch_bounds__(NT) void svd_finish_kernel(const SvdJob *__restrict
 
 int tpa_svd_local_sweeps = 1;
 int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block pairs
+int tpa_svd_wide = 0;   // 16-row blocks (32 x 32 local problems): half the rounds, but measured 1.2-1.5x SLOWER (one-wavefront
+                        // 32 x 32 solve dominates); kept as a tuning option, off by default
 int tpa_svd_split = 1;  // 1: gram / solve+apply kernels over column parts, 0: one fused workgroup per block pair
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
 
@@ -1024,11 +1275,13 @@ struct Layout {
     std::vector<int2> pairs;  // (job,pair)
     std::vector<int2> bpairs; // (job, block pair) for the block-Jacobi rounds
     std::vector<BEntry> bentries;  // (job, pair, part, nparts) for the split rounds
+    std::vector<BEntry> wentries;  // same for the wide (16-row block) rounds
+    int64_t nbw_max_pad = 0;
     int64_t nb_max_pad = 0;
     int64_t w_elems = 0, g_elems = 0, sig_elems = 0, rmax_pad = 0;
     // byte offsets inside work buffer
     int64_t off_w = 0, off_g = 0, off_sig = 0, off_perm = 0, off_jobs = 0, off_rows = 0, off_pairs = 0,
-            off_bpairs = 0, off_bent = 0, off_gpart = 0, off_cnt = 0, off_fro = 0, off_fpart = 0, total = 0;
+            off_bpairs = 0, off_bent = 0, off_went = 0, off_gpart = 0, off_cnt = 0, off_fro = 0, off_fpart = 0, total = 0;
 };
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -1066,6 +1319,11 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
             for (int64_t p = 0; p < NBp / 2; ++p)
                 for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
             lay.nb_max_pad = std::max(lay.nb_max_pad, NBp);
+            const int64_t NBw = (J.R + 15) / 16, NBwp = (NBw + 1) / 2 * 2;
+            const int wparts = (int)std::min<int64_t>(16, std::max<int64_t>(1, (J.L + 31) / 32 / 6));
+            for (int64_t p = 0; p < NBwp / 2; ++p)
+                for (int q = 0; q < wparts; ++q) lay.wentries.push_back(BEntry{b, (int)p, q, wparts});
+            lay.nbw_max_pad = std::max(lay.nbw_max_pad, NBwp);
         }
         lay.jobs.push_back(J);
     }
@@ -1090,8 +1348,10 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.bpairs.size() * sizeof(int2), 256);
     lay.off_bent = o;
     o = align_up(o + (int64_t)lay.bentries.size() * sizeof(BEntry), 256);
+    lay.off_went = o;
+    o = align_up(o + (int64_t)lay.wentries.size() * sizeof(BEntry), 256);
     lay.off_gpart = o;
-    o = align_up(o + (int64_t)lay.bentries.size() * 512 * 8, 256);
+    o = align_up(o + (int64_t)std::max(lay.bentries.size() * 512, lay.wentries.size() * 1024) * 8, 256);
     lay.off_cnt = o;
     o = align_up(o + 256, 256);
     lay.off_fro = o;
@@ -1119,6 +1379,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     int2 *bpairs = (int2 *)(work + lay.off_bpairs);
     BEntry *bent = (BEntry *)(work + lay.off_bent);
     double *gpart = (double *)(work + lay.off_gpart);
+    BEntry *went = (BEntry *)(work + lay.off_went);
+    TPA_HIP_CHECK(hipMemcpyAsync(went, lay.wentries.data(), lay.wentries.size() * sizeof(BEntry), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(bent, lay.bentries.data(), lay.bentries.size() * sizeof(BEntry), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(bpairs, lay.bpairs.data(), lay.bpairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     // pageable host memory: the copies above are staged before returning, vectors may die later.
@@ -1138,12 +1400,16 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
     const bool use_block = !tpa_svd_force_pairwise && (!CPLX || tpa_svd_split);
-    const int rounds = use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1)
+    const bool use_wide = use_block && tpa_svd_split && !CPLX && tpa_svd_wide;
+    const int rounds = use_wide ? (int)std::max<int64_t>(lay.nbw_max_pad - 1, 1) : use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1)
                                  : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
-            if (use_block && tpa_svd_split && CPLX) {
+            if (use_wide) {
+                svd_gram_part_kernel_w<<<(int)lay.wentries.size(), NTG, 0, st>>>(jobs, went, r, W, gpart);
+                svd_solve_apply_kernel_w<<<(int)lay.wentries.size(), NTG, 0, st>>>(jobs, went, r, W, G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
+            } else if (use_block && tpa_svd_split && CPLX) {
                 svd_gram_part_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (const double2 *)W, gpart);
                 svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
             } else if (use_block && tpa_svd_split) {
@@ -1373,7 +1639,8 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
 extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_force_pairwise = (pairwise & 1) ? 1 : 0;
     tpa_svd_split = (pairwise & 2) ? 0 : 1;
-    tpa_svd_cross_only = (pairwise & 4) ? 0 : 1;   // bit 2: full 16x16 local sweep in every round   // bit 1: fused single-workgroup block kernel
+    tpa_svd_cross_only = (pairwise & 4) ? 0 : 1;
+    tpa_svd_wide = (pairwise & 8) ? 1 : 0;         // bit 3: 16-row blocks   // bit 2: full 16x16 local sweep in every round   // bit 1: fused single-workgroup block kernel
     if (pairwise >= 16) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
 }
