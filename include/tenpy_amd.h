@@ -118,11 +118,16 @@ int tpa_gemm_set_variant(int v);
 
 /* ---- K5: batched block SVD, one-sided (Hestenes) Jacobi -- replaces svd_flat / LAPACK gesdd
  *      per charge block (np_conserved.py:4970-4980 via svd_robust.py:36-75) ---------------
- * jobs : int64[n_jobs][8] = {a_off, m, n, u_off, s_off, vh_off, 0, 0}  (HOST pointer)
+ * jobs : int64[n_jobs][8] = {a_off, m, n, u_off, s_off, vh_off, flags, 0}  (HOST pointer)
+ *   flags bit 0 (square blocks only): orthogonalise the rows of A instead of its columns (default 0).
  *   A_b is m x n row-major at a_off in a_base; on return
  *   U_b (m x k, row-major, k=min(m,n)) at u_off in u_base, S_b (k, descending) at s_off in s_dev
  *   (always real), VH_b (k x n, row-major) at vh_off in vh_base.  A is NOT overwritten.
  * work_dev: >= tpa_svd_worksize(...) bytes.  Synchronises the stream (sweep-convergence test).
+ * Real data, min(m,n) >= 32: the blocks are first reduced by a rank-revealing Householder QR with column
+ *   pivoting (X P = Q [R;0], X = A or A^T); the Jacobi iteration then runs on the r x min(m,n) factor only
+ *   (r = numerical rank: residual column norms <= 1e-15 ||A||_F).  Singular values below that threshold are
+ *   returned as exact zeros with zero singular vectors (LAPACK returns rounding noise there).
  * Returns TPA_E_NOCONV if max_sweeps is exhausted, TPA_E_NAN if the input holds NaN/Inf.
  */
 int64_t tpa_svd_worksize(int dtype, const int64_t *jobs_host, int n_jobs);
@@ -130,8 +135,8 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
                   void *u_base, double *s_dev, void *vh_base, void *work_dev, int64_t work_bytes,
                   int max_sweeps, double tol, int *sweeps_done, void *stream);
 
-/* Algorithm switch for real data: 0 (default) = block Jacobi (16-row MFMA Gram + in-LDS eigen-solve),
- * 1 = one wavefront per row pair (always used for complex). */
+/* Algorithm switch (test / benchmark hook): 0 (default) = pivoted-QR preconditioner + block Jacobi (16-row MFMA
+ * Gram + in-LDS eigen-solve); bit 0 = one wavefront per row pair; bit 9 (512) = no pivoted-QR preconditioner. */
 int tpa_svd_set_algorithm(int pairwise);
 
 /* ---- K6: batched Householder QR (np.linalg.qr per block, np_conserved.py:4190) ----------

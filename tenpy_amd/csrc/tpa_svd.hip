@@ -25,8 +25,9 @@ namespace {
 
 constexpr int NT = 256;  // 4 wavefronts = 4 row pairs per workgroup
 
-struct SvdJob {  // int64[12], device copy
+struct SvdJob {  // int64[13], device copy
     int64_t w_off, g_off, R, L, Rpad, a_off, m, n, u_off, s_off, vh_off, sig_off;
+    int64_t tr;   // 1: W = A^T (rows of W = columns of A), 0: W = A.  m == n: host flag bit 0 of jobs[6] selects W = A
 };
 
 template <bool CPLX>
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(NT) void svd_init_kernel(const SvdJob *__restrict__
     if (jr.x < 0) return;
     const SvdJob J = jobs[jr.x];
     const int64_t r = jr.y;
-    const bool tr = (J.m >= J.n);
+    const bool tr = (J.tr != 0);
     for (int64_t c = lane; c < J.L; c += 64) {
         const int64_t src = J.a_off + (tr ? (c * J.n + r) : (r * J.n + c));
         if (CPLX)
@@ -1235,7 +1236,7 @@ __global__ __launch_bounds__(NT) void svd_finish_kernel(const SvdJob *__restrict
     const int64_t j = perm[J.sig_off + jj];
     const double sg = sig[J.sig_off + j];
     const double inv = (sg > 0.0) ? 1.0 / sg : 0.0;
-    const bool tr = (J.m >= J.n);
+    const bool tr = (J.tr != 0);
     const int64_t k = J.R;
     if (lane == 0) S[J.s_off + jj] = sg;
     // Y row j = W[j,:]/sigma  -> VH row (m<n) or U column (m>=n)
@@ -1612,6 +1613,7 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         J.u_off = j[3];
         J.s_off = j[4];
         J.vh_off = j[5];
+        J.tr = (J.m > J.n || (J.m == J.n && !(j[6] & 1))) ? 1 : 0;
         J.R = std::min(J.m, J.n);
         J.L = std::max(J.m, J.n);
         J.Rpad = (J.R + 1) / 2 * 2;
@@ -1802,7 +1804,7 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
         q.c_elems += J.N;
         q.n_max = std::max(q.n_max, J.N);
         q.qjobs.push_back(J);
-        const int64_t nj[8] = {J.r_off, J.N, J.N, J.r_off, J.c_off, J.r_off, 0, 0};
+        const int64_t nj[8] = {J.r_off, J.N, J.N, J.r_off, J.c_off, J.r_off, 1, 0};
         q.nested_max.insert(q.nested_max.end(), nj, nj + 8);
     }
     int64_t o = 0;
@@ -1881,7 +1883,7 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
         }
         rmax = std::max(rmax, r);
         if (r == 0) continue;
-        const int64_t nj[8] = {J.r_off, r, J.N, J.r_off, J.c_off, J.r_off, 0, 0};
+        const int64_t nj[8] = {J.r_off, r, J.N, J.r_off, J.c_off, J.r_off, 1, 0};   // flag 1: orthogonalise the ROWS of R
         nested.insert(nested.end(), nj, nj + 8);
         ++nn;
     }
