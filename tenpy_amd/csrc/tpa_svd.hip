@@ -1524,21 +1524,116 @@ __global__ __launch_bounds__(NT) void qrp_form_t_kernel(const QrpJob *__restrict
     }
 }
 
-// T[k:, :] -= tau_k v_k (v_k^T T[k:, :])   (apply H_k from the left; called for k = rmax-1 .. 0)
-__global__ __launch_bounds__(NTR) void qrp_apply_q_kernel(const QrpJob *__restrict__ jobs, const QrpState *__restrict__ state,
-                                                          int k, double *__restrict__ T, const double *__restrict__ Vall,
-                                                          const double *__restrict__ tau) {
-    __shared__ double red[NTR / 64][RCOLS];
+// ---- blocked application of Q_r = H_0 ... H_{r-1} (compact WY, 16 reflectors per launch) ------------------------
+// H_{k0} ... H_{k0+15} = I - V Tf V^T  with Tf upper triangular (LAPACK dlarft, forward / columnwise).
+constexpr int QNB = 16;
+
+// one workgroup per (block of 16 reflectors, job): Gram of the panel rows, then the Tf recurrence.  One launch
+// covers every block of every job.
+__global__ __launch_bounds__(NTR) void qrp_tfactor_kernel(const QrpJob *__restrict__ jobs, const QrpState *__restrict__ state,
+                                                          const double *__restrict__ Vall, const double *__restrict__ tau,
+                                                          double *__restrict__ Tfac) {
+    __shared__ double S[QNB][QNB + 1];
+    __shared__ double Tf[QNB][QNB + 1];
+    const QrpJob J = jobs[blockIdx.y];
+    const int64_t r = state[blockIdx.y].rank, M = J.M;
+    const int64_t k0 = (int64_t)blockIdx.x * QNB;
+    if (k0 >= r) return;
+    const int nb = (int)((r - k0 < QNB) ? (r - k0) : QNB);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *V = Vall + J.x_off + k0 * M;
+    // 16 waves x 16 (l, l') pairs each: pair index = wave * 16 + q  ->  l = wave, l' = q
+    for (int q = 0; q < QNB; ++q) {
+        const int l = wave, lp = q;
+        double acc = 0;
+        if (l < lp && lp < nb)
+            for (int64_t i = k0 + lp + lane; i < M; i += 64) acc = fma(V[l * M + i], V[lp * M + i], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) S[l][lp] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < QNB * QNB) Tf[threadIdx.x >> 4][threadIdx.x & 15] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        const double tj = tau[J.c_off + k0 + j];
+        if (threadIdx.x < j) {
+            const int i = threadIdx.x;
+            double acc = 0;
+            for (int m = i; m < j; ++m) acc = fma(Tf[i][m], S[m][j], acc);
+            Tf[i][j] = -tj * acc;
+        } else if (threadIdx.x == j)
+            Tf[j][j] = tj;
+        __syncthreads();
+    }
+    if (threadIdx.x < QNB * QNB)
+        Tfac[(J.pad0 + blockIdx.x) * (QNB * QNB) + threadIdx.x] = Tf[threadIdx.x >> 4][threadIdx.x & 15];
+}
+
+// C[k0:, tile] <- (I - V Tf V^T) C[k0:, tile]   for one block of 16 reflectors and a 16-column tile of C (M x r)
+__global__ __launch_bounds__(NTR) void qrp_apply_q_block_kernel(const QrpJob *__restrict__ jobs,
+                                                                const QrpState *__restrict__ state, int blk,
+                                                                double *__restrict__ C, const double *__restrict__ Vall,
+                                                                const double *__restrict__ Tfac) {
+    __shared__ double red[NTR / 64][QNB][RCOLS];   // 32 KB
+    __shared__ double Ysh[QNB][RCOLS], Zsh[QNB][RCOLS], Tsh[QNB][QNB];
     const int b = blockIdx.y;
     const QrpJob J = jobs[b];
-    const int64_t r = state[b].rank;
-    if (k >= r) return;
+    const int64_t r = state[b].rank, M = J.M;
+    const int64_t k0 = (int64_t)blk * QNB;
+    if (k0 >= r) return;
     const int64_t j0 = (int64_t)blockIdx.x * RCOLS;
     if (j0 >= r) return;
-    const double tk = tau[J.c_off + k];
-    if (tk == 0.0) return;
-    const int64_t j = j0 + (threadIdx.x & (RCOLS - 1));
-    reflect_tile<false>(T + J.x_off, r, k, J.M, j, j < r, Vall + J.x_off + (int64_t)k * J.M, tk, red);
+    const int nb = (int)((r - k0 < QNB) ? (r - k0) : QNB);
+    const int col = threadIdx.x & (RCOLS - 1), rg = threadIdx.x >> 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t j = j0 + col;
+    const bool ok = j < r;
+    double *Cb = C + J.x_off;
+    const double *V = Vall + J.x_off + k0 * M;
+    if (threadIdx.x < QNB * QNB) Tsh[threadIdx.x >> 4][threadIdx.x & 15] = Tfac[(J.pad0 + blk) * (QNB * QNB) + threadIdx.x];
+    double y[QNB];
+#pragma unroll
+    for (int l = 0; l < QNB; ++l) y[l] = 0.0;
+    if (ok)
+        for (int64_t i = k0 + rg; i < M; i += RGROUPS) {
+            const double c = Cb[i * r + j];
+#pragma unroll
+            for (int l = 0; l < QNB; ++l)
+                if (l < nb) y[l] = fma(V[l * M + i], c, y[l]);
+        }
+#pragma unroll
+    for (int l = 0; l < QNB; ++l) {
+        y[l] += __shfl_xor(y[l], 16, 64);
+        y[l] += __shfl_xor(y[l], 32, 64);
+        if (lane < RCOLS) red[wave][l][col] = y[l];
+    }
+    __syncthreads();
+    if (threadIdx.x < QNB * RCOLS) {
+        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
+        double t = 0;
+#pragma unroll
+        for (int q = 0; q < NTR / 64; ++q) t += red[q][l][c];
+        Ysh[l][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < QNB * RCOLS) {
+        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
+        double t = 0;
+#pragma unroll
+        for (int m = 0; m < QNB; ++m) t = fma(Tsh[l][m], Ysh[m][c], t);   // Tf upper triangular: zeros below
+        Zsh[l][c] = t;
+    }
+    __syncthreads();
+    double z[QNB];
+#pragma unroll
+    for (int l = 0; l < QNB; ++l) z[l] = Zsh[l][col];
+    if (ok)
+        for (int64_t i = k0 + rg; i < M; i += RGROUPS) {
+            double c = Cb[i * r + j];
+#pragma unroll
+            for (int l = 0; l < QNB; ++l)
+                if (l < nb) c = fma(-V[l * M + i], z[l], c);
+            Cb[i * r + j] = c;
+        }
 }
 
 // final outputs from T = Q_r U_R (M x r), S_R, VH_R (r x N) and the column permutation
@@ -1781,7 +1876,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
 struct QrpLayout {
     std::vector<QrpJob> qjobs;
     std::vector<int64_t> nested_max;   // int64[8] jobs of the largest possible nested problem (r = N)
-    int64_t x_elems = 0, r_elems = 0, c_elems = 0, n_max = 0;
+    int64_t x_elems = 0, r_elems = 0, c_elems = 0, n_max = 0, tf_blocks = 0, off_tfac = 0;
     int64_t off_x = 0, off_vall = 0, off_rtop = 0, off_ur = 0, off_vhr = 0, off_cn = 0, off_tau = 0, off_sr = 0,
             off_cperm = 0, off_qjobs = 0, off_sjobs = 0, off_state = 0, off_fro = 0, off_fpart = 0, off_nested = 0,
             total = 0;
@@ -1798,7 +1893,9 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
         J.x_off = q.x_elems;
         J.r_off = q.r_elems;
         J.c_off = q.c_elems;
-        J.pad0 = J.pad1 = 0;
+        J.pad0 = q.tf_blocks;   // first Tf block of this job
+        J.pad1 = 0;
+        q.tf_blocks += (J.N + QNB - 1) / QNB;
         q.x_elems += J.M * J.N;
         q.r_elems += J.N * J.N;
         q.c_elems += J.N;
@@ -1827,6 +1924,7 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
     q.off_state = take((int64_t)n_jobs * sizeof(QrpState));
     q.off_fro = take((int64_t)n_jobs * 8);
     q.off_fpart = take((int64_t)n_jobs * 64 * 8);
+    q.off_tfac = take(q.tf_blocks * QNB * QNB * 8);
     q.off_nested = o;
     o += make_layout(TPA_F64, q.nested_max.data(), n_jobs).total;
     q.total = o;
@@ -1898,8 +1996,11 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
         rc = svd_run<false>(nlay, nn, Rtop, UR, SR, VHR, work + q.off_nested, max_sweeps, sweeps_done, st, rho);
         if (rc != 0 && rc != TPA_E_NOCONV) return rc;
         qrp_form_t_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, UR, X);
-        for (int k = rmax - 1; k >= 0; --k)
-            qrp_apply_q_kernel<<<dim3((rmax + RCOLS - 1) / RCOLS, n_jobs), NTR, 0, st>>>(qjobs, state, k, X, Vall, tau);
+        double *Tfac = (double *)(work + q.off_tfac);
+        const int nblk = (rmax + QNB - 1) / QNB;
+        qrp_tfactor_kernel<<<dim3(nblk, n_jobs), NTR, 0, st>>>(qjobs, state, Vall, tau, Tfac);
+        for (int blk = nblk - 1; blk >= 0; --blk)
+            qrp_apply_q_block_kernel<<<dim3((rmax + RCOLS - 1) / RCOLS, n_jobs), NTR, 0, st>>>(qjobs, state, blk, X, Vall, Tfac);
     }
     qrp_output_kernel<<<dim3(128, n_jobs), NT, 0, st>>>(qjobs, sjobs, state, X, SR, VHR, cperm, (double *)u_base, s_dev,
                                                         (double *)vh_base);
