@@ -122,7 +122,8 @@ def main():
     _, p = spin_half_leg('Sz')
     psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
     eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': min(64, chi), 'svd_min': 1.e-14},
-                                     'lanczos_params': {'N_min': 2, 'N_max': 20}, 'shard_matvec': world > 1})
+                                     'lanczos_params': {'N_min': 2, 'N_max': 20}, 'shard_matvec': world > 1,
+                                     'profile': bool(os.environ.get('TPA_BENCH_PHASES'))})
     # ---- untimed: grow the state (two quick sweeps at small chi, then double chi per sweep)
     t_prep = time.time()
     c = min(64, chi)
@@ -140,6 +141,7 @@ def main():
     torch.cuda.synchronize()
     t_prep = time.time() - t_prep
 
+    eng.phase_time = {k: 0. for k in eng.phase_time}
     # ---- timed region: exactly K sweeps
     npc.gemm_timer.reset()
     npc.gemm_timer.enabled = True
@@ -194,6 +196,9 @@ def main():
                                       % (L, chi, chi_reached, args.lanczos_N, 2 * (L - 2)),
                           "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD/env replicated" % world},
                "E": E, "chi_reached": chi_reached, "prep_s": t_prep, "roofline": roof}
+        if os.environ.get('TPA_BENCH_PHASES'):   # diagnostic run only: the phase timers synchronise the device
+            out["phases_s"] = {k: round(v / max(args.steps, 1), 4) for k, v in eng.phase_time.items()}
+            out["svd_stats"] = dict(npc.svd_stats)
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(eng, args, gpu_bond_s)

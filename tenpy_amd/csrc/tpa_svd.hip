@@ -1272,234 +1272,458 @@ __global__ __launch_bounds__(NT) void svd_finish_kernel(const SvdJob *__restrict
 // R (r = numerical rank): ~7 sweeps over ~half the rows (numpy experiment on real theta blocks: 25 -> 7 sweeps).
 //     X = (Q_r U_R) Sigma (VH_R P^T),   SVD(R) = U_R Sigma VH_R  by the block-Jacobi kernels above.
 // Per step k two launches for all blocks together: `qrp_pivot_kernel` (one workgroup per block: pivot search on
-// the exact residual column norms, column swap, Householder vector) and `qrp_update_kernel` (column tiles: rank-1
+// the exact residual column norms, column swap, Householder vector; X is kept column-major so that this is coalesced) and `qrp_update_kernel` (column tiles: rank-1
 // update of the trailing matrix and exact recomputation of the residual norms in the same pass).
 struct QrpJob {  // int64[8]
     int64_t x_off, M, N, c_off, tr, r_off, pad0, pad1;   // c_off: offset into cn / tau / cperm ; tr: X = A^T
 };
 struct QrpState {  // per job
-    int rank, done;
+    int rank, done, nbk, last;   // nbk: size of the current panel; last: that panel was the final one
 };
 
 __global__ __launch_bounds__(NT) void qrp_init_kernel(const QrpJob *__restrict__ jobs, const SvdJob *__restrict__ sj,
                                                       const double *__restrict__ A, double *__restrict__ X,
                                                       double *__restrict__ cn, int64_t *__restrict__ cperm,
                                                       QrpState *__restrict__ state) {
-    // grid (col tiles of 64, jobs): X = A or A^T (row-major M x N), exact column norms^2, identity permutation
-    __shared__ double red[NT / 64][64];
+    // grid (column tiles of 64, jobs): X = A or A^T stored COLUMN-major (X[j*M + i]), exact column norms^2,
+    // identity permutation.  Wave w owns the columns j0 + 16 w .. +15 of the tile, lanes run along the rows
+    // (contiguous in X); for X = A the 64 x 64 tile is transposed through LDS so that both sides stay coalesced.
+    __shared__ double tile[64][65];
     const QrpJob J = jobs[blockIdx.y];
     const SvdJob S = sj[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
-    if ((int64_t)blockIdx.x * 64 >= J.N) return;
-    double acc = 0;
-    if (j < J.N) {
-        for (int64_t i = wave; i < J.M; i += NT / 64) {
-            const double v = J.tr ? A[S.a_off + j * S.n + i] : A[S.a_off + i * S.n + j];
-            X[J.x_off + i * J.N + j] = v;
-            acc = fma(v, v, acc);
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    if (j0 >= J.N) return;
+    double acc[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.0;
+    for (int64_t i0 = 0; i0 < J.M; i0 += 64) {
+        if (!J.tr) {
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int64_t i = i0 + wave * 16 + rr, j = j0 + lane;
+                tile[wave * 16 + rr][lane] = (i < J.M && j < J.N) ? A[S.a_off + i * S.n + j] : 0.0;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int64_t j = j0 + wave * 16 + rr, i = i0 + lane;
+            if (j < J.N && i < J.M) {
+                const double v = J.tr ? A[S.a_off + j * S.n + i] : tile[lane][wave * 16 + rr];
+                X[J.x_off + j * J.M + i] = v;
+                acc[rr] = fma(v, v, acc[rr]);
+            }
         }
     }
-    red[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && j < J.N) {
-        cn[J.c_off + j] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        cperm[J.c_off + j] = j;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const double t = wave_sum(acc[rr]);
+        const int64_t j = j0 + wave * 16 + rr;
+        if (lane == 0 && j < J.N) {
+            cn[J.c_off + j] = t;
+            cperm[J.c_off + j] = j;
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) state[blockIdx.y] = QrpState{0, 0};
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[blockIdx.y] = QrpState{0, 0, 0, 0};
 }
 
-constexpr int NTP = 1024;
-__global__ __launch_bounds__(NTP) void qrp_pivot_kernel(const QrpJob *__restrict__ jobs, int k, double *__restrict__ X,
+constexpr int NTP = 256;
+constexpr int PNB = 4;    // pivot columns factorised per launch (panel pivoting: the PNB largest residual columns)
+constexpr int RPT_MAX = 32;  // rows / candidate columns per thread held in registers (template RPT = 8, 16, 32)  ->  max(m, n) <= 8192
+
+// sum K values over the workgroup (NTP threads); results valid in every thread
+template <int K>
+__device__ __forceinline__ void block_sum_vec(double (&v)[K], double (*red)[PNB + 1]) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) red[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NTP / 64; ++w) t += red[w][q];
+        v[q] = t;
+    }
+}
+
+// One workgroup per block: pick the (up to) PNB remaining columns with the largest residual norms, move them to
+// positions k .. k+nbk-1 and factorise that panel (Householder vectors -> Vall, R entries -> X, compact-WY factor
+// -> Tpan).  Greedy pivoting is exact for the first column of a panel and by pre-panel norms for the others; the
+// rank decision is unaffected because the trailing update recomputes every residual norm exactly.
+template <int RPT>
+__global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict__ jobs, int k, double *__restrict__ X,
                                                        double *__restrict__ Vall, double *__restrict__ cn,
                                                        double *__restrict__ tau, int64_t *__restrict__ cperm,
                                                        QrpState *__restrict__ state, const double *__restrict__ fro2,
-                                                       double tol2) {
+                                                       double tol2, double *__restrict__ Tpan) {
     __shared__ double rv[NTP / 64];
     __shared__ int64_t ri[NTP / 64];
-    __shared__ double red[NTP / 64];
-    __shared__ int64_t s_piv;
-    __shared__ int s_stop;
+    __shared__ double red[NTP / 64][PNB + 1];
+    __shared__ int64_t s_p[PNB], s_from[PNB], s_to[PNB];
+    __shared__ int s_nbk, s_nmove;
+    __shared__ double s_alpha, s_vrow[PNB], Tf[PNB][PNB];
     const int b = blockIdx.x;
     const QrpJob J = jobs[b];
-    if (state[b].done) return;
+    const QrpState st0 = state[b];
+    if (st0.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t M = J.M, N = J.N;
-    if (k >= N) {
-        if (tid == 0) state[b] = QrpState{(int)N, 1};
+    if (st0.last || k >= N) {
+        if (tid == 0) state[b] = QrpState{st0.last ? st0.rank : (int)N, 1, 0, 0};
         return;
     }
-    // ---- pivot: largest residual column norm (ties -> smallest index: deterministic)
-    double bv = -1.0;
-    int64_t bidx = N;
-    for (int64_t j = k + tid; j < N; j += NTP) {
-        const double v = cn[J.c_off + j];
-        if (v > bv) {
-            bv = v;
-            bidx = j;
-        }
-    }
+    // ---- the PNB largest residual norms among the columns k .. N-1 (ties -> smallest index: deterministic)
+    double cand[RPT];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(bv, off, 64);
-        const int64_t oi = __shfl_xor(bidx, off, 64);
-        if (ov > bv || (ov == bv && oi < bidx)) {
-            bv = ov;
-            bidx = oi;
-        }
+    for (int t = 0; t < RPT; ++t) {
+        const int64_t j = k + tid + (int64_t)t * NTP;
+        cand[t] = (j < N) ? cn[J.c_off + j] : -4.0;
     }
-    if (lane == 0) {
-        rv[wave] = bv;
-        ri[wave] = bidx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < NTP / 64; ++w)
-            if (rv[w] > rv[0] || (rv[w] == rv[0] && ri[w] < ri[0])) {
-                rv[0] = rv[w];
-                ri[0] = ri[w];
+    const double thresh = tol2 * fro2[b];
+    if (tid == 0) s_nbk = 0;
+    for (int l = 0; l < PNB; ++l) {
+        double bv = -3.0;
+        int64_t bidx = N;
+#pragma unroll
+        for (int t = 0; t < RPT; ++t)
+            if (cand[t] > bv) {
+                bv = cand[t];
+                bidx = k + tid + (int64_t)t * NTP;
             }
-        s_piv = ri[0];
-        s_stop = !(rv[0] > tol2 * fro2[b]);
-        if (s_stop) state[b] = QrpState{k, 1};
-    }
-    __syncthreads();
-    if (s_stop) return;
-    const int64_t piv = s_piv;
-    double *Xb = X + J.x_off;
-    if (piv != k) {
-        for (int64_t i = tid; i < M; i += NTP) {
-            const double t = Xb[i * N + k];
-            Xb[i * N + k] = Xb[i * N + piv];
-            Xb[i * N + piv] = t;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int64_t oi = __shfl_xor(bidx, off, 64);
+            if (ov > bv || (ov == bv && oi < bidx)) {
+                bv = ov;
+                bidx = oi;
+            }
         }
+        __syncthreads();
+        if (lane == 0) {
+            rv[wave] = bv;
+            ri[wave] = bidx;
+        }
+        __syncthreads();
         if (tid == 0) {
-            const double t = cn[J.c_off + k];
-            cn[J.c_off + k] = cn[J.c_off + piv];
-            cn[J.c_off + piv] = t;
-            const int64_t q = cperm[J.c_off + k];
-            cperm[J.c_off + k] = cperm[J.c_off + piv];
-            cperm[J.c_off + piv] = q;
+            double v0 = rv[0];
+            int64_t i0 = ri[0];
+            for (int w = 1; w < NTP / 64; ++w)
+                if (rv[w] > v0 || (rv[w] == v0 && ri[w] < i0)) {
+                    v0 = rv[w];
+                    i0 = ri[w];
+                }
+            if (v0 > thresh && s_nbk == l) {
+                s_p[l] = i0;
+                s_nbk = l + 1;
+            }
         }
+        __syncthreads();
+        if (s_nbk <= l) break;   // uniform
+        const int64_t w = s_p[l];
+#pragma unroll
+        for (int t = 0; t < RPT; ++t)
+            if (k + tid + (int64_t)t * NTP == w) cand[t] = -4.0;
     }
-    __syncthreads();
-    // ---- Householder vector of column k, rows k..M-1
-    double s2 = 0;
-    for (int64_t i = k + 1 + tid; i < M; i += NTP) {
-        const double v = Xb[i * N + k];
-        s2 = fma(v, v, s2);
+    const int nbk = s_nbk;
+    if (nbk == 0) {
+        if (tid == 0) state[b] = QrpState{k, 1, 0, 0};
+        return;
     }
-    s2 = block_sum<NTP>(s2, red);
-    const double alpha = Xb[(int64_t)k * N + k];
-    double beta = alpha, tk = 0.0, scale = 0.0;
-    if (s2 > 0.0) {
-        beta = -copysign(sqrt(alpha * alpha + s2), alpha);
-        tk = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-    }
-    __syncthreads();
-    double *vk = Vall + J.x_off + (int64_t)k * M;
-    for (int64_t i = tid; i < M; i += NTP) {
-        double v = 0.0;
-        if (i == k)
-            v = 1.0;
-        else if (i > k) {
-            v = Xb[i * N + k] * scale;
-            Xb[i * N + k] = 0.0;
-        }
-        vk[i] = v;
-    }
+    // ---- bookkeeping (thread 0): which displaced columns go to which vacated positions; cn / cperm follow
     if (tid == 0) {
-        Xb[(int64_t)k * N + k] = beta;
-        tau[J.c_off + k] = tk;
-        cn[J.c_off + k] = -1.0;  // processed
+        int nm = 0, nv = 0;
+        int64_t vac[PNB];
+        for (int l = 0; l < nbk; ++l)
+            if (s_p[l] >= k + nbk) vac[nv++] = s_p[l];
+        for (int64_t d = k; d < k + nbk; ++d) {
+            bool chosen = false;
+            for (int l = 0; l < nbk; ++l) chosen = chosen || (s_p[l] == d);
+            if (!chosen) {
+                s_from[nm] = d;
+                s_to[nm] = vac[nm];
+                ++nm;
+            }
+        }
+        s_nmove = nm;
+        int64_t cp_p[PNB], cp_d[PNB];
+        double cn_d[PNB];
+        for (int l = 0; l < nbk; ++l) cp_p[l] = cperm[J.c_off + s_p[l]];
+        for (int a = 0; a < nm; ++a) {
+            cp_d[a] = cperm[J.c_off + s_from[a]];
+            cn_d[a] = cn[J.c_off + s_from[a]];
+        }
+        for (int a = 0; a < nm; ++a) {
+            cperm[J.c_off + s_to[a]] = cp_d[a];
+            cn[J.c_off + s_to[a]] = cn_d[a];
+        }
+        for (int l = 0; l < nbk; ++l) {
+            cperm[J.c_off + k + l] = cp_p[l];
+            cn[J.c_off + k + l] = -1.0;   // processed
+        }
+        const bool last = (nbk < PNB);
+        state[b] = QrpState{last ? k + nbk : 0, 0, nbk, last ? 1 : 0};
+        for (int x = 0; x < PNB; ++x)
+            for (int y = 0; y < PNB; ++y) Tf[x][y] = 0.0;
     }
+    __syncthreads();
+    const int nmove = s_nmove;
+    double *Xb = X + J.x_off;
+    // ---- gather the panel into registers (row-local), move the displaced columns
+    double c[PNB][RPT];
+    {
+        double mv[PNB][RPT];   // all loads first, then the stores (possible aliasing would serialise them otherwise)
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) {
+            const int64_t i = tid + (int64_t)t * NTP;
+#pragma unroll
+            for (int l = 0; l < PNB; ++l) {
+                c[l][t] = (i < M && l < nbk) ? Xb[s_p[l] * M + i] : 0.0;
+                mv[l][t] = (i < M && l < nmove) ? Xb[s_from[l] * M + i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) {
+            const int64_t i = tid + (int64_t)t * NTP;
+#pragma unroll
+            for (int l = 0; l < PNB; ++l)
+                if (i < M && l < nmove) Xb[s_to[l] * M + i] = mv[l][t];
+        }
+    }
+    // ---- factorise the panel, column by column
+#pragma unroll
+    for (int l = 0; l < PNB; ++l) {
+        if (l < nbk) {   // uniform
+            const int64_t kl = (int64_t)k + l;
+            if (l > 0) {
+                // c_l <- (I - V Tf^T V^T) c_l  with the l reflectors found so far (their vectors sit in c[0..l-1])
+                double y[PNB];
+#pragma unroll
+                for (int m = 0; m < PNB; ++m) {
+                    y[m] = 0.0;
+                    if (m < l) {
+#pragma unroll
+                        for (int t = 0; t < RPT; ++t) y[m] = fma(c[m][t], c[l][t], y[m]);
+                    }
+                }
+                block_sum_vec<PNB>(y, red);
+                double z[PNB];
+#pragma unroll
+                for (int m = 0; m < PNB; ++m) {
+                    z[m] = 0.0;
+                    if (m < l) {
+#pragma unroll
+                        for (int mm = 0; mm < PNB; ++mm)
+                            if (mm <= m) z[m] = fma(Tf[mm][m], y[mm], z[m]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < PNB; ++m)
+                    if (m < l) {
+#pragma unroll
+                        for (int t = 0; t < RPT; ++t) c[l][t] = fma(-c[m][t], z[m], c[l][t]);
+                    }
+            }
+            // norms below the diagonal, inner products with the earlier vectors (for Tf), alpha
+            double g[PNB + 1];
+#pragma unroll
+            for (int q = 0; q <= PNB; ++q) g[q] = 0.0;
+#pragma unroll
+            for (int t = 0; t < RPT; ++t) {
+                const int64_t i = tid + (int64_t)t * NTP;
+                if (i > kl && i < M) {
+                    g[PNB] = fma(c[l][t], c[l][t], g[PNB]);
+#pragma unroll
+                    for (int m = 0; m < PNB; ++m)
+                        if (m < l) g[m] = fma(c[m][t], c[l][t], g[m]);
+                } else if (i == kl) {
+                    s_alpha = c[l][t];
+#pragma unroll
+                    for (int m = 0; m < PNB; ++m)
+                        if (m < l) s_vrow[m] = c[m][t];
+                }
+            }
+            block_sum_vec<PNB + 1>(g, red);
+            const double s2 = g[PNB], alpha = s_alpha;
+            double beta = alpha, tk = 0.0, scale = 0.0;
+            if (s2 > 0.0) {
+                beta = -copysign(sqrt(alpha * alpha + s2), alpha);
+                tk = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            if (tid == 0) {
+                tau[J.c_off + kl] = tk;
+                Tf[l][l] = tk;
+                for (int i2 = 0; i2 < l; ++i2) {
+                    double acc = 0;
+                    for (int m = i2; m < l; ++m) acc = fma(Tf[i2][m], g[m] * scale + s_vrow[m], acc);
+                    Tf[i2][l] = -tk * acc;
+                }
+            }
+            double *vk = Vall + J.x_off + kl * M;
+#pragma unroll
+            for (int t = 0; t < RPT; ++t) {
+                const int64_t i = tid + (int64_t)t * NTP;
+                if (i < M) {
+                    double v;
+                    if (i < kl) {
+                        Xb[kl * M + i] = c[l][t];   // R entry above the diagonal
+                        v = 0.0;
+                    } else if (i == kl) {
+                        Xb[kl * M + i] = beta;
+                        v = 1.0;
+                    } else {
+                        Xb[kl * M + i] = 0.0;
+                        v = c[l][t] * scale;
+                    }
+                    vk[i] = v;
+                    c[l][t] = v;
+                }
+            }
+            __syncthreads();   // Tf column l, s_alpha / s_vrow reuse
+        }
+    }
+    if (tid < PNB * PNB) Tpan[(int64_t)b * PNB * PNB + tid] = Tf[tid / PNB][tid % PNB];
 }
 
-// Householder reflector applied to a 16-column tile of a row-major matrix:  Y[k:, j] -= tau v (v^T Y[k:, j]).
-// 1024 threads = 64 row groups x 16 columns: the row loop per thread is only (M-k)/64 long, which matters because
-// each step of the factorisation is latency bound (one dependent global round trip per loop iteration), not
-// bandwidth bound (the trailing matrix lives in L2 / Infinity Cache).  Returns sum_{i>k} Y[i,j]^2 (all threads of
-// a column hold it) when NORMS.
-constexpr int NTR = 1024, RCOLS = 16, RGROUPS = NTR / RCOLS;
+// ---- compact-WY block reflector applied to a 16-column tile of a row-major matrix, on the matrix cores ----------
+//     C[k0:, tile] <- (I - V Tf' V^T) C[k0:, tile],    Tf' = Tf^T (TRANS: trailing update of the factorisation)
+//                                                      or Tf (forming Q U_R),
+// V[l*M + i] = component i of reflector l (0 above its diagonal), nb <= NB reflectors, Tf upper triangular in LDS.
+// 1024 threads = 16 wavefronts, each owning 16-row slabs (slab s of wave w = rows k0 + 16 (w + 16 s) ...):
+//   pass 1  Y  = V^T C      v_mfma_f64_16x16x4: A(l, i) = V, B(i, j) = C, K runs over the rows      -> LDS reduce
+//   small   Z  = Tf' Y      (NB x 16, 256 threads)
+//   pass 2  C -= V Z        A(i, l) = V, B(l, j) = -Z, accumulator preloaded with the C slab (NB/4 MFMAs per slab)
+// Returns (NORMS) sum_{i >= kend} C[i, j]^2 of the updated tile column j = j0 + (lane & 15), valid in threads < 16.
+constexpr int NTR = 1024, RCOLS = 16;
 
-template <bool NORMS>
-__device__ __forceinline__ double reflect_tile(double *__restrict__ Y, int64_t ld, int64_t k, int64_t M, int64_t j, bool ok,
-                                               const double *__restrict__ vk, double tk, double (*red)[RCOLS]) {
-    const int col = threadIdx.x & (RCOLS - 1), rg = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-    double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-    if (ok && tk != 0.0) {
-        int64_t i = k + rg;
-        for (; i + 3 * RGROUPS < M; i += 4 * RGROUPS) {
-            const double x0 = Y[i * ld + j], x1 = Y[(i + RGROUPS) * ld + j], x2 = Y[(i + 2 * RGROUPS) * ld + j],
-                         x3 = Y[(i + 3 * RGROUPS) * ld + j];
-            d0 = fma(vk[i], x0, d0);
-            d1 = fma(vk[i + RGROUPS], x1, d1);
-            d2 = fma(vk[i + 2 * RGROUPS], x2, d2);
-            d3 = fma(vk[i + 3 * RGROUPS], x3, d3);
-        }
-        for (; i < M; i += RGROUPS) d0 = fma(vk[i], Y[i * ld + j], d0);
-    }
-    double dot = (d0 + d1) + (d2 + d3);
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
-    if ((threadIdx.x & 63) < RCOLS) red[wave][col] = dot;
-    __syncthreads();
-    double w = 0;
+template <int NB>
+struct WySmem {
+    double red[NTR / 64][NB][RCOLS];
+    double Y[NB][RCOLS], Z[NB][RCOLS], T[NB][NB];
+    double nrm[NTR / 64][RCOLS];
+};
+
+template <int NB, bool TRANS, bool NORMS>
+__device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t cs, int64_t k0, int64_t M, int64_t j0, int64_t jend,
+                                                const double *__restrict__ V, int nb, int64_t kend, WySmem<NB> &sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 15, kq = lane >> 4;
+    const int64_t j = j0 + lo;
+    const bool jok = j < jend;
+    // ---- pass 1: Y(l, j) = sum_i V(l, i) C(i, j)
+    d4 acc = {0, 0, 0, 0};
+    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 16 * (NTR / 64)) {
+        double a[4], bb[4];
 #pragma unroll
-    for (int q = 0; q < NTR / 64; ++q) w += red[q][col];
-    w *= tk;
-    double n0 = 0, n1 = 0;
-    if (ok && (tk != 0.0 || NORMS)) {
-        int64_t i = k + rg;
-        for (; i + RGROUPS < M; i += 2 * RGROUPS) {
-            double x0 = Y[i * ld + j], x1 = Y[(i + RGROUPS) * ld + j];
-            x0 = fma(-vk[i], w, x0);
-            x1 = fma(-vk[i + RGROUPS], w, x1);
-            if (tk != 0.0) {
-                Y[i * ld + j] = x0;
-                Y[(i + RGROUPS) * ld + j] = x1;
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + 4 * kq + q;
+            const bool iok = i < M;
+            a[q] = (iok && lo < nb) ? V[(int64_t)lo * M + i] : 0.0;
+            bb[q] = (iok && jok) ? Cb[i * rs + j * cs] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bb[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+        if (kq + 4 * reg < NB) sm.red[wave][kq + 4 * reg][lo] = acc[reg];
+    __syncthreads();
+    if (threadIdx.x < NB * RCOLS) {
+        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
+        double t = 0;
+#pragma unroll
+        for (int q = 0; q < NTR / 64; ++q) t += sm.red[q][l][c];
+        sm.Y[l][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NB * RCOLS) {
+        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
+        double t = 0;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) t = fma(TRANS ? sm.T[m][l] : sm.T[l][m], sm.Y[m][c], t);
+        sm.Z[l][c] = -t;
+    }
+    __syncthreads();
+    double zneg[NB / 4];
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) zneg[q] = sm.Z[4 * q + kq][lo];
+    // ---- pass 2: two 16-row slabs per iteration (all loads before the stores: the compiler cannot prove that the
+    //      stores of one slab do not alias the loads of the next)
+    double nrm = 0;
+    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 2 * 16 * (NTR / 64)) {
+        d4 c[2];
+        double av[2][NB / 4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t ib = i0 + (int64_t)h * 16 * (NTR / 64);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t i = ib + kq + 4 * reg;
+                c[h][reg] = (i < M && jok) ? Cb[i * rs + j * cs] : 0.0;
             }
-            if (NORMS) {
-                if (i > k) n0 = fma(x0, x0, n0);
-                n1 = fma(x1, x1, n1);
+#pragma unroll
+            for (int q = 0; q < NB / 4; ++q) {
+                const int64_t i = ib + lo;
+                const int l = 4 * q + kq;
+                av[h][q] = (i < M && l < nb) ? V[(int64_t)l * M + i] : 0.0;
             }
         }
-        for (; i < M; i += RGROUPS) {
-            const double x0 = fma(-vk[i], w, Y[i * ld + j]);
-            if (tk != 0.0) Y[i * ld + j] = x0;
-            if (NORMS && i > k) n0 = fma(x0, x0, n0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < NB / 4; ++q) c[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][q], zneg[q], c[h], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t ib = i0 + (int64_t)h * 16 * (NTR / 64);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t i = ib + kq + 4 * reg;
+                if (i < M && jok) {
+                    Cb[i * rs + j * cs] = c[h][reg];
+                    if (NORMS && i >= kend) nrm = fma(c[h][reg], c[h][reg], nrm);
+                }
+            }
         }
     }
     if (!NORMS) return 0.0;
-    double nrm = n0 + n1;
     nrm += __shfl_xor(nrm, 16, 64);
     nrm += __shfl_xor(nrm, 32, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) < RCOLS) red[wave][col] = nrm;
+    if (lane < RCOLS) sm.nrm[wave][lo] = nrm;
     __syncthreads();
     double t = 0;
+    if (threadIdx.x < RCOLS) {
 #pragma unroll
-    for (int q = 0; q < NTR / 64; ++q) t += red[q][col];
+        for (int q = 0; q < NTR / 64; ++q) t += sm.nrm[q][threadIdx.x];
+    }
     return t;
 }
 
-// trailing update  X[k:, j] -= tau v (v^T X[k:, j])  for j > k, plus exact residual norms of rows > k
+// trailing update with the panel's nbk reflectors:  X[k:, j] <- (I - V Tf^T V^T) X[k:, j]  for j >= k + nbk,
+// plus the exact residual norms (rows >= k + nbk) of the updated columns.
 __global__ __launch_bounds__(NTR) void qrp_update_kernel(const QrpJob *__restrict__ jobs, int k, double *__restrict__ X,
                                                          const double *__restrict__ Vall, double *__restrict__ cn,
-                                                         const double *__restrict__ tau,
-                                                         const QrpState *__restrict__ state) {
-    __shared__ double red[NTR / 64][RCOLS];
+                                                         const QrpState *__restrict__ state,
+                                                         const double *__restrict__ Tpan) {
+    __shared__ WySmem<PNB> sm;
     const int b = blockIdx.y;
-    if (state[b].done) return;
+    const QrpState st = state[b];
+    if (st.done || st.nbk == 0) return;
     const QrpJob J = jobs[b];
-    const int64_t j0 = (int64_t)k + 1 + (int64_t)blockIdx.x * RCOLS;
+    const int nbk = st.nbk;
+    const int64_t j0 = (int64_t)k + nbk + (int64_t)blockIdx.x * RCOLS;
     if (j0 >= J.N) return;
-    const int64_t j = j0 + (threadIdx.x & (RCOLS - 1));
-    const bool ok = j < J.N;
-    const double nrm = reflect_tile<true>(X + J.x_off, J.N, k, J.M, j, ok, Vall + J.x_off + (int64_t)k * J.M,
-                                          tau[J.c_off + k], red);
-    if (threadIdx.x < RCOLS && ok) cn[J.c_off + j] = nrm;
+    if (threadIdx.x < PNB * PNB) sm.T[threadIdx.x / PNB][threadIdx.x % PNB] = Tpan[(int64_t)b * PNB * PNB + threadIdx.x];
+    const double nrm = wy_apply_tile<PNB, true, true>(X + J.x_off, 1, J.M, k, J.M, j0, J.N, Vall + J.x_off + (int64_t)k * J.M,
+                                                      nbk, (int64_t)k + nbk, sm);
+    if (threadIdx.x < RCOLS && j0 + threadIdx.x < J.N) cn[J.c_off + j0 + threadIdx.x] = nrm;
 }
 
 // R_top (r x N, contiguous) = upper-triangular part of the first r rows of X
@@ -1509,7 +1733,7 @@ __global__ __launch_bounds__(NT) void qrp_extract_kernel(const QrpJob *__restric
     const int64_t r = state[blockIdx.y].rank, N = J.N;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < r * N; e += (int64_t)gridDim.x * NT) {
         const int64_t i = e / N, j = e - i * N;
-        Rtop[J.r_off + e] = (j >= i) ? X[J.x_off + e] : 0.0;
+        Rtop[J.r_off + e] = (j >= i) ? X[J.x_off + j * J.M + i] : 0.0;
     }
 }
 
@@ -1574,66 +1798,17 @@ __global__ __launch_bounds__(NTR) void qrp_apply_q_block_kernel(const QrpJob *__
                                                                 const QrpState *__restrict__ state, int blk,
                                                                 double *__restrict__ C, const double *__restrict__ Vall,
                                                                 const double *__restrict__ Tfac) {
-    __shared__ double red[NTR / 64][QNB][RCOLS];   // 32 KB
-    __shared__ double Ysh[QNB][RCOLS], Zsh[QNB][RCOLS], Tsh[QNB][QNB];
+    __shared__ WySmem<QNB> sm;
     const int b = blockIdx.y;
     const QrpJob J = jobs[b];
-    const int64_t r = state[b].rank, M = J.M;
+    const int64_t r = state[b].rank;
     const int64_t k0 = (int64_t)blk * QNB;
     if (k0 >= r) return;
     const int64_t j0 = (int64_t)blockIdx.x * RCOLS;
     if (j0 >= r) return;
     const int nb = (int)((r - k0 < QNB) ? (r - k0) : QNB);
-    const int col = threadIdx.x & (RCOLS - 1), rg = threadIdx.x >> 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t j = j0 + col;
-    const bool ok = j < r;
-    double *Cb = C + J.x_off;
-    const double *V = Vall + J.x_off + k0 * M;
-    if (threadIdx.x < QNB * QNB) Tsh[threadIdx.x >> 4][threadIdx.x & 15] = Tfac[(J.pad0 + blk) * (QNB * QNB) + threadIdx.x];
-    double y[QNB];
-#pragma unroll
-    for (int l = 0; l < QNB; ++l) y[l] = 0.0;
-    if (ok)
-        for (int64_t i = k0 + rg; i < M; i += RGROUPS) {
-            const double c = Cb[i * r + j];
-#pragma unroll
-            for (int l = 0; l < QNB; ++l)
-                if (l < nb) y[l] = fma(V[l * M + i], c, y[l]);
-        }
-#pragma unroll
-    for (int l = 0; l < QNB; ++l) {
-        y[l] += __shfl_xor(y[l], 16, 64);
-        y[l] += __shfl_xor(y[l], 32, 64);
-        if (lane < RCOLS) red[wave][l][col] = y[l];
-    }
-    __syncthreads();
-    if (threadIdx.x < QNB * RCOLS) {
-        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
-        double t = 0;
-#pragma unroll
-        for (int q = 0; q < NTR / 64; ++q) t += red[q][l][c];
-        Ysh[l][c] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < QNB * RCOLS) {
-        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
-        double t = 0;
-#pragma unroll
-        for (int m = 0; m < QNB; ++m) t = fma(Tsh[l][m], Ysh[m][c], t);   // Tf upper triangular: zeros below
-        Zsh[l][c] = t;
-    }
-    __syncthreads();
-    double z[QNB];
-#pragma unroll
-    for (int l = 0; l < QNB; ++l) z[l] = Zsh[l][col];
-    if (ok)
-        for (int64_t i = k0 + rg; i < M; i += RGROUPS) {
-            double c = Cb[i * r + j];
-#pragma unroll
-            for (int l = 0; l < QNB; ++l)
-                if (l < nb) c = fma(-V[l * M + i], z[l], c);
-            Cb[i * r + j] = c;
-        }
+    if (threadIdx.x < QNB * QNB) sm.T[threadIdx.x >> 4][threadIdx.x & 15] = Tfac[(J.pad0 + blk) * (QNB * QNB) + threadIdx.x];
+    wy_apply_tile<QNB, false, false>(C + J.x_off, r, 1, k0, J.M, j0, r, Vall + J.x_off + k0 * J.M, nb, 0, sm);
 }
 
 // final outputs from T = Q_r U_R (M x r), S_R, VH_R (r x N) and the column permutation
@@ -1876,7 +2051,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
 struct QrpLayout {
     std::vector<QrpJob> qjobs;
     std::vector<int64_t> nested_max;   // int64[8] jobs of the largest possible nested problem (r = N)
-    int64_t x_elems = 0, r_elems = 0, c_elems = 0, n_max = 0, tf_blocks = 0, off_tfac = 0;
+    int64_t m_max = 0;
+    int64_t x_elems = 0, r_elems = 0, c_elems = 0, n_max = 0, tf_blocks = 0, off_tfac = 0, off_tpan = 0;
     int64_t off_x = 0, off_vall = 0, off_rtop = 0, off_ur = 0, off_vhr = 0, off_cn = 0, off_tau = 0, off_sr = 0,
             off_cperm = 0, off_qjobs = 0, off_sjobs = 0, off_state = 0, off_fro = 0, off_fpart = 0, off_nested = 0,
             total = 0;
@@ -1900,6 +2076,7 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
         q.r_elems += J.N * J.N;
         q.c_elems += J.N;
         q.n_max = std::max(q.n_max, J.N);
+        q.m_max = std::max(q.m_max, J.M);
         q.qjobs.push_back(J);
         const int64_t nj[8] = {J.r_off, J.N, J.N, J.r_off, J.c_off, J.r_off, 1, 0};
         q.nested_max.insert(q.nested_max.end(), nj, nj + 8);
@@ -1925,6 +2102,7 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
     q.off_fro = take((int64_t)n_jobs * 8);
     q.off_fpart = take((int64_t)n_jobs * 64 * 8);
     q.off_tfac = take(q.tf_blocks * QNB * QNB * 8);
+    q.off_tpan = take((int64_t)n_jobs * PNB * PNB * 8);
     q.off_nested = o;
     o += make_layout(TPA_F64, q.nested_max.data(), n_jobs).total;
     q.total = o;
@@ -1933,7 +2111,7 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
 
 constexpr int64_t QRP_MIN_DIM = 32;        // below this the plain Jacobi path is launch-cheaper
 constexpr double QRP_RANK_TOL = 1.0e-15;   // residual column norm <= tol * ||A||_F  ->  numerical rank reached
-constexpr int QRP_POLL = 32;               // steps between host polls of the "all blocks finished" state
+constexpr int QRP_POLL = 8;                // steps between host polls of the "all blocks finished" state
 
 int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a_base, void *u_base, double *s_dev,
                 void *vh_base, char *work, int max_sweeps, int *sweeps_done, hipStream_t st, double rho) {
@@ -1954,11 +2132,18 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     TPA_LAUNCH_CHECK();
     std::vector<QrpState> hstate(n_jobs);
     const double tol2 = QRP_RANK_TOL * QRP_RANK_TOL;
-    for (int k = 0; k <= nmax; ++k) {
-        qrp_pivot_kernel<<<n_jobs, NTP, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2);
+    double *Tpan = (double *)(work + q.off_tpan);
+    for (int k = 0, step = 0;; k += PNB, ++step) {
+        if (q.m_max <= 8 * NTP)
+            qrp_panel_kernel<8><<<n_jobs, NTP, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+        else if (q.m_max <= 16 * NTP)
+            qrp_panel_kernel<16><<<n_jobs, NTP, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+        else
+            qrp_panel_kernel<32><<<n_jobs, NTP, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+        if (k >= nmax) break;   // that launch only finalised the states
         const int tiles = (nmax - k - 1 + RCOLS - 1) / RCOLS;
-        if (tiles > 0) qrp_update_kernel<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, X, Vall, cn, tau, state);
-        if ((k % QRP_POLL) == QRP_POLL - 1 && k < nmax) {
+        if (tiles > 0) qrp_update_kernel<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, X, Vall, cn, state, Tpan);
+        if ((step % QRP_POLL) == QRP_POLL - 1) {
             TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
             TPA_HIP_CHECK(hipStreamSynchronize(st));
             bool all = true;
@@ -2029,7 +2214,10 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
     Layout lay = make_layout(dtype, jobs_host, n_jobs);
     TPA_ARG_CHECK(work_bytes >= lay.total);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == TPA_F64 && tpa_svd_use_qrp && !tpa_svd_force_pairwise && lay.rmax_pad >= QRP_MIN_DIM) {
+    int64_t dim_max = 0;
+    for (int b = 0; b < n_jobs; ++b) dim_max = std::max(dim_max, std::max(jobs_host[8 * b + 1], jobs_host[8 * b + 2]));
+    if (dtype == TPA_F64 && tpa_svd_use_qrp && !tpa_svd_force_pairwise && lay.rmax_pad >= QRP_MIN_DIM &&
+        dim_max <= (int64_t)NTP * RPT_MAX) {
         QrpLayout q = make_qrp_layout(jobs_host, n_jobs);
         TPA_ARG_CHECK(work_bytes >= q.total);
         return svd_run_qrp(lay, q, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
