@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(NT) void qrp_init_kernel(const QrpJob *__restrict__
 }
 
 constexpr int NTP = 256;
-constexpr int PNB = 4;    // pivot columns factorised per launch (panel pivoting: the PNB largest residual columns)
+constexpr int PNB = 8;    // pivot columns factorised per launch (panel pivoting: the PNB largest residual columns)
 constexpr int RPT_MAX = 32;  // rows / candidate columns per thread held in registers (template RPT = 8, 16, 32)  ->  max(m, n) <= 8192
 
 // sum K values over the workgroup (NTP threads); results valid in every thread
@@ -1366,7 +1366,8 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
     __shared__ double rv[NTP / 64];
     __shared__ int64_t ri[NTP / 64];
     __shared__ double red[NTP / 64][PNB + 1];
-    __shared__ int64_t s_p[PNB], s_from[PNB], s_to[PNB];
+    __shared__ int64_t s_p[PNB], s_from[PNB], s_to[PNB], s_vac[PNB], s_cpp[PNB], s_cpd[PNB];
+    __shared__ double s_cnd[PNB], s_g[PNB + 1];
     __shared__ int s_nbk, s_nmove;
     __shared__ double s_alpha, s_vrow[PNB], Tf[PNB][PNB];
     const int b = blockIdx.x;
@@ -1438,34 +1439,31 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
         return;
     }
     // ---- bookkeeping (thread 0): which displaced columns go to which vacated positions; cn / cperm follow
-    if (tid == 0) {
+    if (tid == 0) {   // (LDS scratch arrays: dynamically indexed locals would live in scratch memory)
         int nm = 0, nv = 0;
-        int64_t vac[PNB];
         for (int l = 0; l < nbk; ++l)
-            if (s_p[l] >= k + nbk) vac[nv++] = s_p[l];
+            if (s_p[l] >= k + nbk) s_vac[nv++] = s_p[l];
         for (int64_t d = k; d < k + nbk; ++d) {
             bool chosen = false;
             for (int l = 0; l < nbk; ++l) chosen = chosen || (s_p[l] == d);
             if (!chosen) {
                 s_from[nm] = d;
-                s_to[nm] = vac[nm];
+                s_to[nm] = s_vac[nm];
                 ++nm;
             }
         }
         s_nmove = nm;
-        int64_t cp_p[PNB], cp_d[PNB];
-        double cn_d[PNB];
-        for (int l = 0; l < nbk; ++l) cp_p[l] = cperm[J.c_off + s_p[l]];
+        for (int l = 0; l < nbk; ++l) s_cpp[l] = cperm[J.c_off + s_p[l]];
         for (int a = 0; a < nm; ++a) {
-            cp_d[a] = cperm[J.c_off + s_from[a]];
-            cn_d[a] = cn[J.c_off + s_from[a]];
+            s_cpd[a] = cperm[J.c_off + s_from[a]];
+            s_cnd[a] = cn[J.c_off + s_from[a]];
         }
         for (int a = 0; a < nm; ++a) {
-            cperm[J.c_off + s_to[a]] = cp_d[a];
-            cn[J.c_off + s_to[a]] = cn_d[a];
+            cperm[J.c_off + s_to[a]] = s_cpd[a];
+            cn[J.c_off + s_to[a]] = s_cnd[a];
         }
         for (int l = 0; l < nbk; ++l) {
-            cperm[J.c_off + k + l] = cp_p[l];
+            cperm[J.c_off + k + l] = s_cpp[l];
             cn[J.c_off + k + l] = -1.0;   // processed
         }
         const bool last = (nbk < PNB);
@@ -1497,8 +1495,8 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                 if (i < M && l < nmove) Xb[s_to[l] * M + i] = mv[l][t];
         }
     }
-    // ---- factorise the panel, column by column
-#pragma unroll
+    // ---- factorise the panel, column by column (must be fully unrolled: c[l] has to stay in registers)
+#pragma clang loop unroll(full)
     for (int l = 0; l < PNB; ++l) {
         if (l < nbk) {   // uniform
             const int64_t kl = (int64_t)k + l;
@@ -1561,9 +1559,11 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
             if (tid == 0) {
                 tau[J.c_off + kl] = tk;
                 Tf[l][l] = tk;
+#pragma unroll
+                for (int m = 0; m < PNB; ++m) s_g[m] = g[m] * scale + s_vrow[m];   // v_m^T v_l
                 for (int i2 = 0; i2 < l; ++i2) {
                     double acc = 0;
-                    for (int m = i2; m < l; ++m) acc = fma(Tf[i2][m], g[m] * scale + s_vrow[m], acc);
+                    for (int m = i2; m < l; ++m) acc = fma(Tf[i2][m], s_g[m], acc);
                     Tf[i2][l] = -tk * acc;
                 }
             }
