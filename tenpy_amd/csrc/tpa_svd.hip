@@ -2155,6 +2155,16 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     qrp_extract_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, X, Rtop);
     TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
     TPA_HIP_CHECK(hipStreamSynchronize(st));
+    {   // NaN / Inf in the input: ||A||_F^2 is not finite (the pivot search would silently report rank 0)
+        std::vector<double> hfro(n_jobs);
+        TPA_HIP_CHECK(hipMemcpyAsync(hfro.data(), fro2, n_jobs * sizeof(double), hipMemcpyDeviceToHost, st));
+        TPA_HIP_CHECK(hipStreamSynchronize(st));
+        for (int b = 0; b < n_jobs; ++b)
+            if (!std::isfinite(hfro[b])) {
+                snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: NaN/Inf in block %d", b);
+                return TPA_E_NAN;
+            }
+    }
     std::vector<int64_t> nested;
     int rmax = 0, nn = 0;
     for (int b = 0; b < n_jobs; ++b) {

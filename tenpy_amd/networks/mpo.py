@@ -76,6 +76,7 @@ class MPOEnvironment:
         self.L = psi.L
         self.dtype = np.result_type(psi.dtype, H.dtype)
         self._LP = [None] * self.L
+        self._heff_cache = {}        # (side, site) -> (env tensor, fused Heff, pipe); see TwoSiteH.combine_Heff
         self._RP = [None] * self.L
         self._LP[0] = self.init_LP(0)
         self._RP[self.L - 1] = self.init_RP(self.L - 1)

@@ -202,6 +202,86 @@ def test_svd_batch(env, cplx, shapes):
         assert bool((s[:-1] >= s[1:]).all())
 
 
+def _svd_call(torch, lib, mats, max_sweeps=60, rho=1e-6):
+    """tpa_svd_batch on a list of real host matrices -> list of (u, s, vh) host tensors, return code."""
+    jobs, a_off, u_off, s_off, v_off = [], 0, 0, 0, 0
+    for x in mats:
+        m, n = x.shape
+        k = min(m, n)
+        jobs.append([a_off, m, n, u_off, s_off, v_off, 0, 0])
+        a_off, u_off, s_off, v_off = a_off + m * n, u_off + m * k, s_off + k, v_off + k * n
+    A = torch.cat([x.reshape(-1) for x in mats]).cuda()
+    U = torch.zeros(u_off, dtype=torch.float64).cuda()
+    S = torch.zeros(s_off, dtype=torch.float64).cuda()
+    VH = torch.zeros(v_off, dtype=torch.float64).cuda()
+    jh = np.array(jobs, np.int64)
+    wb = lib.tpa_svd_worksize(0, jh.ctypes.data, len(jobs))
+    work = torch.empty(wb, dtype=torch.uint8).cuda()
+    sw = ctypes.c_int()
+    rc = lib.tpa_svd_batch(0, jh.ctypes.data, len(jobs), A.data_ptr(), U.data_ptr(), S.data_ptr(), VH.data_ptr(),
+                           work.data_ptr(), wb, max_sweeps, rho, ctypes.byref(sw), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = []
+    for x, j in zip(mats, jobs):
+        m, n = x.shape
+        k = min(m, n)
+        out.append((U[j[3]:j[3] + m * k].reshape(m, k).cpu(), S[j[4]:j[4] + k].cpu(), VH[j[5]:j[5] + k * n].reshape(k, n).cpu()))
+    return out, rc, sw.value
+
+
+def test_svd_rank_revealing_path(env):
+    """Rank-deficient, graded blocks like DMRG wave functions (pivoted-QR preconditioner + Jacobi on the r x n factor)
+    against torch's LAPACK SVD and against the same call with the preconditioner switched off."""
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mats = []
+    for (m, n, r) in [(300, 300, 160), (200, 333, 90), (333, 200, 200), (70, 40, 1), (1, 1, 1), (5, 90, 5), (64, 64, 0)]:
+        u, _ = torch.linalg.qr(torch.randn(m, max(r, 1), dtype=torch.float64, generator=g))
+        v, _ = torch.linalg.qr(torch.randn(n, max(r, 1), dtype=torch.float64, generator=g))
+        sv = torch.logspace(0, -9, max(r, 1), dtype=torch.float64) * (1. if r > 0 else 0.)
+        mats.append((u * sv) @ v.T)
+    res, rc, sweeps = _svd_call(torch, lib, mats)
+    assert rc == 0
+    lib.tpa_svd_set_algorithm(512)        # same kernels without the pivoted-QR preconditioner
+    try:
+        res_plain, rc_plain, sweeps_plain = _svd_call(torch, lib, mats)
+    finally:
+        lib.tpa_svd_set_algorithm(0)
+    assert rc_plain == 0
+    assert sweeps < sweeps_plain, "the preconditioner must reduce the number of Jacobi sweeps"
+    for x, (u, s, vh), (u2, s2, vh2) in zip(mats, res, res_plain):
+        m, n = x.shape
+        ref = torch.linalg.svdvals(x)
+        scale = max(ref[0].item(), 1e-300)
+        assert (s - ref).abs().max().item() <= 1e-13 * scale * max(m, n)          # absolute accuracy eps ||A||
+        assert (s - s2).abs().max().item() <= 1e-13 * scale * max(m, n)
+        assert bool((s[:-1] >= s[1:]).all())
+        assert ((u * s) @ vh - x).abs().max().item() <= 1e-12 * scale * max(m, n)
+        # vectors of sigma >= rho ||A|| (rho = 1e-6, the absolute floor of the stopping rule) are orthonormal to
+        # working precision, the ones below it to ~ eps rho ||A|| / sigma  (DESIGN.md 3.2)
+        for thresh, tol in ((1e-6, 1e-12), (1e-12, 1e-9)):
+            nz = s > thresh * scale
+            k = int(nz.sum())
+            if k:
+                assert (u[:, nz].T @ u[:, nz] - torch.eye(k, dtype=torch.float64)).abs().max().item() < tol
+                assert (vh[nz] @ vh[nz].T - torch.eye(k, dtype=torch.float64)).abs().max().item() < tol
+        # beyond the numerical rank: exact zeros, zero vectors (documented in include/tenpy_amd.h)
+        dead = s == 0
+        assert u[:, dead].abs().max().item() == 0.0 if bool(dead.any()) else True
+
+
+def test_svd_nan_input_is_an_error(env):
+    """NaN in a block: TPA_E_NAN -> ValueError like np_conserved.py:4978-4982, on both SVD paths."""
+    torch, lib, _lib = env
+    for n in (8, 96):                     # plain Jacobi path / pivoted-QR path
+        x = torch.randn(n, n, dtype=torch.float64)
+        x[n // 2, n // 3] = float("nan")
+        _, rc, _ = _svd_call(torch, lib, [x, torch.randn(n, n, dtype=torch.float64)])
+        assert rc == -3
+        with pytest.raises(ValueError):
+            _lib.check(rc, "svd")
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_qr_batch(env, cplx):
     torch, lib, _lib = env
