@@ -4,8 +4,9 @@ Follows the call sequence of the reference: ``Sweep.sweep`` (mps_co
 ``prepare_update_local`` (:498) -> ``update_local`` (dmrg.py:529: ``diag`` :672 = Lanczos,
 ``mixed_svd`` :876 = ``svd_theta``, ``set_B`` :934) -> ``update_env`` (:569).  Options keep the
 reference's names (``trunc_params``, ``lanczos_params``, ``chi_list``, ``max_sweeps``, ``min_sweeps``,
-``max_E_err``, ``N_sweeps_check``, ``combine``).  Only what a finite two-site sweep without mixer needs is
-here; the rest of ``algorithms/dmrg.py`` (mixers, infinite MPS, one-site engine) is out of scope this round.
+``max_E_err``, ``N_sweeps_check``, ``combine``, ``mixer``, ``mixer_params``, ``chi_list_reactivates_mixer``).  Only what a
+finite two-site sweep needs is here (optionally with the density-matrix mixer); the rest of ``algorithms/dmrg.py``
+(infinite MPS, one-site engine, subspace expansion) is out of scope.
 """
 import time
 
@@ -15,7 +16,7 @@ from ..linalg import np_conserved as npc
 from ..linalg.krylov_based import LanczosGroundState
 from ..linalg.truncation import svd_theta, TruncationError
 from ..networks.mpo import MPOEnvironment
-from .mps_common import TwoSiteH
+from .mps_common import DensityMatrixMixer, TwoSiteH
 
 __all__ = ['TwoSiteDMRGEngine', 'run']
 
@@ -41,6 +42,60 @@ class TwoSiteDMRGEngine:
         self.shard_matvec = options.get('shard_matvec', False)
         self.profile = options.get('profile', False)
         self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
+        self.mixer = None            # activated by run() / mixer_activate() (reference: pre_run_initialize :829)
+
+    # ---- mixer handling (reference mps_common.py:653-760, :1547-1653) -----------------------------------------
+    def mixer_activate(self):
+        """Create the mixer requested by ``options['mixer']`` (``True`` / 'DensityMatrixMixer'; default: none, as
+        ``TwoSiteDMRGEngine.use_mixer_by_default = False``, dmrg.py:867) with ``options['mixer_params']``."""
+        which = self.options.get('mixer', False)
+        if not which:
+            return
+        if which is not True and which != 'DensityMatrixMixer':
+            raise NotImplementedError("tenpy_amd: only the DensityMatrixMixer is available for the two-site engine")
+        mp = dict(self.options.get('mixer_params', {}))
+        self.mixer = DensityMatrixMixer(mp.get('amplitude', 1.e-5), self.H.IdL, self.H.IdR,
+                                        decay=mp.get('decay', 2.), disable_after=mp.get('disable_after', 15),
+                                        sweep_activated=self.sweeps)
+
+    def mixer_deactivate(self):
+        self.mixer = None
+
+    def mixer_cleanup(self):
+        """Bring the 2-D bond matrices left behind by a sweep with mixer back to diagonal form by SVDs of the
+        matrices, absorbing the unitaries into the neighbouring tensors and environments (reference :693-769)."""
+        psi, env = self.psi, self.env
+        for i in range(1, psi.L):
+            S = psi.get_SL(i)
+            if not isinstance(S, npc.Array):
+                continue
+            U, S, V = npc.svd(S, inner_labels=['vR', 'vL'])
+            S = S / np.linalg.norm(S)
+            form_L, form_R = psi.form[i - 1][1], psi.form[i][0]
+            B_L, B_R = psi.get_B(i - 1, None), psi.get_B(i, None)
+            if form_L == 0.:
+                B_L = npc.tensordot(B_L, U, axes=['vR', 'vL'])
+            elif form_L == 1.:
+                B_L = npc.tensordot(B_L, V.conj().replace_labels(['vR*', 'vL*'], ['vL', 'vR']), axes=['vR', 'vL'])
+            else:
+                raise RuntimeError("bond matrices are only supported next to A, B, Th or G form tensors")
+            if form_R == 0.:
+                B_R = npc.tensordot(V, B_R, axes=['vR', 'vL'])
+            elif form_R == 1.:
+                B_R = npc.tensordot(U.conj().replace_labels(['vR*', 'vL*'], ['vL', 'vR']), B_R, axes=['vR', 'vL'])
+            else:
+                raise RuntimeError("bond matrices are only supported next to A, B, Th or G form tensors")
+            psi.set_B(i - 1, B_L, form=psi.form[i - 1])
+            psi.set_SL(i, S)
+            psi.set_B(i, B_R, form=psi.form[i])
+            if env._LP[i] is not None:
+                LP = npc.tensordot(env._LP[i], U.conj(), axes=['vR*', 'vL*'])
+                LP = npc.tensordot(LP, U, axes=['vR', 'vL'])
+                env.set_LP(i, LP.transpose(['vR*', 'wR', 'vR']))
+            if env._RP[i - 1] is not None:
+                RP = npc.tensordot(V.conj(), env._RP[i - 1], axes=['vR*', 'vL*'])
+                RP = npc.tensordot(V, RP, axes=['vR', 'vL'])
+                env.set_RP(i - 1, RP.transpose(['vL', 'wL', 'vL*']))
 
     def get_sweep_schedule(self):
         L = self.psi.L
@@ -55,6 +110,8 @@ class TwoSiteDMRGEngine:
             keys = [k for k in self.chi_list if k <= self.sweeps]
             if keys:
                 self.trunc_params['chi_max'] = self.chi_list[max(keys)]
+            if optimize and self.sweeps in self.chi_list and self.options.get('chi_list_reactivates_mixer', True):
+                self.mixer_activate()                       # reference mps_common.py:376-382
         t0 = time.time()
         max_err, n_upd = 0., 0
         for i0, move_right, (upd_LP, upd_RP) in self.get_sweep_schedule():
@@ -62,6 +119,8 @@ class TwoSiteDMRGEngine:
             max_err = max(max_err, err.eps)
             n_upd += 1
         self.sweeps += 1
+        if self.mixer is not None and self.mixer.update_amplitude(self.sweeps) is None:
+            self.mixer_deactivate()
         st = self.sweep_stats
         st['sweep'].append(self.sweeps)
         st['E'].append(self.update_stats['E_total'][-1])
@@ -90,7 +149,13 @@ class TwoSiteDMRGEngine:
         tick('lanczos')
         i1 = i0 + 1
         qtotal_i0 = psi.get_B(i0, None).qtotal
-        U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[qtotal_i0, None], inner_labels=['vR', 'vL'])
+        if self.mixer is None:
+            U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[qtotal_i0, None], inner_labels=['vR', 'vL'])
+            S_a = S
+        else:       # reference dmrg.py:921-929: perturbed density matrices, S is a general bond matrix
+            qtotal_LR = [qtotal_i0, theta.chinfo.make_valid(theta.qtotal - qtotal_i0)]
+            rho_L, rho_R = self.mixer.mix_rho(eff_H, theta, update_LP, update_RP)
+            U, S, VH, err, S_a = self.mixer.svd_from_rho(rho_L, rho_R, theta, self.trunc_params, qtotal_LR)
         tick('svd')
         if update_LP:
             eff_H.update_LP(self.env, i1, U)
@@ -122,7 +187,7 @@ class TwoSiteDMRGEngine:
         us['N_lanczos'].append(N)
         us['time'].append(time.time() - t0)
         us['err'].append(err.eps)
-        us['chi'].append(len(S))
+        us['chi'].append(len(S_a))
         us['flops'].append(eff_H.flops_per_matvec)
         us['bytes'].append(eff_H.bytes_per_matvec)
         if self.log_matvec:
@@ -148,14 +213,18 @@ class TwoSiteDMRGEngine:
         max_E_err = opt.get('max_E_err', 1.e-8)
         n_check = opt.get('N_sweeps_check', 1)
         E_old = None
+        self.mixer_activate()
         while self.sweeps < max_sweeps:
             for _ in range(n_check):
                 self.sweep()
             E = self.sweep_stats['E'][-1]
             if E_old is not None and self.sweeps >= min_sweeps:
                 if abs((E - E_old) / max(abs(E), 1.)) < max_E_err:
-                    break
+                    if self.mixer is None:
+                        break
+                    self.mixer_deactivate()      # converged with the mixer still on: switch it off and go on (:905-914)
             E_old = E
+        self.mixer_cleanup()
         return self.sweep_stats['E'][-1], self.psi
 
 

@@ -137,10 +137,23 @@ class DensityMatrixMixer:
     (``_mix_LR``, :1846).  Returns a general (non-diagonal) bond matrix ``S`` like the reference.
     """
 
-    def __init__(self, amplitude=1.e-5, IdL=0, IdR=-1, explicit_plus_hc=False):
+    def __init__(self, amplitude=1.e-5, IdL=0, IdR=-1, explicit_plus_hc=False, decay=2., disable_after=15,
+                 sweep_activated=0):
+        assert amplitude <= 1.
         self.amplitude = amplitude
         self.IdL, self.IdR = IdL, IdR
         self.explicit_plus_hc = explicit_plus_hc
+        self.decay, self.disable_after, self.sweep_activated = decay, disable_after, sweep_activated
+
+    def update_amplitude(self, sweeps):
+        """Divide the amplitude by ``decay`` after a sweep; returns ``None`` when the mixer should be switched off
+        (``disable_after`` sweeps after activation or amplitude below machine precision; reference :1626-1653)."""
+        off = self.disable_after is not None and sweeps >= self.sweep_activated + self.disable_after
+        if self.amplitude is not None and self.decay is not None:
+            self.amplitude /= self.decay
+            if self.amplitude <= np.finfo('float').eps:
+                off = True
+        return None if off else self
 
     def _mix_LR(self, chi_MPO):
         mix_L = np.full((chi_MPO,), self.amplitude)

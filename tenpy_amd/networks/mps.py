@@ -49,7 +49,8 @@ class MPS:
 
     @property
     def chi(self):
-        return [len(s) for s in self._S[1:-1]]
+        """Bond dimensions; a 2-D bond matrix (DMRG with mixer) counts with its smaller dimension (reference mps.py)."""
+        return [int(min(s.shape)) if isinstance(s, npc.Array) else len(s) for s in self._S[1:-1]]
 
     def get_SL(self, i):
         return self._S[i]
@@ -58,10 +59,12 @@ class MPS:
         return self._S[i + 1]
 
     def set_SL(self, i, S):
-        self._S[i] = np.asarray(S)
+        """Schmidt values (1-D host array) or, during DMRG with a mixer, a general bond MATRIX (2-D device Array with
+        labels 'vL', 'vR') left of site i  (reference ``MPS.set_SL``; 2-D case: mps.py:5970)."""
+        self._S[i] = S if isinstance(S, npc.Array) else np.asarray(S)
 
     def set_SR(self, i, S):
-        self._S[i + 1] = np.asarray(S)
+        self._S[i + 1] = S if isinstance(S, npc.Array) else np.asarray(S)
 
     def set_B(self, i, B, form='B'):
         self._B[i] = B.transpose(['vL', 'p', 'vR']) if B._labels != ['vL', 'p', 'vR'] else B
@@ -69,8 +72,19 @@ class MPS:
 
     @staticmethod
     def _scale_axis_B(B, S, power, axis):
+        """``B.scale_axis(S**power)``; a 2-D bond matrix is contracted instead (reference mps.py:5964-6002; the
+        pseudo-inverse needed for power -1 is never requested inside a sweep and is not provided)."""
         if power == 0.:
             return B
+        if isinstance(S, npc.Array):
+            if power != 1.:
+                raise ValueError("Can't scale/tensordot a 2D `S` with power %r" % (power,))
+            labels = B.get_leg_labels()
+            if axis == 'vL':
+                B = npc.tensordot(S, B, axes=['vR', 'vL'])
+            else:
+                B = npc.tensordot(B, S, axes=['vR', 'vL'])
+            return B.transpose(labels)
         if power == 1.:
             return B.scale_axis(S, axis)
         return B.scale_axis(S**power, axis)
@@ -102,6 +116,9 @@ class MPS:
     def entanglement_entropy(self):
         res = []
         for s in self._S[1:-1]:
+            if isinstance(s, npc.Array):      # bond matrix: its singular values are the Schmidt values
+                _, s, _ = npc.svd(s, inner_labels=['vR', 'vL'])
+                s = s / np.linalg.norm(s)
             p = s[s > 1e-30]**2
             res.append(float(-np.sum(p * np.log(p))))
         return np.array(res)

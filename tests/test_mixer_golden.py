@@ -32,3 +32,34 @@ def test_mixer(backend):
         np.testing.assert_allclose(mine, ref, rtol=0, atol=1e-9)
         np.testing.assert_allclose(np.linalg.svd(S.to_ndarray(), compute_uv=False),
                                    np.linalg.svd(rec['S']['dense'], compute_uv=False), atol=1e-10)
+
+
+def test_dmrg_with_mixer(backend):
+    """Whole two-site DMRG runs with the density-matrix mixer switched on for the first sweeps vs the reference's
+    run (tests/golden/make_golden.py:gen_dmrg_mixer): energy of every bond update, truncation errors, on/off
+    schedule of the mixer, and -- after mixer_cleanup -- the Schmidt spectrum of every bond."""
+    from tenpy_amd.algorithms.dmrg import TwoSiteDMRGEngine
+    from tenpy_amd.models.spin_chains import spin_half_leg, xxz_chain_mpo
+    from tenpy_amd.networks.mps import MPS
+    for rec in golden('dmrg_mixer.pkl'):
+        L = rec['L']
+        H = xxz_chain_mpo(L, rec['Jxx'], rec['Jz'], rec['hz'])
+        _, p = spin_half_leg('Sz')
+        psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
+        eng = TwoSiteDMRGEngine(psi, H, {'mixer': True, 'mixer_params': {'amplitude': rec['amplitude'], 'decay': rec['decay'],
+                                                                          'disable_after': rec['disable_after']},
+                                         'trunc_params': {'chi_max': rec['chi'], 'svd_min': rec['svd_min']}, 'lanczos_params': {}})
+        eng.mixer_activate()
+        for s in range(rec['n_sweeps']):
+            assert (eng.mixer is not None) == rec['mixer_on'][s]
+            eng.sweep()
+            assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= 1e-10 * abs(rec['E_sweeps'][s])
+        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(eng.update_stats['err'], rec['err_updates'], rtol=0, atol=1e-11)
+        eng.mixer_cleanup()
+        for i in range(1, L):
+            S = psi.get_SL(i)
+            assert isinstance(S, np.ndarray) and S.ndim == 1
+            np.testing.assert_allclose(np.sort(S)[::-1], np.sort(rec['S'][i - 1])[::-1], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-8)
+        assert abs(psi.norm_test() - 1.) < 1e-10
