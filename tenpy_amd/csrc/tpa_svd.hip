@@ -636,49 +636,44 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__re
     }
     __syncthreads();
 
-    // ---- apply: X <- Q X on this part's columns of the W rows and of the G rows ------------------------
+    // ---- apply: X <- Q X on this part's columns of the W rows and of the G rows.  The column chunks of W and of G
+    //      assigned to this part form ONE list that is dealt out to the wavefronts, so that with enough parts every
+    //      wavefront has a single chunk: one load round trip, 16 MFMAs, one store (no second, dependent pass for G).
     double qa[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qa[kk] = Qm[l15][kk * 4 + l4];
-    for (int pass = 0; pass < 2; ++pass) {
-        double *M = (pass == 0) ? (W + J.w_off) : (G + J.g_off);
-        const int64_t len = (pass == 0) ? L : R;
-        const int64_t nch = (len + CHJ - 1) / CHJ;
-        const int64_t c_lo = nch * E.part / E.nparts, c_hi = nch * (E.part + 1) / E.nparts;
+    const int64_t nchW = (L + CHJ - 1) / CHJ, nchG = (R + CHJ - 1) / CHJ;
+    const int64_t w_lo = nchW * E.part / E.nparts, w_hi = nchW * (E.part + 1) / E.nparts;
+    const int64_t g_lo = nchG * E.part / E.nparts, g_hi = nchG * (E.part + 1) / E.nparts;
+    const int64_t nW = w_hi - w_lo, nU = nW + (g_hi - g_lo);
+    for (int64_t u = wave; u < nU; u += NTG / 64) {
+        const bool isW = u < nW;
+        double *M = isW ? (W + J.w_off) : (G + J.g_off);
+        const int64_t len = isW ? L : R;
+        const int64_t c = isW ? (w_lo + u) : (g_lo + (u - nW));
+        const int64_t col = c * CHJ + lane;
         double reg[TRJ];
-        int64_t c = c_lo + wave;
-        if (c < c_hi) {
-            const int64_t col = c * CHJ + lane;
 #pragma unroll
-            for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
-        }
-        for (; c < c_hi; c += NTG / 64) {
+        for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
 #pragma unroll
-            for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
-            const int64_t cn = c + NTG / 64;
-            if (cn < c_hi) {
-                const int64_t col = cn * CHJ + lane;
+        for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
+        d4 o[CHJ / 16];
 #pragma unroll
-                for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
-            }
-            d4 o[CHJ / 16];
+        for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
 #pragma unroll
-            for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int tile = 0; tile < CHJ / 16; ++tile) {
-                    const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
-                    o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
-                }
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int tile = 0; tile < CHJ / 16; ++tile) {
-                const int64_t oc = c * CHJ + tile * 16 + l15;
+                const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
+                o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t gr = rowoff[l4 + 4 * r];
-                    if (gr >= 0 && oc < len) M[gr * len + oc] = o[tile][r];
-                }
+        for (int tile = 0; tile < CHJ / 16; ++tile) {
+            const int64_t oc = c * CHJ + tile * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = rowoff[l4 + 4 * r];
+                if (gr >= 0 && oc < len) M[gr * len + oc] = o[tile][r];
             }
         }
     }
@@ -1901,7 +1896,10 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
             for (int64_t p = 0; p < NBp / 2; ++p) lay.bpairs.push_back(int2{b, (int)p});
             // column parts: >= 4 chunks of 64 columns each, at most 8 parts
             const int64_t nchunk = (J.L + 63) / 64;   // (complex kernels use 32-column chunks: twice as many)
-            int nparts = (int)std::min<int64_t>(8, std::max<int64_t>(1, nchunk / 4));
+            // real kernels: W and G chunks of a part are dealt out to 4 wavefronts together -> aim at <= 4 per part
+            const int64_t nch_all = nchunk + (J.R + 63) / 64;
+            int nparts = (dtype == TPA_C128) ? (int)std::min<int64_t>(8, std::max<int64_t>(1, nchunk / 4))
+                                             : (int)std::min<int64_t>(8, std::max<int64_t>(1, nch_all / 6));
             for (int64_t p = 0; p < NBp / 2; ++p)
                 for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
             lay.nb_max_pad = std::max(lay.nb_max_pad, NBp);
