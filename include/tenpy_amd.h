@@ -91,6 +91,14 @@ int tpa_lanczos_update(int dtype, int64_t n, void *w_dev, double alpha_re, doubl
 #define TPA_COPY_MAXDIM 6
 int tpa_copy_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
                    const void *src_base, void *dst_base, void *stream);
+/* dst slab (rows x cols, row stride dst_ld) = sum_t alpha_t * src_t slab (row stride src_ld_t), batched.
+ * Fuses tensordot(LP, W) + combine_legs of MPOEnvironment._contract_LHeff / _contract_RHeff (networks/mpo.py:3107,
+ * :3118; TwoSiteH.combine_Heff, mps_common.py:1350) when every charge block of the MPO tensor W is a single number:
+ * each (w', p, p*) slab of LHeff is a linear combination of the LP[:, w, :] blocks with the W entries as coefficients.
+ * jobs : int64[n_jobs][8] = {dst_off, rows, cols, dst_ld, term_begin, term_count, 0, 0}
+ * terms: int64[n_terms][4] = {src_off, src_ld, alpha_re, alpha_im}  (alpha_* are the IEEE-754 bit patterns of doubles) */
+int tpa_lincomb_batch(int dtype, const int64_t *jobs_dev, int n_jobs, const int64_t *terms_dev, int64_t max_job_elems,
+                      const void *src_base, void *dst_base, void *stream);
 /* x_b[i, j, l] *= s[s_off_b + j]  for each block b viewed as (pre, len, post).  Replaces
  * iscale_axis, np_conserved.py:2132-2140.  jobs: int64[n][6] = {x_off, pre, len, post, s_off, 0};
  * the scale vector s is real (F64) or of `dtype` when s_is_complex. */

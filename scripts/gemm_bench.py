@@ -13,8 +13,10 @@ from tenpy_amd.linalg.charges import ChargeInfo, LegCharge, LegPipe
 def dense(n, reps=5):
     ch = ChargeInfo()
     leg = LegCharge.from_trivial(n, ch)
-    a = npc.Array.from_ndarray(np.random.rand(n, n), [leg, leg.conj()])
-    b = npc.Array.from_ndarray(np.random.rand(n, n), [leg, leg.conj()])
+    fill = os.environ.get('FILL', 'rand')     # 'ones': constant data -> low toggle power (DVFS check)
+    gen = (lambda: np.random.rand(n, n)) if fill == 'rand' else (lambda: np.full((n, n), 1.0))
+    a = npc.Array.from_ndarray(gen(), [leg, leg.conj()])
+    b = npc.Array.from_ndarray(gen(), [leg, leg.conj()])
     plan, a, b = npc.plan_tensordot(a, b, axes=1)
     out = None
     for _ in range(2):
@@ -25,7 +27,7 @@ def dense(n, reps=5):
         out = plan.apply(a, b)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / reps
-    print("dense %d^3: %.3f ms  %.2f TFLOP/s  (tiles %d)" % (n, dt * 1e3, 2 * n**3 / dt / 1e12, plan.n_tiles), flush=True)
+    print("dense[%s] %d^3: %.3f ms  %.2f TFLOP/s  (tiles %d)" % (fill, n, dt * 1e3, 2 * n**3 / dt / 1e12, plan.n_tiles), flush=True)
 
 
 def sectors(chi, var=8.0):

@@ -42,3 +42,13 @@ plan, a_use, b_use = npc.plan_tensordot(LP, W0, axes=['wR', 'wL'])
 t_apply, _ = timeit(lambda: plan.apply(a_use, b_use))
 print("   plan.apply alone %.3f ms (%d gemms, %d tiles); transposed operand copy needed: %s" % (
     t_apply, plan.n_gemm, plan.n_tiles, a_use is not LP), flush=True)
+from tenpy_amd.algorithms import mps_common
+t_fused, res = timeit(lambda: mps_common._fused_heff(LP, W0, True))
+print("   fused lincomb builder %.3f ms (%s)" % (t_fused, 'ok' if res is not None else 'not applicable'), flush=True)
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5):
+    mps_common._fused_heff(LP, W0, True)
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(12)

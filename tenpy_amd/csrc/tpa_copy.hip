@@ -47,6 +47,41 @@ __global__ __launch_bounds__(NT) void copy_batch_kernel(const CopyJob *__restric
     }
 }
 
+
+// dst slab = sum_t alpha_t * src_t slab  (row-major slabs with their own row strides; coalesced along the columns)
+struct LinJob {   // int64[8]
+    int64_t dst_off, rows, cols, dst_ld, term_begin, term_count, pad0, pad1;
+};
+struct LinTerm {  // int64[4]
+    int64_t src_off, src_ld;
+    double a_re, a_im;
+};
+
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void lincomb_kernel(const LinJob *__restrict__ jobs, const LinTerm *__restrict__ terms,
+                                                     const double *__restrict__ src, double *__restrict__ dst) {
+    const LinJob J = jobs[blockIdx.y];
+    const int64_t total = J.rows * J.cols;
+    const LinTerm *T = terms + J.term_begin;
+    const int nt = (int)J.term_count;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int64_t r = e / J.cols, c = e - r * J.cols;
+        if (!CPLX) {
+            double v = 0.0;
+            for (int t = 0; t < nt; ++t) v = fma(T[t].a_re, src[T[t].src_off + r * T[t].src_ld + c], v);
+            dst[J.dst_off + r * J.dst_ld + c] = v;
+        } else {
+            double2 v{0.0, 0.0};
+            for (int t = 0; t < nt; ++t) {
+                const double2 x = reinterpret_cast<const double2 *>(src)[T[t].src_off + r * T[t].src_ld + c];
+                v.x += T[t].a_re * x.x - T[t].a_im * x.y;
+                v.y += T[t].a_re * x.y + T[t].a_im * x.x;
+            }
+            reinterpret_cast<double2 *>(dst)[J.dst_off + r * J.dst_ld + c] = v;
+        }
+    }
+}
+
 struct ScaleJob {  // int64[6]
     int64_t x_off, pre, len, post, s_off, pad;
 };
@@ -170,6 +205,21 @@ extern "C" int tpa_copy_batch(int dtype, const int64_t *jobs_dev, int n_jobs, in
         copy_batch_kernel<false><<<grid, NT, 0, st>>>((const CopyJob *)jobs_dev, (const double *)src_base, (double *)dst_base);
     else
         copy_batch_kernel<true><<<grid, NT, 0, st>>>((const CopyJob *)jobs_dev, (const double *)src_base, (double *)dst_base);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int tpa_lincomb_batch(int dtype, const int64_t *jobs_dev, int n_jobs, const int64_t *terms_dev,
+                                 int64_t max_job_elems, const void *src_base, void *dst_base, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n_jobs <= 0) return 0;
+    TPA_ARG_CHECK(n_jobs <= 65535);
+    dim3 grid(grid_x(max_job_elems), n_jobs);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TPA_F64)
+        lincomb_kernel<false><<<grid, NT, 0, st>>>((const LinJob *)jobs_dev, (const LinTerm *)terms_dev, (const double *)src_base, (double *)dst_base);
+    else
+        lincomb_kernel<true><<<grid, NT, 0, st>>>((const LinJob *)jobs_dev, (const LinTerm *)terms_dev, (const double *)src_base, (double *)dst_base);
     TPA_LAUNCH_CHECK();
     return 0;
 }

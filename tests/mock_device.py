@@ -183,6 +183,24 @@ class MockLib:
             dst[do] = v
         return 0
 
+    def tpa_lincomb_batch(self, code, jobs_p, n_jobs, terms_p, max_elems, src_p, dst_p, stream):
+        dt = _npdt(code)
+        jobs = REG.view(jobs_p, np.int64)[:8 * n_jobs].reshape(n_jobs, 8)
+        n_terms = int(np.max(jobs[:, 4] + jobs[:, 5])) if n_jobs else 0
+        terms = REG.view(terms_p, np.int64)[:4 * n_terms].reshape(n_terms, 4)
+        alphas = terms[:, 2:4].copy().view(np.float64)
+        src, dst = REG.view(src_p, dt), REG.view(dst_p, dt)
+        for j in jobs:
+            rows, cols = int(j[1]), int(j[2])
+            assert rows * cols <= max_elems, "max_job_elems too small"
+            r, c = np.indices((rows, cols)).reshape(2, -1)
+            acc = np.zeros(rows * cols, dtype=dt)
+            for t in range(int(j[4]), int(j[4] + j[5])):
+                a = alphas[t, 0] + (1j * alphas[t, 1] if code else 0.)
+                acc = acc + a * src[terms[t, 0] + r * terms[t, 1] + c]
+            dst[j[0] + r * j[3] + c] = acc
+        return 0
+
     def tpa_scale_axis_batch(self, code, jobs_p, n_jobs, max_elems, x_p, s_p, s_cplx, stream):
         dt = _npdt(code)
         jobs = REG.view(jobs_p, np.int64)[:6 * n_jobs].reshape(n_jobs, 6)
