@@ -1324,15 +1324,16 @@ __global__ __launch_bounds__(NT) void qrp_init_kernel(const QrpJob *__restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) state[blockIdx.y] = QrpState{0, 0, 0, 0};
 }
 
-constexpr int NTP = 256;
+constexpr int NTP_MAX = 256;   // threads of the panel kernel: 64 (one wavefront, no cross-wave barriers) or 256
 constexpr int PNB = 8;    // pivot columns factorised per launch (panel pivoting: the PNB largest residual columns)
 constexpr int RPT_MAX = 32;  // rows / candidate columns per thread held in registers (template RPT = 8, 16, 32)  ->  max(m, n) <= 8192
 
 // sum K values over the workgroup (NTP threads); results valid in every thread
-template <int K>
+template <int NTP, int K>
 __device__ __forceinline__ void block_sum_vec(double (&v)[K], double (*red)[PNB + 1]) {
 #pragma unroll
     for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+    if (NTP == 64) return;   // a single wavefront: wave_sum already left the total in every lane
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -1348,11 +1349,15 @@ __device__ __forceinline__ void block_sum_vec(double (&v)[K], double (*red)[PNB 
     }
 }
 
-// One workgroup per block: pick the (up to) PNB remaining columns with the largest residual norms, move them to
-// positions k .. k+nbk-1 and factorise that panel (Householder vectors -> Vall, R entries -> X, compact-WY factor
-// -> Tpan).  Greedy pivoting is exact for the first column of a panel and by pre-panel norms for the others; the
-// rank decision is unaffected because the trailing update recomputes every residual norm exactly.
-template <int RPT>
+// One workgroup per block: pick the (up to) PNB unprocessed columns with the largest residual norms and factorise
+// that panel (Householder vectors -> Vall, R entries -> X, compact-WY factor -> Tpan).  Columns are never moved:
+// cperm[k + l] records which physical column became logical column k + l, cn[j] = -1 marks column j as done, and the
+// trailing update walks over the physical columns skipping the marked ones.  Greedy pivoting is exact for the first
+// column of a panel and by pre-panel norms for the others; the rank decision is unaffected because the trailing update
+// recomputes every residual norm exactly.
+// (A one-wavefront variant with the whole panel in the registers of one SIMD was 1.6x slower: the per-lane serial work
+// outweighs the saved barriers.)
+template <int NTP, int RPT>
 __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict__ jobs, int k, double *__restrict__ X,
                                                        double *__restrict__ Vall, double *__restrict__ cn,
                                                        double *__restrict__ tau, int64_t *__restrict__ cperm,
@@ -1361,9 +1366,8 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
     __shared__ double rv[NTP / 64];
     __shared__ int64_t ri[NTP / 64];
     __shared__ double red[NTP / 64][PNB + 1];
-    __shared__ int64_t s_p[PNB], s_from[PNB], s_to[PNB], s_vac[PNB], s_cpp[PNB], s_cpd[PNB];
-    __shared__ double s_cnd[PNB], s_g[PNB + 1];
-    __shared__ int s_nbk, s_nmove;
+    __shared__ int64_t s_p[PNB];
+    __shared__ int s_nbk;
     __shared__ double s_alpha, s_vrow[PNB], Tf[PNB][PNB];
     const int b = blockIdx.x;
     const QrpJob J = jobs[b];
@@ -1375,12 +1379,12 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
         if (tid == 0) state[b] = QrpState{st0.last ? st0.rank : (int)N, 1, 0, 0};
         return;
     }
-    // ---- the PNB largest residual norms among the columns k .. N-1 (ties -> smallest index: deterministic)
+    // ---- the PNB largest residual norms among the unprocessed columns (ties -> smallest index: deterministic)
     double cand[RPT];
 #pragma unroll
     for (int t = 0; t < RPT; ++t) {
-        const int64_t j = k + tid + (int64_t)t * NTP;
-        cand[t] = (j < N) ? cn[J.c_off + j] : -4.0;
+        const int64_t j = tid + (int64_t)t * NTP;
+        cand[t] = (j < N) ? cn[J.c_off + j] : -4.0;       // processed columns hold -1
     }
     const double thresh = tol2 * fro2[b];
     if (tid == 0) s_nbk = 0;
@@ -1391,7 +1395,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
         for (int t = 0; t < RPT; ++t)
             if (cand[t] > bv) {
                 bv = cand[t];
-                bidx = k + tid + (int64_t)t * NTP;
+                bidx = tid + (int64_t)t * NTP;
             }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -1426,69 +1430,32 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
         const int64_t w = s_p[l];
 #pragma unroll
         for (int t = 0; t < RPT; ++t)
-            if (k + tid + (int64_t)t * NTP == w) cand[t] = -4.0;
+            if (tid + (int64_t)t * NTP == w) cand[t] = -4.0;
     }
     const int nbk = s_nbk;
     if (nbk == 0) {
         if (tid == 0) state[b] = QrpState{k, 1, 0, 0};
         return;
     }
-    // ---- bookkeeping (thread 0): which displaced columns go to which vacated positions; cn / cperm follow
-    if (tid == 0) {   // (LDS scratch arrays: dynamically indexed locals would live in scratch memory)
-        int nm = 0, nv = 0;
-        for (int l = 0; l < nbk; ++l)
-            if (s_p[l] >= k + nbk) s_vac[nv++] = s_p[l];
-        for (int64_t d = k; d < k + nbk; ++d) {
-            bool chosen = false;
-            for (int l = 0; l < nbk; ++l) chosen = chosen || (s_p[l] == d);
-            if (!chosen) {
-                s_from[nm] = d;
-                s_to[nm] = s_vac[nm];
-                ++nm;
-            }
-        }
-        s_nmove = nm;
-        for (int l = 0; l < nbk; ++l) s_cpp[l] = cperm[J.c_off + s_p[l]];
-        for (int a = 0; a < nm; ++a) {
-            s_cpd[a] = cperm[J.c_off + s_from[a]];
-            s_cnd[a] = cn[J.c_off + s_from[a]];
-        }
-        for (int a = 0; a < nm; ++a) {
-            cperm[J.c_off + s_to[a]] = s_cpd[a];
-            cn[J.c_off + s_to[a]] = s_cnd[a];
-        }
-        for (int l = 0; l < nbk; ++l) {
-            cperm[J.c_off + k + l] = s_cpp[l];
-            cn[J.c_off + k + l] = -1.0;   // processed
-        }
+    if (tid == 0) {
         const bool last = (nbk < PNB);
         state[b] = QrpState{last ? k + nbk : 0, 0, nbk, last ? 1 : 0};
         for (int x = 0; x < PNB; ++x)
             for (int y = 0; y < PNB; ++y) Tf[x][y] = 0.0;
     }
+    if (tid < nbk) {
+        cperm[J.c_off + k + tid] = s_p[tid];
+        cn[J.c_off + s_p[tid]] = -1.0;     // processed
+    }
     __syncthreads();
-    const int nmove = s_nmove;
     double *Xb = X + J.x_off;
-    // ---- gather the panel into registers (row-local), move the displaced columns
+    // ---- gather the panel into registers (X is column-major: contiguous loads)
     double c[PNB][RPT];
-    {
-        double mv[PNB][RPT];   // all loads first, then the stores (possible aliasing would serialise them otherwise)
 #pragma unroll
-        for (int t = 0; t < RPT; ++t) {
-            const int64_t i = tid + (int64_t)t * NTP;
+    for (int t = 0; t < RPT; ++t) {
+        const int64_t i = tid + (int64_t)t * NTP;
 #pragma unroll
-            for (int l = 0; l < PNB; ++l) {
-                c[l][t] = (i < M && l < nbk) ? Xb[s_p[l] * M + i] : 0.0;
-                mv[l][t] = (i < M && l < nmove) ? Xb[s_from[l] * M + i] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < RPT; ++t) {
-            const int64_t i = tid + (int64_t)t * NTP;
-#pragma unroll
-            for (int l = 0; l < PNB; ++l)
-                if (i < M && l < nmove) Xb[s_to[l] * M + i] = mv[l][t];
-        }
+        for (int l = 0; l < PNB; ++l) c[l][t] = (i < M && l < nbk) ? Xb[s_p[l] * M + i] : 0.0;
     }
     // ---- factorise the panel, column by column (must be fully unrolled: c[l] has to stay in registers)
 #pragma clang loop unroll(full)
@@ -1506,7 +1473,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                         for (int t = 0; t < RPT; ++t) y[m] = fma(c[m][t], c[l][t], y[m]);
                     }
                 }
-                block_sum_vec<PNB>(y, red);
+                block_sum_vec<NTP, PNB>(y, red);
                 double z[PNB];
 #pragma unroll
                 for (int m = 0; m < PNB; ++m) {
@@ -1524,7 +1491,8 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                         for (int t = 0; t < RPT; ++t) c[l][t] = fma(-c[m][t], z[m], c[l][t]);
                     }
             }
-            // norms below the diagonal, inner products with the earlier vectors (for Tf), alpha
+            // norm below the diagonal and inner products with the earlier vectors (for Tf) in one reduction; the diagonal
+            // element alpha and row kl of the earlier vectors are broadcast through LDS by the thread that owns row kl
             double g[PNB + 1];
 #pragma unroll
             for (int q = 0; q <= PNB; ++q) g[q] = 0.0;
@@ -1543,7 +1511,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                         if (m < l) s_vrow[m] = c[m][t];
                 }
             }
-            block_sum_vec<PNB + 1>(g, red);
+            block_sum_vec<NTP, PNB + 1>(g, red);
             const double s2 = g[PNB], alpha = s_alpha;
             double beta = alpha, tk = 0.0, scale = 0.0;
             if (s2 > 0.0) {
@@ -1551,31 +1519,32 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                 tk = (beta - alpha) / beta;
                 scale = 1.0 / (alpha - beta);
             }
-            if (tid == 0) {
-                tau[J.c_off + kl] = tk;
-                Tf[l][l] = tk;
+            // column l of the compact-WY factor: Tf[i2][l] = -tau sum_{m=i2}^{l-1} Tf[i2][m] (v_m^T v_l), thread i2 each
+            if (tid < l) {
+                double acc = 0;
 #pragma unroll
-                for (int m = 0; m < PNB; ++m) s_g[m] = g[m] * scale + s_vrow[m];   // v_m^T v_l
-                for (int i2 = 0; i2 < l; ++i2) {
-                    double acc = 0;
-                    for (int m = i2; m < l; ++m) acc = fma(Tf[i2][m], s_g[m], acc);
-                    Tf[i2][l] = -tk * acc;
-                }
+                for (int m = 0; m < PNB; ++m)
+                    if (m >= tid && m < l) acc = fma(Tf[tid][m], g[m] * scale + s_vrow[m], acc);
+                Tf[tid][l] = -tk * acc;
+            } else if (tid == l) {
+                Tf[l][l] = tk;
+                tau[J.c_off + kl] = tk;
             }
             double *vk = Vall + J.x_off + kl * M;
+            double *xc = Xb + s_p[l] * M;
 #pragma unroll
             for (int t = 0; t < RPT; ++t) {
                 const int64_t i = tid + (int64_t)t * NTP;
                 if (i < M) {
                     double v;
                     if (i < kl) {
-                        Xb[kl * M + i] = c[l][t];   // R entry above the diagonal
                         v = 0.0;
+                        xc[i] = c[l][t];              // R entry (rows k .. kl-1 were changed by this panel's earlier reflectors)
                     } else if (i == kl) {
-                        Xb[kl * M + i] = beta;
+                        xc[i] = beta;
                         v = 1.0;
                     } else {
-                        Xb[kl * M + i] = 0.0;
+                        xc[i] = 0.0;
                         v = c[l][t] * scale;
                     }
                     vk[i] = v;
@@ -1608,11 +1577,12 @@ struct WySmem {
 
 template <int NB, bool TRANS, bool NORMS>
 __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t cs, int64_t k0, int64_t M, int64_t j0, int64_t jend,
-                                                const double *__restrict__ V, int nb, int64_t kend, WySmem<NB> &sm) {
+                                                const double *__restrict__ V, int nb, int64_t kend, WySmem<NB> &sm,
+                                                bool col_ok = true) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = lane & 15, kq = lane >> 4;
     const int64_t j = j0 + lo;
-    const bool jok = j < jend;
+    const bool jok = (j < jend) && col_ok;
     // ---- pass 1: Y(l, j) = sum_i V(l, i) C(i, j)
     d4 acc = {0, 0, 0, 0};
     for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 16 * (NTR / 64)) {
@@ -1701,8 +1671,8 @@ __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t 
     return t;
 }
 
-// trailing update with the panel's nbk reflectors:  X[k:, j] <- (I - V Tf^T V^T) X[k:, j]  for j >= k + nbk,
-// plus the exact residual norms (rows >= k + nbk) of the updated columns.
+// trailing update with the panel's nbk reflectors:  X[k:, j] <- (I - V Tf^T V^T) X[k:, j]  for every column j that has not
+// been factorised yet (cn[j] >= 0; tiles walk over the physical columns), plus the exact residual norms (rows >= k + nbk).
 __global__ __launch_bounds__(NTR) void qrp_update_kernel(const QrpJob *__restrict__ jobs, int k, double *__restrict__ X,
                                                          const double *__restrict__ Vall, double *__restrict__ cn,
                                                          const QrpState *__restrict__ state,
@@ -1713,22 +1683,52 @@ __global__ __launch_bounds__(NTR) void qrp_update_kernel(const QrpJob *__restric
     if (st.done || st.nbk == 0) return;
     const QrpJob J = jobs[b];
     const int nbk = st.nbk;
-    const int64_t j0 = (int64_t)k + nbk + (int64_t)blockIdx.x * RCOLS;
+    const int64_t j0 = (int64_t)blockIdx.x * RCOLS;
     if (j0 >= J.N) return;
+    const int64_t jl = j0 + (threadIdx.x & (RCOLS - 1));
+    const bool col_ok = (jl < J.N) && (cn[J.c_off + jl] >= 0.0);
+    if (__ballot(col_ok) == 0) return;   // same 16 columns in every wavefront: uniform over the workgroup
     if (threadIdx.x < PNB * PNB) sm.T[threadIdx.x / PNB][threadIdx.x % PNB] = Tpan[(int64_t)b * PNB * PNB + threadIdx.x];
     const double nrm = wy_apply_tile<PNB, true, true>(X + J.x_off, 1, J.M, k, J.M, j0, J.N, Vall + J.x_off + (int64_t)k * J.M,
-                                                      nbk, (int64_t)k + nbk, sm);
-    if (threadIdx.x < RCOLS && j0 + threadIdx.x < J.N) cn[J.c_off + j0 + threadIdx.x] = nrm;
+                                                      nbk, (int64_t)k + nbk, sm, col_ok);
+    if (threadIdx.x < RCOLS && col_ok) cn[J.c_off + jl] = nrm;
 }
 
-// R_top (r x N, contiguous) = upper-triangular part of the first r rows of X
+// after the factorisation: the columns that were never used as pivots become the logical columns r .. N-1 (in
+// increasing physical order)
+__global__ __launch_bounds__(NT) void qrp_finish_perm_kernel(const QrpJob *__restrict__ jobs, const QrpState *__restrict__ state,
+                                                             const double *__restrict__ cn, int64_t *__restrict__ cperm) {
+    __shared__ int cnt[NT];
+    const QrpJob J = jobs[blockIdx.x];
+    const int64_t N = J.N, r = state[blockIdx.x].rank;
+    const int64_t per = (N + NT - 1) / NT, lo = (int64_t)threadIdx.x * per, hi = (lo + per < N) ? lo + per : N;
+    int mine = 0;
+    for (int64_t j = lo; j < hi; ++j) mine += (cn[J.c_off + j] >= 0.0) ? 1 : 0;
+    cnt[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < NT; ++t) {
+            const int c = cnt[t];
+            cnt[t] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    int64_t pos = r + cnt[threadIdx.x];
+    for (int64_t j = lo; j < hi; ++j)
+        if (cn[J.c_off + j] >= 0.0) cperm[J.c_off + pos++] = j;
+}
+
+// R_top (r x N, contiguous, logical column order) = upper-trapezoidal part of the first r rows of X
 __global__ __launch_bounds__(NT) void qrp_extract_kernel(const QrpJob *__restrict__ jobs, const QrpState *__restrict__ state,
-                                                         const double *__restrict__ X, double *__restrict__ Rtop) {
+                                                         const double *__restrict__ X, const int64_t *__restrict__ cperm,
+                                                         double *__restrict__ Rtop) {
     const QrpJob J = jobs[blockIdx.y];
     const int64_t r = state[blockIdx.y].rank, N = J.N;
     for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < r * N; e += (int64_t)gridDim.x * NT) {
         const int64_t i = e / N, j = e - i * N;
-        Rtop[J.r_off + e] = (j >= i) ? X[J.x_off + j * J.M + i] : 0.0;
+        Rtop[J.r_off + e] = (j >= i) ? X[J.x_off + cperm[J.c_off + j] * J.M + i] : 0.0;
     }
 }
 
@@ -2132,14 +2132,14 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     const double tol2 = QRP_RANK_TOL * QRP_RANK_TOL;
     double *Tpan = (double *)(work + q.off_tpan);
     for (int k = 0, step = 0;; k += PNB, ++step) {
-        if (q.m_max <= 8 * NTP)
-            qrp_panel_kernel<8><<<n_jobs, NTP, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
-        else if (q.m_max <= 16 * NTP)
-            qrp_panel_kernel<16><<<n_jobs, NTP, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+        if (q.m_max <= 8 * 256)
+            qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+        else if (q.m_max <= 16 * 256)
+            qrp_panel_kernel<256, 16><<<n_jobs, 256, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
         else
-            qrp_panel_kernel<32><<<n_jobs, NTP, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+            qrp_panel_kernel<256, 32><<<n_jobs, 256, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
         if (k >= nmax) break;   // that launch only finalised the states
-        const int tiles = (nmax - k - 1 + RCOLS - 1) / RCOLS;
+        const int tiles = (nmax + RCOLS - 1) / RCOLS;   // physical columns; finished ones are skipped inside
         if (tiles > 0) qrp_update_kernel<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, X, Vall, cn, state, Tpan);
         if ((step % QRP_POLL) == QRP_POLL - 1) {
             TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
@@ -2150,7 +2150,8 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
         }
     }
     TPA_LAUNCH_CHECK();
-    qrp_extract_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, X, Rtop);
+    qrp_finish_perm_kernel<<<n_jobs, NT, 0, st>>>(qjobs, state, cn, cperm);
+    qrp_extract_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, X, cperm, Rtop);
     TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
     TPA_HIP_CHECK(hipStreamSynchronize(st));
     {   // NaN / Inf in the input: ||A||_F^2 is not finite (the pivot search would silently report rank 0)
@@ -2225,7 +2226,7 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
     int64_t dim_max = 0;
     for (int b = 0; b < n_jobs; ++b) dim_max = std::max(dim_max, std::max(jobs_host[8 * b + 1], jobs_host[8 * b + 2]));
     if (dtype == TPA_F64 && tpa_svd_use_qrp && !tpa_svd_force_pairwise && lay.rmax_pad >= QRP_MIN_DIM &&
-        dim_max <= (int64_t)NTP * RPT_MAX) {
+        dim_max <= (int64_t)NTP_MAX * RPT_MAX) {
         QrpLayout q = make_qrp_layout(jobs_host, n_jobs);
         TPA_ARG_CHECK(work_bytes >= q.total);
         return svd_run_qrp(lay, q, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
