@@ -22,7 +22,7 @@ __all__ = ['TwoSiteDMRGEngine', 'run']
 
 
 class TwoSiteDMRGEngine:
-    def __init__(self, psi, model_H, options):
+    def __init__(self, psi, model_H, options, resume_data=None):
         self.psi = psi
         self.H = model_H
         self.options = options = dict(options)
@@ -43,6 +43,36 @@ class TwoSiteDMRGEngine:
         self.profile = options.get('profile', False)
         self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
         self.mixer = None            # activated by run() / mixer_activate() (reference: pre_run_initialize :829)
+        if resume_data is not None:  # reference: Algorithm.__init__(..., resume_data=...) / get_resume_data (algorithm.py)
+            self.sweeps = int(resume_data['sweeps'])
+            for k, v in resume_data.get('sweep_stats', {}).items():
+                self.sweep_stats[k] = list(v)
+            for k, v in resume_data.get('update_stats', {}).items():
+                self.update_stats[k] = list(v)
+            if resume_data.get('chi_max') is not None:
+                self.trunc_params['chi_max'] = resume_data['chi_max']
+
+    # ---- checkpoint / resume (reference: Algorithm.get_resume_data, simulations/simulation.py:1189) ----
+    def get_resume_data(self):
+        """Everything needed to continue the run in a new process: the state (device arrays are pickled through the host,
+        ``Array.__getstate__``), sweep counter and statistics.  Environments are NOT stored; they are rebuilt from the
+        state on demand.  Bond matrices of a mixer sweep are diagonalised first (``mixer_cleanup``)."""
+        self.mixer_cleanup()
+        return {'psi': self.psi, 'sweeps': self.sweeps, 'sweep_stats': {k: list(v) for k, v in self.sweep_stats.items()},
+                'update_stats': {k: list(v) for k, v in self.update_stats.items()},
+                'chi_max': self.trunc_params.get('chi_max')}
+
+    def save_checkpoint(self, filename):
+        import pickle
+        with open(filename, 'wb') as f:
+            pickle.dump(self.get_resume_data(), f, protocol=4)
+
+    @classmethod
+    def from_checkpoint(cls, filename, model_H, options):
+        import pickle
+        with open(filename, 'rb') as f:
+            data = pickle.load(f)
+        return cls(data['psi'], model_H, options, resume_data=data)
 
     # ---- mixer handling (reference mps_common.py:653-760, :1547-1653) -----------------------------------------
     def mixer_activate(self):
