@@ -203,226 +203,6 @@ constexpr int BRJ = 8;            // rows per block
 constexpr int TRJ = 2 * BRJ;      // rows per workgroup
 constexpr int CHJ = 64;           // columns per staged chunk
 constexpr int CHP = CHJ + 1;      // LDS row pitch of a chunk
-constexpr int NTB = 512;          // 8 wavefronts stream the row panels; 256 threads solve the 16x16 problem
-constexpr int NWB = NTB / 64;
-
-__global__ __launch_bounds__(NTB) void svd_block_round_kernel(const SvdJob *__restrict__ jobs,
-                                                              const int2 *__restrict__ bpairs, int round,
-                                                              double *__restrict__ W, double *__restrict__ G,
-                                                              unsigned int *__restrict__ n_rot,
-                                                              const double *__restrict__ fro2, double rho,
-                                                              int local_sweeps) {
-    __shared__ double Xs[NWB][TRJ][CHP];
-    __shared__ double Sm[TRJ][TRJ + 1], Tm[TRJ][TRJ + 1], Qm[TRJ][TRJ + 1], Qt[TRJ][TRJ + 1];
-    __shared__ int any_flag, sweep_flag;
-    const int2 jp = bpairs[blockIdx.x];
-    if (jp.x < 0) return;
-    const SvdJob J = jobs[jp.x];
-    const int64_t R = J.R, L = J.L;
-    const int64_t NB = (R + BRJ - 1) / BRJ;
-    const int64_t NBp = (NB + 1) / 2 * 2;
-    const int64_t mod = NBp - 1;
-    int64_t bi, bj;
-    {
-        const int64_t r = (mod > 0) ? (round % mod) : 0;
-        const int64_t i = jp.y;
-        if (i == 0) {
-            bi = NBp - 1;
-            bj = r;
-        } else {
-            bi = (r + i) % mod;
-            bj = (r - i + mod) % mod;
-        }
-        if (bi > bj) {
-            const int64_t t = bi;
-            bi = bj;
-            bj = t;
-        }
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // global row of local row t (or -1)
-    auto grow = [&](int t) -> int64_t {
-        const int64_t b = (t < BRJ) ? bi : bj;
-        const int64_t r = b * BRJ + (t % BRJ);
-        return (b < NB && r < R) ? r : -1;
-    };
-    if (grow(0) < 0 && grow(BRJ) < 0) return;
-    int64_t rowoff[TRJ];  // element offset of each local row inside a row-major (rows x len) matrix / len
-#pragma unroll
-    for (int t = 0; t < TRJ; ++t) rowoff[t] = grow(t);
-
-    // ---- phase 1: Gram -------------------------------------------------------------------------
-    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    const int64_t nchunk = (L + CHJ - 1) / CHJ;
-    {
-        const double *Wb = W + J.w_off;
-        double reg[TRJ];
-        int64_t c = wave;
-        if (c < nchunk) {
-            const int64_t col = c * CHJ + lane;
-#pragma unroll
-            for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < L) ? Wb[rowoff[t] * L + col] : 0.0;
-        }
-        for (; c < nchunk; c += NWB) {
-#pragma unroll
-            for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
-            const int64_t cn = c + NWB;
-            if (cn < nchunk) {  // prefetch the next chunk while the MFMAs of this one run
-                const int64_t col = cn * CHJ + lane;
-#pragma unroll
-                for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < L) ? Wb[rowoff[t] * L + col] : 0.0;
-            }
-#pragma unroll
-            for (int ks = 0; ks < CHJ / 4; ks += 2) {
-                const double a0 = Xs[wave][l15][ks * 4 + l4];
-                const double a1 = Xs[wave][l15][ks * 4 + 4 + l4];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
-            }
-        }
-    }
-    // partial Gram of this wave -> Xs[wave] (reuse) ; rows (l4 + 4 r), col l15
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Xs[wave][l4 + 4 * r][l15] = acc0[r] + acc1[r];
-    if (tid == 0) any_flag = 0;
-    __syncthreads();
-    const int ei = (tid >> 4) & 15, ej = tid & 15;
-    const bool solver = tid < TRJ * TRJ;
-    if (solver) {
-        double sacc = 0;
-#pragma unroll
-        for (int w = 0; w < NWB; ++w) sacc += Xs[w][ei][ej];
-        Sm[ei][ej] = sacc;
-        Qm[ei][ej] = (ei == ej) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-
-    // ---- phase 2: cyclic two-sided Jacobi on the 16 x 16 Gram matrix, one element per thread -----
-    const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[jp.x];
-    // Convergence is judged on the FRESH Gram matrix only (the exact Hestenes criterion on the data);
-    // the in-LDS updates below carry rounding noise and must not decide whether the sweep "rotated".
-    if (solver && ei < ej) {
-        const double a = Sm[ei][ei], b = Sm[ej][ej], g = Sm[ei][ej];
-        if (svd_needs_rotation(a, b, g * g, tol, floor2)) any_flag = 1;
-    }
-    __syncthreads();
-    if (any_flag == 0) return;  // these 16 rows are already mutually orthogonal
-    // rotation of the pair that contains index i in round rr (computed redundantly by every thread that
-    // needs it: no serial section, one barrier less per round).  Returns partner and (c_self, c_partner)
-    // of the row update  x_i' = c_self x_i + c_part x_partner.
-    auto rot_of = [&](int i, int rr, int &pi, double &cs, double &cp) -> bool {
-        if (i == TRJ - 1)
-            pi = rr;
-        else if (i == rr)
-            pi = TRJ - 1;
-        else
-            pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1);
-        const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
-        const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
-        double c = 1.0, s = 0.0;
-        bool did = false;
-        if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
-            // The angle only has to be approximately right (an error eps_t leaves a residual coupling
-            // ~eps_t*gamma, removed at the next visit); what must hold to full precision is c^2 + s^2 = 1.
-            // So zeta and t use the raw hardware reciprocal / sqrt, and only c gets Newton-refined.
-            const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
-            const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
-            const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
-            const double x = fma(t, t, 1.0);
-            double c0 = __builtin_amdgcn_rsq(x);
-            c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
-            c = c0 * fma(-0.5 * x * c0, c0, 1.5);
-            s = c * t;
-            did = true;
-        }
-        cs = c;
-        cp = (i == p) ? -s : s;  // row p: x' = c x - s y ; row q: y' = s x + c y
-        return did;
-    };
-    for (int sweep = 0; sweep < local_sweeps; ++sweep) {
-        if (tid == 0) sweep_flag = 0;
-        __syncthreads();
-        for (int rr = 0; rr < TRJ - 1; ++rr) {
-            int pi = 0, pj = 0;
-            double csi = 1, cpi = 0, csj = 1, cpj = 0;
-            if (solver) {
-                const bool d1 = rot_of(ei, rr, pi, csi, cpi);
-                rot_of(ej, rr, pj, csj, cpj);
-                if (d1 && ej == 0) sweep_flag = 1;
-                Tm[ei][ej] = csi * Sm[ei][ej] + cpi * Sm[pi][ej];
-                Qt[ei][ej] = csi * Qm[ei][ej] + cpi * Qm[pi][ej];
-            }
-            __syncthreads();
-            if (solver) {
-                Sm[ei][ej] = csj * Tm[ei][ej] + cpj * Tm[ei][pj];
-                Qm[ei][ej] = Qt[ei][ej];
-            }
-            __syncthreads();
-        }
-        if (sweep_flag == 0) break;
-        __syncthreads();
-    }
-    __syncthreads();
-    if (tid == 0) atomicAdd(n_rot, 1u);
-
-    // ---- phase 3: X <- Q X on the rows of W, then of G --------------------------------------------
-    double qa[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qa[kk] = Qm[l15][kk * 4 + l4];  // A fragment of Q for k-step kk
-    for (int pass = 0; pass < 2; ++pass) {
-        double *M = (pass == 0) ? (W + J.w_off) : (G + J.g_off);
-        const int64_t len = (pass == 0) ? L : R;
-        const int64_t nch = (len + CHJ - 1) / CHJ;
-        double reg[TRJ];
-        int64_t c = wave;
-        if (c < nch) {
-            const int64_t col = c * CHJ + lane;
-#pragma unroll
-            for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
-        }
-        for (; c < nch; c += NWB) {
-#pragma unroll
-            for (int t = 0; t < TRJ; ++t) Xs[wave][t][lane] = reg[t];
-            const int64_t cn = c + NWB;
-            if (cn < nch) {
-                const int64_t col = cn * CHJ + lane;
-#pragma unroll
-                for (int t = 0; t < TRJ; ++t) reg[t] = (rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
-            }
-            d4 o[CHJ / 16];
-#pragma unroll
-            for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int tile = 0; tile < CHJ / 16; ++tile) {
-                    const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
-                    o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
-                }
-#pragma unroll
-            for (int tile = 0; tile < CHJ / 16; ++tile) {
-                const int64_t oc = c * CHJ + tile * 16 + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t gr = rowoff[l4 + 4 * r];
-                    if (gr >= 0 && oc < len) M[gr * len + oc] = o[tile][r];
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Split block-Jacobi round: the streaming phases of one block pair are spread over `nparts` workgroups
-// (column ranges), because a single CU can only pull ~10-12 B/clk from L2/MALL: one workgroup per pair
-// made the round per-CU-bandwidth bound (measured 19 us of 36 us in the apply phase at R = L = 1086).
-//   kernel G : partial 16x16 Gram of (pair, column part)            -> gpart[entry][256]
-//   kernel A : every (pair, part) workgroup sums the partials of its pair in a FIXED order (deterministic,
-//              identical in all parts), solves the 16x16 problem in ONE wavefront (no workgroup barriers:
-//              the matrix lives in LDS, cross-lane traffic is ordered by the in-order LDS pipe), and applies
-//              Q to its column part of the W rows and of the G rows.
 struct BEntry {  // int32[4]
     int job, pair, part, nparts;
 };
@@ -448,6 +228,90 @@ __device__ __forceinline__ void block_pair_of(const SvdJob &J, int pair, int rou
 }
 
 constexpr int NTG = 256;  // 4 wavefronts per (pair, part) workgroup
+
+// Local solve of the 16 x 16 symmetric problem by ONE wavefront (callers: the first wavefront of the workgroup).
+// Sm: Gram matrix (destroyed), Qm: accumulated rotations (identity on entry); csA / cpA / partA: LDS scratch.
+__device__ __forceinline__ void svd_local_solve(double (*Sm)[TRJ + 1], double (*Qm)[TRJ + 1], double *csA, double *cpA,
+                                                int *partA, int lane, int local_sweeps, int full_local, double tol,
+                                                double floor2) {
+    // ---- local solve: ONE wavefront, 4 matrix elements per lane, no workgroup barriers ---------------
+    // `full` rounds sweep all 120 pairs of the 16 rows (15 local rounds); otherwise only the 64 CROSS pairs
+    // between the two 8-row blocks are rotated (8 local rounds, partner of i<8 is 8 + (i + rr) % 8): pairs
+    // inside a block were orthogonalised when the block last took part in a full round and are only
+    // perturbed at second order since.  The host requests a full round once per sweep for every pair.
+    {
+        const int ei = lane >> 2, ej0 = (lane & 3) * 4;
+        const int n_local = full_local ? (TRJ - 1) : BRJ;
+        for (int sweep = 0; sweep < local_sweeps; ++sweep) {
+            bool rotated = false;
+            for (int rr = 0; rr < n_local; ++rr) {
+                if (lane < TRJ) {
+                    const int i = lane;
+                    int pi;
+                    if (full_local) {
+                        if (i == TRJ - 1)
+                            pi = rr;
+                        else if (i == rr)
+                            pi = TRJ - 1;
+                        else
+                            pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1);
+                    } else {
+                        pi = (i < BRJ) ? (BRJ + ((i + rr) & (BRJ - 1))) : (((i - BRJ) - rr) & (BRJ - 1));
+                    }
+                    const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
+                    const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
+                    double c = 1.0, s = 0.0;
+                    if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
+                        const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
+                        const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
+                        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
+                        const double x = fma(t, t, 1.0);
+                        double c0 = __builtin_amdgcn_rsq(x);
+                        c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        c = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                        s = c * t;
+                        rotated = true;
+                    }
+                    partA[i] = pi;
+                    csA[i] = c;
+                    cpA[i] = (i == p) ? -s : s;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    const int pi = partA[ei];
+                    const double cs = csA[ei], cp = cpA[ei];
+                    double s_new[4], q_new[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s_new[u] = cs * Sm[ei][ej0 + u] + cp * Sm[pi][ej0 + u];
+                        q_new[u] = cs * Qm[ei][ej0 + u] + cp * Qm[pi][ej0 + u];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        Sm[ei][ej0 + u] = s_new[u];
+                        Qm[ei][ej0 + u] = q_new[u];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                {
+                    double s_new[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ej = ej0 + u, pj = partA[ej];
+                        s_new[u] = csA[ej] * Sm[ei][ej] + cpA[ej] * Sm[ei][pj];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) Sm[ei][ej0 + u] = s_new[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (!__any(rotated)) break;
+        }
+    }
+    }
+
 
 __global__ __launch_bounds__(NTG) void svd_gram_part_kernel(const SvdJob *__restrict__ jobs,
                                                             const BEntry *__restrict__ entries, int round,
@@ -558,82 +422,7 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__re
     if (any_flag == 0) return;
     if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
 
-    // ---- local solve: ONE wavefront, 4 matrix elements per lane, no workgroup barriers ---------------
-    // `full` rounds sweep all 120 pairs of the 16 rows (15 local rounds); otherwise only the 64 CROSS pairs
-    // between the two 8-row blocks are rotated (8 local rounds, partner of i<8 is 8 + (i + rr) % 8): pairs
-    // inside a block were orthogonalised when the block last took part in a full round and are only
-    // perturbed at second order since.  The host requests a full round once per sweep for every pair.
-    if (wave == 0) {
-        const int ei = lane >> 2, ej0 = (lane & 3) * 4;
-        const int n_local = full_local ? (TRJ - 1) : BRJ;
-        for (int sweep = 0; sweep < local_sweeps; ++sweep) {
-            bool rotated = false;
-            for (int rr = 0; rr < n_local; ++rr) {
-                if (lane < TRJ) {
-                    const int i = lane;
-                    int pi;
-                    if (full_local) {
-                        if (i == TRJ - 1)
-                            pi = rr;
-                        else if (i == rr)
-                            pi = TRJ - 1;
-                        else
-                            pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1);
-                    } else {
-                        pi = (i < BRJ) ? (BRJ + ((i + rr) & (BRJ - 1))) : (((i - BRJ) - rr) & (BRJ - 1));
-                    }
-                    const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
-                    const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
-                    double c = 1.0, s = 0.0;
-                    if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
-                        const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
-                        const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
-                        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
-                        const double x = fma(t, t, 1.0);
-                        double c0 = __builtin_amdgcn_rsq(x);
-                        c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
-                        c = c0 * fma(-0.5 * x * c0, c0, 1.5);
-                        s = c * t;
-                        rotated = true;
-                    }
-                    partA[i] = pi;
-                    csA[i] = c;
-                    cpA[i] = (i == p) ? -s : s;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                {
-                    const int pi = partA[ei];
-                    const double cs = csA[ei], cp = cpA[ei];
-                    double s_new[4], q_new[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        s_new[u] = cs * Sm[ei][ej0 + u] + cp * Sm[pi][ej0 + u];
-                        q_new[u] = cs * Qm[ei][ej0 + u] + cp * Qm[pi][ej0 + u];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        Sm[ei][ej0 + u] = s_new[u];
-                        Qm[ei][ej0 + u] = q_new[u];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                {
-                    double s_new[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ej = ej0 + u, pj = partA[ej];
-                        s_new[u] = csA[ej] * Sm[ei][ej] + cpA[ej] * Sm[ei][pj];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) Sm[ei][ej0 + u] = s_new[u];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            }
-            if (!__any(rotated)) break;
-        }
-    }
+    if (wave == 0) svd_local_solve(Sm, Qm, csA, cpA, partA, lane, local_sweeps, full_local, tol, floor2);
     __syncthreads();
 
     // ---- apply: X <- Q X on this part's columns of the W rows and of the G rows.  The column chunks of W and of G
@@ -665,6 +454,167 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__re
 #pragma unroll
             for (int tile = 0; tile < CHJ / 16; ++tile) {
                 const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
+                o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
+            }
+#pragma unroll
+        for (int tile = 0; tile < CHJ / 16; ++tile) {
+            const int64_t oc = c * CHJ + tile * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = rowoff[l4 + 4 * r];
+                if (gr >= 0 && oc < len) M[gr * len + oc] = o[tile][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One launch per round: Gram, local solve and application fused.  Each (pair, column part) workgroup loads its
+// column chunks of the 16 W rows (and of the 16 G rows) ONCE into LDS, publishes the partial Gram of its W columns,
+// waits for the partials of the other parts of the same pair (a counter per pair: agent-scope release / acquire,
+// only the <= 8 sibling workgroups of a pair synchronise, never the grid), solves the 16 x 16 problem and applies
+// Q to the LDS-resident chunks.  Compared with the two-kernel round this removes one kernel boundary, one table /
+// row reload and one pass over W.  Requirements (checked by the host, else the two-kernel round is used): every
+// workgroup of the launch is resident at the same time (spin wait!) and a part has at most 4 * FIT chunks.
+// A bounded spin (FUSED_SPIN_MAX polls) turns a lost sibling into an error code instead of a hang.
+constexpr int FIT = 2;                      // chunks per wavefront kept in LDS
+constexpr unsigned FUSED_SPIN_MAX = 4000000u;
+
+__global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__restrict__ jobs,
+                                                              const BEntry *__restrict__ entries, int round,
+                                                              double *__restrict__ W, double *__restrict__ G,
+                                                              double *gpart, unsigned int *pair_cnt, unsigned int seq,
+                                                              unsigned int *__restrict__ n_rot,
+                                                              const double *__restrict__ fro2, double rho,
+                                                              int local_sweeps, int full_local, int *err_flag) {
+    __shared__ double Xs[NTG / 64][FIT][TRJ][CHP];
+    __shared__ double Gs[NTG / 64][TRJ][TRJ + 1];
+    __shared__ double Sm[TRJ][TRJ + 1], Qm[TRJ][TRJ + 1];
+    __shared__ double csA[TRJ], cpA[TRJ];
+    __shared__ int partA[TRJ];
+    __shared__ int any_flag;
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int64_t rowoff[TRJ];
+#pragma unroll
+    for (int t = 0; t < TRJ; ++t) {
+        const int64_t b = (t < BRJ) ? bi : bj;
+        const int64_t r = b * BRJ + (t % BRJ);
+        rowoff[t] = (b < NB && r < R) ? r : -1;
+    }
+    const int64_t nchW = (L + CHJ - 1) / CHJ, nchG = (R + CHJ - 1) / CHJ;
+    const int64_t w_lo = nchW * E.part / E.nparts, w_hi = nchW * (E.part + 1) / E.nparts;
+    const int64_t g_lo = nchG * E.part / E.nparts, g_hi = nchG * (E.part + 1) / E.nparts;
+    const int64_t nW = w_hi - w_lo, nU = nW + (g_hi - g_lo);
+    // ---- load all chunks of this part (both iterations in flight), W chunks also feed the Gram partial
+    double reg[FIT][TRJ];
+#pragma unroll
+    for (int it = 0; it < FIT; ++it) {
+        const int64_t u = wave + (int64_t)it * (NTG / 64);
+        const bool isW = u < nW;
+        const double *M = isW ? (W + J.w_off) : (G + J.g_off);
+        const int64_t len = isW ? L : R;
+        const int64_t c = isW ? (w_lo + u) : (g_lo + (u - nW));
+        const int64_t col = c * CHJ + lane;
+#pragma unroll
+        for (int t = 0; t < TRJ; ++t) reg[it][t] = (u < nU && rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
+    }
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < FIT; ++it) {
+        const int64_t u = wave + (int64_t)it * (NTG / 64);
+#pragma unroll
+        for (int t = 0; t < TRJ; ++t) Xs[wave][it][t][lane] = reg[it][t];
+        if (u < nW) {   // wave-uniform
+#pragma unroll
+            for (int ks = 0; ks < CHJ / 4; ks += 2) {
+                const double a0 = Xs[wave][it][l15][ks * 4 + l4];
+                const double a1 = Xs[wave][it][l15][ks * 4 + 4 + l4];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Gs[wave][l4 + 4 * r][l15] = acc0[r] + acc1[r];
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x - E.part;
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double sacc = 0;
+#pragma unroll
+        for (int w = 0; w < NTG / 64; ++w) sacc += Gs[w][i][j];
+        // write-through store (agent scope -> sc1): the partial is not left dirty in this XCD's L2, so no cache
+        // write-back fence is needed before the flag (a __threadfence() here cost ~45 us per round with ~400
+        // workgroups fencing at once)
+        __hip_atomic_store(&gpart[(int64_t)blockIdx.x * 256 + tid], sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- publish the partial, wait for the siblings of this pair
+    if (E.nparts > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my store has reached the coherent level
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&pair_cnt[first], 1u);
+            const unsigned int target = (unsigned int)E.nparts * seq;
+            unsigned int spins = 0;
+            while (__hip_atomic_load(&pair_cnt[first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > FUSED_SPIN_MAX) {
+                    atomicExch(err_flag, 1);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- full Gram = sum of the partials in a fixed order (identical in every part)
+    {
+        double sacc = 0;
+        for (int p = 0; p < E.nparts; ++p)     // coherent (sc1) loads: never served from a stale L1 / foreign-L2 line
+            sacc += __hip_atomic_load(&gpart[(first + p) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Sm[tid >> 4][tid & 15] = sacc;
+        Qm[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[E.job];
+    {
+        const int ei = tid >> 4, ej = tid & 15;
+        const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
+        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2)) any_flag = 1;
+    }
+    __syncthreads();
+    if (any_flag == 0) return;
+    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
+    if (wave == 0) svd_local_solve(Sm, Qm, csA, cpA, partA, lane, local_sweeps, full_local, tol, floor2);
+    __syncthreads();
+    // ---- apply Q to the LDS-resident chunks
+    double qa[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qa[kk] = Qm[l15][kk * 4 + l4];
+#pragma unroll
+    for (int it = 0; it < FIT; ++it) {
+        const int64_t u = wave + (int64_t)it * (NTG / 64);
+        if (u >= nU) continue;
+        const bool isW = u < nW;
+        double *M = isW ? (W + J.w_off) : (G + J.g_off);
+        const int64_t len = isW ? L : R;
+        const int64_t c = isW ? (w_lo + u) : (g_lo + (u - nW));
+        d4 o[CHJ / 16];
+#pragma unroll
+        for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int tile = 0; tile < CHJ / 16; ++tile) {
+                const double bb = Xs[wave][it][kk * 4 + l4][tile * 16 + l15];
                 o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
             }
 #pragma unroll
@@ -939,255 +889,6 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__
                 for (int r = 0; r < 4; ++r) {
                     const int64_t gr = rowoff[l4 + 4 * r];
                     if (gr >= 0 && oc < len) M[gr * len + oc] = double2{orr[r], oii[r]};
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// "Wide" real block-Jacobi round: blocks of 16 rows, 32 rows per pair.  Half as many rounds (launches) per
-// sweep as the 8-row version; the 32 x 32 local problem is still solved by one wavefront (16 elements per
-// lane), and the streaming phases are spread over column parts, so a round costs about the same.
-constexpr int BRW = 16;
-constexpr int TRW = 32;
-constexpr int CHW = 32;           // columns per staged chunk
-constexpr int CHWP = CHW + 1;
-
-__device__ __forceinline__ void block_pair_of_w(const SvdJob &J, int pair, int round, int64_t &bi, int64_t &bj,
-                                                int64_t &NB) {
-    NB = (J.R + BRW - 1) / BRW;
-    const int64_t NBp = (NB + 1) / 2 * 2;
-    const int64_t mod = NBp - 1;
-    const int64_t r = (mod > 0) ? (round % mod) : 0;
-    if (pair == 0) {
-        bi = NBp - 1;
-        bj = r;
-    } else {
-        bi = (r + pair) % mod;
-        bj = (r - pair + mod) % mod;
-    }
-    if (bi > bj) {
-        const int64_t t = bi;
-        bi = bj;
-        bj = t;
-    }
-}
-
-__global__ __launch_bounds__(NTG) void svd_gram_part_kernel_w(const SvdJob *__restrict__ jobs,
-                                                              const BEntry *__restrict__ entries, int round,
-                                                              const double *__restrict__ W,
-                                                              double *__restrict__ gpart) {
-    __shared__ double Xs[NTG / 64][TRW][CHWP];
-    const BEntry E = entries[blockIdx.x];
-    if (E.job < 0) return;
-    const SvdJob J = jobs[E.job];
-    int64_t bi, bj, NB;
-    block_pair_of_w(J, E.pair, round, bi, bj, NB);
-    const int64_t R = J.R, L = J.L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int64_t nchunk = (L + CHW - 1) / CHW;
-    const int64_t c_lo = nchunk * E.part / E.nparts, c_hi = nchunk * (E.part + 1) / E.nparts;
-    d4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0, 0, 0, 0};
-    const double *Wb = W + J.w_off;
-    // this lane's row for load instruction t (t = 0..15): local row 2t + half
-    for (int64_t c = c_lo + wave; c < c_hi; c += NTG / 64) {
-        const int64_t col = c * CHW + l31;
-#pragma unroll
-        for (int t = 0; t < TRW / 2; ++t) {
-            const int lr = 2 * t + half;
-            const int64_t b = (lr < BRW) ? bi : bj;
-            const int64_t r = b * BRW + (lr & (BRW - 1));
-            Xs[wave][lr][l31] = (b < NB && r < R && col < L) ? Wb[r * L + col] : 0.0;
-        }
-#pragma unroll
-        for (int ks = 0; ks < CHW / 4; ++ks) {
-            const double f0 = Xs[wave][l15][ks * 4 + l4], f1 = Xs[wave][16 + l15][ks * 4 + l4];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, acc[1][1], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    // partial 32 x 32 of this wave -> Xs[wave][row][col]  (row = a*16 + l4 + 4r, col = b*16 + l15)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Xs[wave][a * 16 + l4 + 4 * r][b * 16 + l15] = acc[a][b][r];
-    __syncthreads();
-    for (int e = tid; e < TRW * TRW; e += NTG) {
-        const int i = e >> 5, j = e & 31;
-        double sacc = 0;
-#pragma unroll
-        for (int w = 0; w < NTG / 64; ++w) sacc += Xs[w][i][j];
-        gpart[(int64_t)blockIdx.x * 1024 + e] = sacc;
-    }
-}
-
-__global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_w(const SvdJob *__restrict__ jobs,
-                                                                const BEntry *__restrict__ entries, int round,
-                                                                double *__restrict__ W, double *__restrict__ G,
-                                                                const double *__restrict__ gpart,
-                                                                unsigned int *__restrict__ n_rot,
-                                                                const double *__restrict__ fro2, double rho,
-                                                                int local_sweeps, int full_local) {
-    __shared__ double Xs[NTG / 64][TRW][CHWP];
-    __shared__ double Sm[TRW][TRW + 1], Qm[TRW][TRW + 1];
-    __shared__ double csA[TRW], cpA[TRW];
-    __shared__ int partA[TRW];
-    __shared__ int any_flag;
-    const BEntry E = entries[blockIdx.x];
-    if (E.job < 0) return;
-    const SvdJob J = jobs[E.job];
-    int64_t bi, bj, NB;
-    block_pair_of_w(J, E.pair, round, bi, bj, NB);
-    const int64_t R = J.R, L = J.L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int half = lane >> 5, l31 = lane & 31;
-    {
-        const int64_t first = (int64_t)blockIdx.x - E.part;
-        for (int e = tid; e < TRW * TRW; e += NTG) {
-            double sacc = 0;
-            for (int p = 0; p < E.nparts; ++p) sacc += gpart[(first + p) * 1024 + e];
-            Sm[e >> 5][e & 31] = sacc;
-            Qm[e >> 5][e & 31] = ((e >> 5) == (e & 31)) ? 1.0 : 0.0;
-        }
-    }
-    if (tid == 0) any_flag = 0;
-    __syncthreads();
-    const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[E.job];
-    for (int e = tid; e < TRW * TRW; e += NTG) {
-        const int ei = e >> 5, ej = e & 31;
-        const bool relevant = full_local ? (ei < ej) : (ei < BRW && ej >= BRW);
-        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2)) any_flag = 1;
-    }
-    __syncthreads();
-    if (any_flag == 0) return;
-    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
-
-    if (wave == 0) {
-        const int ei = lane >> 1, ej0 = (lane & 1) * 16;   // 2 lanes per row, 16 elements per lane
-        const int n_local = full_local ? (TRW - 1) : BRW;
-        for (int sweep = 0; sweep < local_sweeps; ++sweep) {
-            bool rotated = false;
-            for (int rr = 0; rr < n_local; ++rr) {
-                if (lane < TRW) {
-                    const int i = lane;
-                    int pi;
-                    if (full_local) {
-                        if (i == TRW - 1)
-                            pi = rr;
-                        else if (i == rr)
-                            pi = TRW - 1;
-                        else
-                            pi = (2 * rr - i + 2 * (TRW - 1)) % (TRW - 1);
-                    } else {
-                        pi = (i < BRW) ? (BRW + ((i + rr) & (BRW - 1))) : (((i - BRW) - rr) & (BRW - 1));
-                    }
-                    const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
-                    const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
-                    double c = 1.0, s = 0.0;
-                    if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
-                        const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
-                        const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
-                        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
-                        const double x = fma(t, t, 1.0);
-                        double c0 = __builtin_amdgcn_rsq(x);
-                        c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
-                        c = c0 * fma(-0.5 * x * c0, c0, 1.5);
-                        s = c * t;
-                        rotated = true;
-                    }
-                    partA[i] = pi;
-                    csA[i] = c;
-                    cpA[i] = (i == p) ? -s : s;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                {
-                    const int pi = partA[ei];
-                    const double cs = csA[ei], cp = cpA[ei];
-                    double s_new[16], q_new[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        s_new[u] = cs * Sm[ei][ej0 + u] + cp * Sm[pi][ej0 + u];
-                        q_new[u] = cs * Qm[ei][ej0 + u] + cp * Qm[pi][ej0 + u];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        Sm[ei][ej0 + u] = s_new[u];
-                        Qm[ei][ej0 + u] = q_new[u];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                {
-                    double s_new[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int ej = ej0 + u, pj = partA[ej];
-                        s_new[u] = csA[ej] * Sm[ei][ej] + cpA[ej] * Sm[ei][pj];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) Sm[ei][ej0 + u] = s_new[u];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            }
-            if (!__any(rotated)) break;
-        }
-    }
-    __syncthreads();
-
-    // ---- apply: X <- Q X, Q is 32 x 32: two output row tiles, K = 32 (8 MFMA k-steps)
-    double qa[2][8];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qa[a][kk] = Qm[a * 16 + l15][kk * 4 + l4];
-    for (int pass = 0; pass < 2; ++pass) {
-        double *M = (pass == 0) ? (W + J.w_off) : (G + J.g_off);
-        const int64_t len = (pass == 0) ? L : R;
-        const int64_t nch = (len + CHW - 1) / CHW;
-        const int64_t c_lo = nch * E.part / E.nparts, c_hi = nch * (E.part + 1) / E.nparts;
-        for (int64_t c = c_lo + wave; c < c_hi; c += NTG / 64) {
-            const int64_t col = c * CHW + l31;
-#pragma unroll
-            for (int t = 0; t < TRW / 2; ++t) {
-                const int lr = 2 * t + half;
-                const int64_t b = (lr < BRW) ? bi : bj;
-                const int64_t r = b * BRW + (lr & (BRW - 1));
-                Xs[wave][lr][l31] = (b < NB && r < R && col < len) ? M[r * len + col] : 0.0;
-            }
-#pragma unroll
-            for (int tile = 0; tile < CHW / 16; ++tile) {
-                d4 o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const double bb = Xs[wave][kk * 4 + l4][tile * 16 + l15];
-                    o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0][kk], bb, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[1][kk], bb, o1, 0, 0, 0);
-                }
-                const int64_t oc = c * CHW + tile * 16 + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const int lr = a * 16 + l4 + 4 * r;
-                        const int64_t b = (lr < BRW) ? bi : bj;
-                        const int64_t gr = b * BRW + (lr & (BRW - 1));
-                        if (b < NB && gr < R && oc < len) M[gr * len + oc] = (a == 0) ? o0[r] : o1[r];
-                    }
                 }
             }
         }
@@ -1842,26 +1543,23 @@ __global__ __launch_bounds__(NT) void qrp_output_kernel(const QrpJob *__restrict
 
 int tpa_svd_use_qrp = 1;   // real data: rank-revealing pivoted QR before the Jacobi iteration
 
+int tpa_svd_fused_round = 1;   // real data: one launch per Jacobi round (sibling workgroups synchronise through a counter)
 int tpa_svd_local_sweeps = 1;
 int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block pairs
-int tpa_svd_wide = 0;   // 16-row blocks (32 x 32 local problems): half the rounds, but measured 1.2-1.5x SLOWER (one-wavefront
                         // 32 x 32 solve dominates); kept as a tuning option, off by default
-int tpa_svd_split = 1;  // 1: gram / solve+apply kernels over column parts, 0: one fused workgroup per block pair
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
 
 struct Layout {
     std::vector<SvdJob> jobs;
     std::vector<int2> rows;   // (job,row) per wavefront, padded to multiple of 4 with (-1,-1)
     std::vector<int2> pairs;  // (job,pair)
-    std::vector<int2> bpairs; // (job, block pair) for the block-Jacobi rounds
     std::vector<BEntry> bentries;  // (job, pair, part, nparts) for the split rounds
-    std::vector<BEntry> wentries;  // same for the wide (16-row block) rounds
-    int64_t nbw_max_pad = 0;
     int64_t nb_max_pad = 0;
+    int64_t max_part_chunks = 0;   // largest number of (W + G) column chunks of one part (fused round: <= 4 * FIT)
     int64_t w_elems = 0, g_elems = 0, sig_elems = 0, rmax_pad = 0;
     // byte offsets inside work buffer
     int64_t off_w = 0, off_g = 0, off_sig = 0, off_perm = 0, off_jobs = 0, off_rows = 0, off_pairs = 0,
-            off_bpairs = 0, off_bent = 0, off_went = 0, off_gpart = 0, off_cnt = 0, off_fro = 0, off_fpart = 0, total = 0;
+            off_bent = 0, off_pcnt = 0, off_gpart = 0, off_cnt = 0, off_fro = 0, off_fpart = 0, total = 0;
 };
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -1893,21 +1591,33 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         for (int64_t p = 0; p < J.Rpad / 2; ++p) lay.pairs.push_back(int2{b, (int)p});
         {
             const int64_t NB = (J.R + 7) / 8, NBp = (NB + 1) / 2 * 2;
-            for (int64_t p = 0; p < NBp / 2; ++p) lay.bpairs.push_back(int2{b, (int)p});
             // column parts: >= 4 chunks of 64 columns each, at most 8 parts
             const int64_t nchunk = (J.L + 63) / 64;   // (complex kernels use 32-column chunks: twice as many)
             // real kernels: W and G chunks of a part are dealt out to 4 wavefronts together -> aim at <= 4 per part
             const int64_t nch_all = nchunk + (J.R + 63) / 64;
             int nparts = (dtype == TPA_C128) ? (int)std::min<int64_t>(8, std::max<int64_t>(1, nchunk / 4))
-                                             : (int)std::min<int64_t>(8, std::max<int64_t>(1, nch_all / 6));
+                                             : (int)std::min<int64_t>(8, std::max<int64_t>(1, (nch_all + 7) / 8));
+            if (dtype != TPA_C128) {   // every part must fit the LDS-resident budget of the fused round (4 * FIT chunks)
+                const int64_t nchG0 = (J.R + 63) / 64;
+                auto worst = [&](int np) {
+                    int64_t w = 0;
+                    for (int q = 0; q < np; ++q)
+                        w = std::max(w, (nchunk * (q + 1) / np - nchunk * q / np) + (nchG0 * (q + 1) / np - nchG0 * q / np));
+                    return w;
+                };
+                while (nparts < 8 && worst(nparts) > 8) ++nparts;
+            }
             for (int64_t p = 0; p < NBp / 2; ++p)
                 for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
+            if (dtype != TPA_C128 && NBp >= 2) {
+                const int64_t nchG = (J.R + 63) / 64;
+                for (int q = 0; q < nparts; ++q) {
+                    const int64_t nw = nchunk * (q + 1) / nparts - nchunk * q / nparts;
+                    const int64_t ng = nchG * (q + 1) / nparts - nchG * q / nparts;
+                    lay.max_part_chunks = std::max(lay.max_part_chunks, nw + ng);
+                }
+            }
             lay.nb_max_pad = std::max(lay.nb_max_pad, NBp);
-            const int64_t NBw = (J.R + 15) / 16, NBwp = (NBw + 1) / 2 * 2;
-            const int wparts = (int)std::min<int64_t>(16, std::max<int64_t>(1, (J.L + 31) / 32 / 6));
-            for (int64_t p = 0; p < NBwp / 2; ++p)
-                for (int q = 0; q < wparts; ++q) lay.wentries.push_back(BEntry{b, (int)p, q, wparts});
-            lay.nbw_max_pad = std::max(lay.nbw_max_pad, NBwp);
         }
         lay.jobs.push_back(J);
     }
@@ -1928,14 +1638,12 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.rows.size() * sizeof(int2), 256);
     lay.off_pairs = o;
     o = align_up(o + (int64_t)lay.pairs.size() * sizeof(int2), 256);
-    lay.off_bpairs = o;
-    o = align_up(o + (int64_t)lay.bpairs.size() * sizeof(int2), 256);
     lay.off_bent = o;
     o = align_up(o + (int64_t)lay.bentries.size() * sizeof(BEntry), 256);
-    lay.off_went = o;
-    o = align_up(o + (int64_t)lay.wentries.size() * sizeof(BEntry), 256);
+    lay.off_pcnt = o;
+    o = align_up(o + (int64_t)lay.bentries.size() * 4 + 64, 256);   // per-entry pair counters + error flag
     lay.off_gpart = o;
-    o = align_up(o + (int64_t)std::max(lay.bentries.size() * 512, lay.wentries.size() * 1024) * 8, 256);
+    o = align_up(o + (int64_t)lay.bentries.size() * 512 * 8, 256);   // 256 (real) / 512 (complex: re + im) doubles per entry
     lay.off_cnt = o;
     o = align_up(o + 256, 256);
     lay.off_fro = o;
@@ -1944,6 +1652,21 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.jobs.size() * 64 * 8, 256);
     lay.total = o;
     return lay;
+}
+
+// number of svd_round_fused_kernel workgroups that are guaranteed to be resident together (occupancy query x CUs)
+int64_t fused_round_capacity() {
+    static int64_t cap = -1;
+    if (cap < 0) {
+        int per_cu = 0, dev_id = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev_id) != hipSuccess || hipGetDeviceProperties(&prop, dev_id) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, svd_round_fused_kernel, NTG, 0) != hipSuccess)
+            cap = 0;
+        else
+            cap = (int64_t)per_cu * prop.multiProcessorCount;
+    }
+    return cap;
 }
 
 template <bool CPLX>
@@ -1960,13 +1683,9 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     TPA_HIP_CHECK(hipMemcpyAsync(jobs, lay.jobs.data(), lay.jobs.size() * sizeof(SvdJob), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(rows, lay.rows.data(), lay.rows.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(pairs, lay.pairs.data(), lay.pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-    int2 *bpairs = (int2 *)(work + lay.off_bpairs);
     BEntry *bent = (BEntry *)(work + lay.off_bent);
     double *gpart = (double *)(work + lay.off_gpart);
-    BEntry *went = (BEntry *)(work + lay.off_went);
-    TPA_HIP_CHECK(hipMemcpyAsync(went, lay.wentries.data(), lay.wentries.size() * sizeof(BEntry), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(bent, lay.bentries.data(), lay.bentries.size() * sizeof(BEntry), hipMemcpyHostToDevice, st));
-    TPA_HIP_CHECK(hipMemcpyAsync(bpairs, lay.bpairs.data(), lay.bpairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     // pageable host memory: the copies above are staged before returning, vectors may die later.
     const int g_rows = (int)(lay.rows.size() / (NT / 64));
     const int g_pairs = (int)(lay.pairs.size() / (NT / 64));
@@ -1983,31 +1702,43 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     TPA_LAUNCH_CHECK();
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
-    const bool use_block = !tpa_svd_force_pairwise && (!CPLX || tpa_svd_split);
-    const bool use_wide = use_block && tpa_svd_split && !CPLX && tpa_svd_wide;
-    const int rounds = use_wide ? (int)std::max<int64_t>(lay.nbw_max_pad - 1, 1) : use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1)
-                                 : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
+    const bool use_block = !tpa_svd_force_pairwise;
+    // fused one-launch round: spin-waits between sibling workgroups need the whole grid resident (<= 2 workgroups of
+    // 70 KB LDS per CU) and every part must fit the LDS-resident chunk budget
+    const bool use_fused = use_block && !CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FIT &&
+                           (int64_t)lay.bentries.size() <= fused_round_capacity();
+    unsigned int *pcnt = (unsigned int *)(work + lay.off_pcnt);
+    int *perr = (int *)(pcnt + lay.bentries.size());
+    unsigned int fused_seq = 0;
+    if (use_fused) TPA_HIP_CHECK(hipMemsetAsync(pcnt, 0, lay.bentries.size() * 4 + 4, st));
+    const int rounds = use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1) : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
-            if (use_wide) {
-                svd_gram_part_kernel_w<<<(int)lay.wentries.size(), NTG, 0, st>>>(jobs, went, r, W, gpart);
-                svd_solve_apply_kernel_w<<<(int)lay.wentries.size(), NTG, 0, st>>>(jobs, went, r, W, G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
-            } else if (use_block && tpa_svd_split && CPLX) {
+            const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
+            if (use_block && CPLX) {
                 svd_gram_part_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (const double2 *)W, gpart);
-                svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
-            } else if (use_block && tpa_svd_split) {
+                svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
+            } else if (use_fused) {
+                ++fused_seq;
+                svd_round_fused_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, G, gpart, pcnt, fused_seq, cnt, fro2, rho,
+                                                                                tpa_svd_local_sweeps, full_local, perr);
+            } else if (use_block) {
                 svd_gram_part_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, gpart);
-                svd_solve_apply_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, (tpa_svd_cross_only && r > 0) ? 0 : 1);
-            } else if (use_block)
-                svd_block_round_kernel<<<(int)lay.bpairs.size(), NTB, 0, st>>>(jobs, bpairs, r, W, G, cnt, fro2, rho, tpa_svd_local_sweeps);
-            else
+                svd_solve_apply_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
+            } else
                 svd_round_kernel<CPLX><<<g_pairs, NT, 0, st>>>(jobs, pairs, r, W, G, cnt, fro2, rho);
         }
         TPA_LAUNCH_CHECK();
         unsigned int h = 0;
+        int herr = 0;
         TPA_HIP_CHECK(hipMemcpyAsync(&h, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        if (use_fused) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
         TPA_HIP_CHECK(hipStreamSynchronize(st));
+        if (herr) {
+            snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: sibling workgroups of a fused Jacobi round lost each other (spin limit)");
+            return TPA_E_NOCONV;
+        }
         ++sweep;
         converged = (h == 0);
     }
@@ -2392,10 +2123,9 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
 
 extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_force_pairwise = (pairwise & 1) ? 1 : 0;
-    tpa_svd_split = (pairwise & 2) ? 0 : 1;
     tpa_svd_cross_only = (pairwise & 4) ? 0 : 1;
-    tpa_svd_wide = (pairwise & 8) ? 1 : 0;         // bit 3: 16-row blocks   // bit 2: full 16x16 local sweep in every round   // bit 1: fused single-workgroup block kernel
     tpa_svd_use_qrp = (pairwise & 512) ? 0 : 1;    // bit 9: no pivoted-QR preconditioner
+    tpa_svd_fused_round = (pairwise & 2) ? 0 : 1;  // bit 1: two-kernel rounds (gram, then solve + apply)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
 }
