@@ -132,7 +132,7 @@ int tpa_gemm_set_variant(int v);
  *   U_b (m x k, row-major, k=min(m,n)) at u_off in u_base, S_b (k, descending) at s_off in s_dev
  *   (always real), VH_b (k x n, row-major) at vh_off in vh_base.  A is NOT overwritten.
  * work_dev: >= tpa_svd_worksize(...) bytes.  Synchronises the stream (sweep-convergence test).
- * Real data, min(m,n) >= 32: the blocks are first reduced by a rank-revealing Householder QR with column
+ * min(m,n) >= 32 (complex: and max(m,n) <= 2048): the blocks are first reduced by a rank-revealing Householder QR with column
  *   pivoting (X P = Q [R;0], X = A or A^T); the Jacobi iteration then runs on the r x min(m,n) factor only
  *   (r = numerical rank: residual column norms <= 1e-15 ||A||_F).  Singular values below that threshold are
  *   returned as exact zeros with zero singular vectors (LAPACK returns rounding noise there).
@@ -144,7 +144,8 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
                   int max_sweeps, double tol, int *sweeps_done, void *stream);
 
 /* Algorithm switch (test / benchmark hook): 0 (default) = pivoted-QR preconditioner + block Jacobi (16-row MFMA
- * Gram + in-LDS eigen-solve); bit 0 = one wavefront per row pair; bit 9 (512) = no pivoted-QR preconditioner. */
+ * Gram + in-LDS eigen-solve); bit 0 = one wavefront per row pair; bit 1 = two-kernel Jacobi rounds instead of the fused one; bit 2 = full local
+ * sweep in every round; bits 4-7 = local sweeps; bit 9 (512) = no pivoted-QR preconditioner. */
 int tpa_svd_set_algorithm(int pairwise);
 
 /* ---- K6: batched Householder QR (np.linalg.qr per block, np_conserved.py:4190) ----------

@@ -1541,6 +1541,559 @@ __global__ __launch_bounds__(NT) void qrp_output_kernel(const QrpJob *__restrict
     }
 }
 
+// ===================================================================================================
+// Complex version of the rank-revealing preconditioner (same structure; interleaved double2 storage).
+//   X = A (m >= n) or A^H (m < n), column-major;   X P = Q [R; 0],   H = I - tau v v^H (LAPACK zlarfg: beta real),
+//   the factorisation applies H^H from the left, blocks H_0 .. H_{l-1} = I - V T V^H (zlarft, forward / columnwise).
+//   A = X:    U = Q_r U_R,          VH[jj][cperm[c]] = VH_R[jj][c]
+//   A = X^H:  U[cperm[c]][jj] = conj(VH_R[jj][c]),   VH[jj][c] = conj((Q_r U_R)[c][jj])
+// Complex products on the matrix cores are 4 real MFMAs on the (re, im) planes of the fragments.
+typedef double2 cd;
+__device__ __forceinline__ cd c_mul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cd c_mulc(cd a, cd b) { return cd{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x}; }   // conj(a) * b
+__device__ __forceinline__ cd c_fma(cd a, cd b, cd acc) { return cd{acc.x + a.x * b.x - a.y * b.y, acc.y + a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cd c_fmac(cd a, cd b, cd acc) { return cd{acc.x + a.x * b.x + a.y * b.y, acc.y + a.x * b.y - a.y * b.x}; }  // acc + conj(a) b
+
+__global__ __launch_bounds__(NT) void qrp_init_kernel_c(const QrpJob *__restrict__ jobs, const SvdJob *__restrict__ sj,
+                                                        const cd *__restrict__ A, cd *__restrict__ X,
+                                                        double *__restrict__ cn, int64_t *__restrict__ cperm,
+                                                        QrpState *__restrict__ state) {
+    // grid (column tiles of 64, jobs); wave w owns the columns j0 + 16 w .. +15, lanes run along the rows
+    __shared__ double tr_[64][65], ti_[64][65];
+    const QrpJob J = jobs[blockIdx.y];
+    const SvdJob S = sj[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    if (j0 >= J.N) return;
+    double acc[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.0;
+    for (int64_t i0 = 0; i0 < J.M; i0 += 64) {
+        if (!J.tr) {
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int64_t i = i0 + wave * 16 + rr, j = j0 + lane;
+                const cd v = (i < J.M && j < J.N) ? A[S.a_off + i * S.n + j] : cd{0.0, 0.0};
+                tr_[wave * 16 + rr][lane] = v.x;
+                ti_[wave * 16 + rr][lane] = v.y;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int64_t j = j0 + wave * 16 + rr, i = i0 + lane;
+            if (j < J.N && i < J.M) {
+                cd v;
+                if (J.tr) {          // X = A^H:  X[i][j] = conj(A[j][i])
+                    v = A[S.a_off + j * S.n + i];
+                    v.y = -v.y;
+                } else
+                    v = cd{tr_[lane][wave * 16 + rr], ti_[lane][wave * 16 + rr]};
+                X[J.x_off + j * J.M + i] = v;
+                acc[rr] = fma(v.x, v.x, fma(v.y, v.y, acc[rr]));
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const double t = wave_sum(acc[rr]);
+        const int64_t j = j0 + wave * 16 + rr;
+        if (lane == 0 && j < J.N) {
+            cn[J.c_off + j] = t;
+            cperm[J.c_off + j] = j;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[blockIdx.y] = QrpState{0, 0, 0, 0};
+}
+
+constexpr int KC = 2 * PNB + 1;   // real values reduced together in the complex panel kernel
+
+template <int NTP, int K>
+__device__ __forceinline__ void block_sum_arr(double (&v)[K], double (*red)[KC]) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) red[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NTP / 64; ++w) t += red[w][q];
+        v[q] = t;
+    }
+}
+
+template <int NTP, int RPT>
+__global__ __launch_bounds__(NTP) void qrp_panel_kernel_c(const QrpJob *__restrict__ jobs, int k, cd *__restrict__ X,
+                                                          cd *__restrict__ Vall, double *__restrict__ cn,
+                                                          cd *__restrict__ tau, int64_t *__restrict__ cperm,
+                                                          QrpState *__restrict__ state, const double *__restrict__ fro2,
+                                                          double tol2, cd *__restrict__ Tpan) {
+    __shared__ double rv[NTP / 64];
+    __shared__ int64_t ri[NTP / 64];
+    __shared__ double red[NTP / 64][KC];
+    __shared__ int64_t s_p[PNB];
+    __shared__ int s_nbk;
+    __shared__ cd s_alpha, s_vrow[PNB], Tf[PNB][PNB];
+    const int b = blockIdx.x;
+    const QrpJob J = jobs[b];
+    const QrpState st0 = state[b];
+    if (st0.done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t M = J.M, N = J.N;
+    if (st0.last || k >= N) {
+        if (tid == 0) state[b] = QrpState{st0.last ? st0.rank : (int)N, 1, 0, 0};
+        return;
+    }
+    double cand[RPT];
+#pragma unroll
+    for (int t = 0; t < RPT; ++t) {
+        const int64_t j = tid + (int64_t)t * NTP;
+        cand[t] = (j < N) ? cn[J.c_off + j] : -4.0;
+    }
+    const double thresh = tol2 * fro2[b];
+    if (tid == 0) s_nbk = 0;
+    for (int l = 0; l < PNB; ++l) {
+        double bv = -3.0;
+        int64_t bidx = N;
+#pragma unroll
+        for (int t = 0; t < RPT; ++t)
+            if (cand[t] > bv) {
+                bv = cand[t];
+                bidx = tid + (int64_t)t * NTP;
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int64_t oi = __shfl_xor(bidx, off, 64);
+            if (ov > bv || (ov == bv && oi < bidx)) {
+                bv = ov;
+                bidx = oi;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            rv[wave] = bv;
+            ri[wave] = bidx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double v0 = rv[0];
+            int64_t i0 = ri[0];
+            for (int w = 1; w < NTP / 64; ++w)
+                if (rv[w] > v0 || (rv[w] == v0 && ri[w] < i0)) {
+                    v0 = rv[w];
+                    i0 = ri[w];
+                }
+            if (v0 > thresh && s_nbk == l) {
+                s_p[l] = i0;
+                s_nbk = l + 1;
+            }
+        }
+        __syncthreads();
+        if (s_nbk <= l) break;
+        const int64_t w = s_p[l];
+#pragma unroll
+        for (int t = 0; t < RPT; ++t)
+            if (tid + (int64_t)t * NTP == w) cand[t] = -4.0;
+    }
+    const int nbk = s_nbk;
+    if (nbk == 0) {
+        if (tid == 0) state[b] = QrpState{k, 1, 0, 0};
+        return;
+    }
+    if (tid == 0) {
+        const bool last = (nbk < PNB);
+        state[b] = QrpState{last ? k + nbk : 0, 0, nbk, last ? 1 : 0};
+        for (int x = 0; x < PNB; ++x)
+            for (int y = 0; y < PNB; ++y) Tf[x][y] = cd{0.0, 0.0};
+    }
+    if (tid < nbk) {
+        cperm[J.c_off + k + tid] = s_p[tid];
+        cn[J.c_off + s_p[tid]] = -1.0;
+    }
+    __syncthreads();
+    cd *Xb = X + J.x_off;
+    cd c[PNB][RPT];
+#pragma unroll
+    for (int t = 0; t < RPT; ++t) {
+        const int64_t i = tid + (int64_t)t * NTP;
+#pragma unroll
+        for (int l = 0; l < PNB; ++l) c[l][t] = (i < M && l < nbk) ? Xb[s_p[l] * M + i] : cd{0.0, 0.0};
+    }
+#pragma clang loop unroll(full)
+    for (int l = 0; l < PNB; ++l) {
+        if (l < nbk) {
+            const int64_t kl = (int64_t)k + l;
+            if (l > 0) {
+                // c_l <- (I - V T^H V^H) c_l :  y = V^H c_l,  z = T^H y,  c_l -= V z
+                double y[2 * PNB];
+#pragma unroll
+                for (int m = 0; m < PNB; ++m) {
+                    cd a{0.0, 0.0};
+                    if (m < l) {
+#pragma unroll
+                        for (int t = 0; t < RPT; ++t) a = c_fmac(c[m][t], c[l][t], a);
+                    }
+                    y[2 * m] = a.x;
+                    y[2 * m + 1] = a.y;
+                }
+                block_sum_arr<NTP, 2 * PNB>(y, red);
+                cd z[PNB];
+#pragma unroll
+                for (int m = 0; m < PNB; ++m) {
+                    z[m] = cd{0.0, 0.0};
+                    if (m < l) {
+#pragma unroll
+                        for (int mm = 0; mm < PNB; ++mm)
+                            if (mm <= m) z[m] = c_fmac(Tf[mm][m], cd{y[2 * mm], y[2 * mm + 1]}, z[m]);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < PNB; ++m)
+                    if (m < l) {
+                        const cd zn{-z[m].x, -z[m].y};
+#pragma unroll
+                        for (int t = 0; t < RPT; ++t) c[l][t] = c_fma(c[m][t], zn, c[l][t]);
+                    }
+            }
+            double g[KC];
+#pragma unroll
+            for (int q = 0; q < KC; ++q) g[q] = 0.0;
+#pragma unroll
+            for (int t = 0; t < RPT; ++t) {
+                const int64_t i = tid + (int64_t)t * NTP;
+                if (i > kl && i < M) {
+                    g[2 * PNB] = fma(c[l][t].x, c[l][t].x, fma(c[l][t].y, c[l][t].y, g[2 * PNB]));
+#pragma unroll
+                    for (int m = 0; m < PNB; ++m)
+                        if (m < l) {
+                            const cd a = c_mulc(c[m][t], c[l][t]);
+                            g[2 * m] += a.x;
+                            g[2 * m + 1] += a.y;
+                        }
+                } else if (i == kl) {
+                    s_alpha = c[l][t];
+#pragma unroll
+                    for (int m = 0; m < PNB; ++m)
+                        if (m < l) s_vrow[m] = c[m][t];
+                }
+            }
+            block_sum_arr<NTP, KC>(g, red);
+            const double s2 = g[2 * PNB];
+            const cd alpha = s_alpha;
+            double beta = alpha.x;
+            cd tk{0.0, 0.0}, scale{0.0, 0.0};
+            if (s2 > 0.0 || alpha.y != 0.0) {       // zlarfg
+                beta = -copysign(sqrt(alpha.x * alpha.x + alpha.y * alpha.y + s2), alpha.x);
+                tk = cd{(beta - alpha.x) / beta, -alpha.y / beta};
+                const double dr = alpha.x - beta, di = alpha.y, dn = dr * dr + di * di;
+                scale = cd{dr / dn, -di / dn};      // 1 / (alpha - beta)
+            }
+            // column l of T:  T[i2][l] = -tau sum_{m=i2}^{l-1} T[i2][m] (v_m^H v_l),  v_m^H v_l = g_m scale + conj(v_m[kl])
+            if (tid < l) {
+                cd acc{0.0, 0.0};
+#pragma unroll
+                for (int m = 0; m < PNB; ++m)
+                    if (m >= tid && m < l) {
+                        cd sml = c_mul(cd{g[2 * m], g[2 * m + 1]}, scale);
+                        sml.x += s_vrow[m].x;
+                        sml.y -= s_vrow[m].y;
+                        acc = c_fma(Tf[tid][m], sml, acc);
+                    }
+                const cd r = c_mul(tk, acc);
+                Tf[tid][l] = cd{-r.x, -r.y};
+            } else if (tid == l) {
+                Tf[l][l] = tk;
+                tau[J.c_off + kl] = tk;
+            }
+            cd *vk = Vall + J.x_off + kl * M;
+            cd *xc = Xb + s_p[l] * M;
+#pragma unroll
+            for (int t = 0; t < RPT; ++t) {
+                const int64_t i = tid + (int64_t)t * NTP;
+                if (i < M) {
+                    cd v;
+                    if (i < kl) {
+                        v = cd{0.0, 0.0};
+                        xc[i] = c[l][t];
+                    } else if (i == kl) {
+                        xc[i] = cd{beta, 0.0};
+                        v = cd{1.0, 0.0};
+                    } else {
+                        xc[i] = cd{0.0, 0.0};
+                        v = c_mul(c[l][t], scale);
+                    }
+                    vk[i] = v;
+                    c[l][t] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < PNB * PNB) Tpan[(int64_t)b * PNB * PNB + tid] = Tf[tid / PNB][tid % PNB];
+}
+
+template <int NB>
+struct WySmemC {
+    double redr[NTR / 64][NB][RCOLS], redi[NTR / 64][NB][RCOLS];
+    cd Y[NB][RCOLS], Z[NB][RCOLS], T[NB][NB];
+    double nrm[NTR / 64][RCOLS];
+};
+
+// complex compact-WY tile:  C[k0:, tile] <- (I - V T' V^H) C[k0:, tile],  T' = T^H (CONJT: factorisation) or T (forming Q U_R)
+template <int NB, bool CONJT, bool NORMS>
+__device__ __forceinline__ double wy_apply_tile_c(cd *Cb, int64_t rs, int64_t cs, int64_t k0, int64_t M, int64_t j0, int64_t jend,
+                                                  const cd *__restrict__ V, int nb, int64_t kend, WySmemC<NB> &sm,
+                                                  bool col_ok = true) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lo = lane & 15, kq = lane >> 4;
+    const int64_t j = j0 + lo;
+    const bool jok = (j < jend) && col_ok;
+    // ---- pass 1: Y(l, j) = sum_i conj(V(l, i)) C(i, j)
+    d4 ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 16 * (NTR / 64)) {
+        cd a[4], bb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + 4 * kq + q;
+            const bool iok = i < M;
+            a[q] = (iok && lo < nb) ? V[(int64_t)lo * M + i] : cd{0.0, 0.0};
+            bb[q] = (iok && jok) ? Cb[i * rs + j * cs] : cd{0.0, 0.0};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ar = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q].x, bb[q].x, ar, 0, 0, 0);
+            ar = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q].y, bb[q].y, ar, 0, 0, 0);
+            ai = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q].x, bb[q].y, ai, 0, 0, 0);
+            ai = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[q].y, bb[q].x, ai, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+        if (kq + 4 * reg < NB) {
+            sm.redr[wave][kq + 4 * reg][lo] = ar[reg];
+            sm.redi[wave][kq + 4 * reg][lo] = ai[reg];
+        }
+    __syncthreads();
+    if (threadIdx.x < NB * RCOLS) {
+        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
+        double tr = 0, ti = 0;
+#pragma unroll
+        for (int q = 0; q < NTR / 64; ++q) {
+            tr += sm.redr[q][l][c];
+            ti += sm.redi[q][l][c];
+        }
+        sm.Y[l][c] = cd{tr, ti};
+    }
+    __syncthreads();
+    if (threadIdx.x < NB * RCOLS) {
+        const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
+        cd t{0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < NB; ++m) t = CONJT ? c_fmac(sm.T[m][l], sm.Y[m][c], t) : c_fma(sm.T[l][m], sm.Y[m][c], t);
+        sm.Z[l][c] = cd{-t.x, -t.y};
+    }
+    __syncthreads();
+    cd zneg[NB / 4];
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) zneg[q] = sm.Z[4 * q + kq][lo];
+    // ---- pass 2: C += V Zneg
+    double nrm = 0;
+    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 2 * 16 * (NTR / 64)) {
+        d4 cr[2], ci[2];
+        cd av[2][NB / 4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t ib = i0 + (int64_t)h * 16 * (NTR / 64);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t i = ib + kq + 4 * reg;
+                const cd v = (i < M && jok) ? Cb[i * rs + j * cs] : cd{0.0, 0.0};
+                cr[h][reg] = v.x;
+                ci[h][reg] = v.y;
+            }
+#pragma unroll
+            for (int q = 0; q < NB / 4; ++q) {
+                const int64_t i = ib + lo;
+                const int l = 4 * q + kq;
+                av[h][q] = (i < M && l < nb) ? V[(int64_t)l * M + i] : cd{0.0, 0.0};
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < NB / 4; ++q) {
+                cr[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][q].x, zneg[q].x, cr[h], 0, 0, 0);
+                cr[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[h][q].y, zneg[q].y, cr[h], 0, 0, 0);
+                ci[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][q].x, zneg[q].y, ci[h], 0, 0, 0);
+                ci[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][q].y, zneg[q].x, ci[h], 0, 0, 0);
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t ib = i0 + (int64_t)h * 16 * (NTR / 64);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t i = ib + kq + 4 * reg;
+                if (i < M && jok) {
+                    Cb[i * rs + j * cs] = cd{cr[h][reg], ci[h][reg]};
+                    if (NORMS && i >= kend) nrm = fma(cr[h][reg], cr[h][reg], fma(ci[h][reg], ci[h][reg], nrm));
+                }
+            }
+        }
+    }
+    if (!NORMS) return 0.0;
+    nrm += __shfl_xor(nrm, 16, 64);
+    nrm += __shfl_xor(nrm, 32, 64);
+    if (lane < RCOLS) sm.nrm[wave][lo] = nrm;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x < RCOLS) {
+#pragma unroll
+        for (int q = 0; q < NTR / 64; ++q) t += sm.nrm[q][threadIdx.x];
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(NTR) void qrp_update_kernel_c(const QrpJob *__restrict__ jobs, int k, cd *__restrict__ X,
+                                                           const cd *__restrict__ Vall, double *__restrict__ cn,
+                                                           const QrpState *__restrict__ state, const cd *__restrict__ Tpan) {
+    __shared__ WySmemC<PNB> sm;
+    const int b = blockIdx.y;
+    const QrpState st = state[b];
+    if (st.done || st.nbk == 0) return;
+    const QrpJob J = jobs[b];
+    const int nbk = st.nbk;
+    const int64_t j0 = (int64_t)blockIdx.x * RCOLS;
+    if (j0 >= J.N) return;
+    const int64_t jl = j0 + (threadIdx.x & (RCOLS - 1));
+    const bool col_ok = (jl < J.N) && (cn[J.c_off + jl] >= 0.0);
+    if (__ballot(col_ok) == 0) return;
+    if (threadIdx.x < PNB * PNB) sm.T[threadIdx.x / PNB][threadIdx.x % PNB] = Tpan[(int64_t)b * PNB * PNB + threadIdx.x];
+    const double nrm = wy_apply_tile_c<PNB, true, true>(X + J.x_off, 1, J.M, k, J.M, j0, J.N, Vall + J.x_off + (int64_t)k * J.M,
+                                                        nbk, (int64_t)k + nbk, sm, col_ok);
+    if (threadIdx.x < RCOLS && col_ok) cn[J.c_off + jl] = nrm;
+}
+
+__global__ __launch_bounds__(NT) void qrp_extract_kernel_c(const QrpJob *__restrict__ jobs, const QrpState *__restrict__ state,
+                                                           const cd *__restrict__ X, const int64_t *__restrict__ cperm,
+                                                           cd *__restrict__ Rtop) {
+    const QrpJob J = jobs[blockIdx.y];
+    const int64_t r = state[blockIdx.y].rank, N = J.N;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < r * N; e += (int64_t)gridDim.x * NT) {
+        const int64_t i = e / N, j = e - i * N;
+        Rtop[J.r_off + e] = (j >= i) ? X[J.x_off + cperm[J.c_off + j] * J.M + i] : cd{0.0, 0.0};
+    }
+}
+
+__global__ __launch_bounds__(NT) void qrp_form_t_kernel_c(const QrpJob *__restrict__ jobs, const QrpState *__restrict__ state,
+                                                          const cd *__restrict__ UR, cd *__restrict__ T) {
+    const QrpJob J = jobs[blockIdx.y];
+    const int64_t r = state[blockIdx.y].rank, M = J.M;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < M * r; e += (int64_t)gridDim.x * NT) {
+        const int64_t i = e / r;
+        T[J.x_off + e] = (i < r) ? UR[J.r_off + e] : cd{0.0, 0.0};
+    }
+}
+
+__global__ __launch_bounds__(NTR) void qrp_tfactor_kernel_c(const QrpJob *__restrict__ jobs, const QrpState *__restrict__ state,
+                                                            const cd *__restrict__ Vall, const cd *__restrict__ tau,
+                                                            cd *__restrict__ Tfac) {
+    __shared__ cd S[QNB][QNB + 1];
+    __shared__ cd Tf[QNB][QNB + 1];
+    const QrpJob J = jobs[blockIdx.y];
+    const int64_t r = state[blockIdx.y].rank, M = J.M;
+    const int64_t k0 = (int64_t)blockIdx.x * QNB;
+    if (k0 >= r) return;
+    const int nb = (int)((r - k0 < QNB) ? (r - k0) : QNB);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const cd *V = Vall + J.x_off + k0 * M;
+    for (int q = 0; q < QNB; ++q) {          // S[l][l'] = v_l^H v_l'
+        const int l = wave, lp = q;
+        cd acc{0.0, 0.0};
+        if (l < lp && lp < nb)
+            for (int64_t i = k0 + lp + lane; i < M; i += 64) acc = c_fmac(V[l * M + i], V[lp * M + i], acc);
+        acc.x = wave_sum(acc.x);
+        acc.y = wave_sum(acc.y);
+        if (lane == 0) S[l][lp] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < QNB * QNB) Tf[threadIdx.x >> 4][threadIdx.x & 15] = cd{0.0, 0.0};
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        const cd tj = tau[J.c_off + k0 + j];
+        if (threadIdx.x < j) {
+            const int i = threadIdx.x;
+            cd acc{0.0, 0.0};
+            for (int m = i; m < j; ++m) acc = c_fma(Tf[i][m], S[m][j], acc);
+            const cd rr = c_mul(tj, acc);
+            Tf[i][j] = cd{-rr.x, -rr.y};
+        } else if (threadIdx.x == j)
+            Tf[j][j] = tj;
+        __syncthreads();
+    }
+    if (threadIdx.x < QNB * QNB)
+        Tfac[(J.pad0 + blockIdx.x) * (QNB * QNB) + threadIdx.x] = Tf[threadIdx.x >> 4][threadIdx.x & 15];
+}
+
+__global__ __launch_bounds__(NTR) void qrp_apply_q_block_kernel_c(const QrpJob *__restrict__ jobs,
+                                                                  const QrpState *__restrict__ state, int blk,
+                                                                  cd *__restrict__ C, const cd *__restrict__ Vall,
+                                                                  const cd *__restrict__ Tfac) {
+    __shared__ WySmemC<QNB> sm;
+    const int b = blockIdx.y;
+    const QrpJob J = jobs[b];
+    const int64_t r = state[b].rank;
+    const int64_t k0 = (int64_t)blk * QNB;
+    if (k0 >= r) return;
+    const int64_t j0 = (int64_t)blockIdx.x * RCOLS;
+    if (j0 >= r) return;
+    const int nb = (int)((r - k0 < QNB) ? (r - k0) : QNB);
+    if (threadIdx.x < QNB * QNB) sm.T[threadIdx.x >> 4][threadIdx.x & 15] = Tfac[(J.pad0 + blk) * (QNB * QNB) + threadIdx.x];
+    wy_apply_tile_c<QNB, false, false>(C + J.x_off, r, 1, k0, J.M, j0, r, Vall + J.x_off + k0 * J.M, nb, 0, sm);
+}
+
+__global__ __launch_bounds__(NT) void qrp_output_kernel_c(const QrpJob *__restrict__ jobs, const SvdJob *__restrict__ sj,
+                                                          const QrpState *__restrict__ state, const cd *__restrict__ T,
+                                                          const double *__restrict__ SR, const cd *__restrict__ VHR,
+                                                          const int64_t *__restrict__ cperm, cd *__restrict__ U,
+                                                          double *__restrict__ S, cd *__restrict__ VH) {
+    const QrpJob J = jobs[blockIdx.y];
+    const SvdJob O = sj[blockIdx.y];
+    const int64_t r = state[blockIdx.y].rank, M = J.M, N = J.N, K = N;
+    const int64_t stride = (int64_t)gridDim.x * NT, t0 = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const cd zero{0.0, 0.0};
+    for (int64_t e = t0; e < K; e += stride) S[O.s_off + e] = (e < r) ? SR[J.c_off + e] : 0.0;
+    if (!J.tr) {
+        for (int64_t e = t0; e < M * K; e += stride) {
+            const int64_t i = e / K, jj = e - i * K;
+            U[O.u_off + e] = (jj < r) ? T[J.x_off + i * r + jj] : zero;
+        }
+        for (int64_t e = t0; e < K * N; e += stride) {
+            const int64_t jj = e / N, c = e - jj * N;
+            VH[O.vh_off + jj * N + cperm[J.c_off + c]] = (jj < r) ? VHR[J.r_off + jj * N + c] : zero;
+        }
+    } else {
+        for (int64_t e = t0; e < N * K; e += stride) {
+            const int64_t c = e / K, jj = e - c * K;
+            cd v = (jj < r) ? VHR[J.r_off + jj * N + c] : zero;
+            v.y = -v.y;
+            U[O.u_off + cperm[J.c_off + c] * K + jj] = v;
+        }
+        for (int64_t e = t0; e < K * M; e += stride) {
+            const int64_t jj = e / M, c = e - jj * M;
+            cd v = (jj < r) ? T[J.x_off + c * r + jj] : zero;
+            v.y = -v.y;
+            VH[O.vh_off + e] = v;
+        }
+    }
+}
+
 int tpa_svd_use_qrp = 1;   // real data: rank-revealing pivoted QR before the Jacobi iteration
 
 int tpa_svd_fused_round = 1;   // real data: one launch per Jacobi round (sibling workgroups synchronise through a counter)
@@ -1787,8 +2340,9 @@ struct QrpLayout {
             total = 0;
 };
 
-QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
+QrpLayout make_qrp_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     QrpLayout q;
+    const int64_t esz = (dtype == TPA_C128) ? 16 : 8;
     for (int b = 0; b < n_jobs; ++b) {
         const int64_t m = jobs_host[8 * b + 1], n = jobs_host[8 * b + 2];
         QrpJob J;
@@ -1816,13 +2370,13 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
         o = align_up(o + bytes, 256);
         return at;
     };
-    q.off_x = take(q.x_elems * 8);
-    q.off_vall = take(q.x_elems * 8);
-    q.off_rtop = take(q.r_elems * 8);
-    q.off_ur = take(q.r_elems * 8);
-    q.off_vhr = take(q.r_elems * 8);
+    q.off_x = take(q.x_elems * esz);
+    q.off_vall = take(q.x_elems * esz);
+    q.off_rtop = take(q.r_elems * esz);
+    q.off_ur = take(q.r_elems * esz);
+    q.off_vhr = take(q.r_elems * esz);
     q.off_cn = take(q.c_elems * 8);
-    q.off_tau = take(q.c_elems * 8);
+    q.off_tau = take(q.c_elems * esz);
     q.off_sr = take(q.c_elems * 8);
     q.off_cperm = take(q.c_elems * 8);
     q.off_qjobs = take((int64_t)n_jobs * sizeof(QrpJob));
@@ -1830,10 +2384,10 @@ QrpLayout make_qrp_layout(const int64_t *jobs_host, int n_jobs) {
     q.off_state = take((int64_t)n_jobs * sizeof(QrpState));
     q.off_fro = take((int64_t)n_jobs * 8);
     q.off_fpart = take((int64_t)n_jobs * 64 * 8);
-    q.off_tfac = take(q.tf_blocks * QNB * QNB * 8);
-    q.off_tpan = take((int64_t)n_jobs * PNB * PNB * 8);
+    q.off_tfac = take(q.tf_blocks * QNB * QNB * esz);
+    q.off_tpan = take((int64_t)n_jobs * PNB * PNB * esz);
     q.off_nested = o;
-    o += make_layout(TPA_F64, q.nested_max.data(), n_jobs).total;
+    o += make_layout(dtype, q.nested_max.data(), n_jobs).total;
     q.total = o;
     return q;
 }
@@ -1842,11 +2396,14 @@ constexpr int64_t QRP_MIN_DIM = 32;        // below this the plain Jacobi path i
 constexpr double QRP_RANK_TOL = 1.0e-15;   // residual column norm <= tol * ||A||_F  ->  numerical rank reached
 constexpr int QRP_POLL = 8;                // steps between host polls of the "all blocks finished" state
 
+template <bool CPLX>
 int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a_base, void *u_base, double *s_dev,
                 void *vh_base, char *work, int max_sweeps, int *sweeps_done, hipStream_t st, double rho) {
-    double *X = (double *)(work + q.off_x), *Vall = (double *)(work + q.off_vall);
-    double *Rtop = (double *)(work + q.off_rtop), *UR = (double *)(work + q.off_ur), *VHR = (double *)(work + q.off_vhr);
-    double *cn = (double *)(work + q.off_cn), *tau = (double *)(work + q.off_tau), *SR = (double *)(work + q.off_sr);
+    const int dtype = CPLX ? TPA_C128 : TPA_F64;
+    void *X = work + q.off_x, *Vall = work + q.off_vall;
+    void *Rtop = work + q.off_rtop, *UR = work + q.off_ur, *VHR = work + q.off_vhr;
+    double *cn = (double *)(work + q.off_cn), *SR = (double *)(work + q.off_sr);
+    void *tau = work + q.off_tau;
     int64_t *cperm = (int64_t *)(work + q.off_cperm);
     QrpJob *qjobs = (QrpJob *)(work + q.off_qjobs);
     SvdJob *sjobs = (SvdJob *)(work + q.off_sjobs);
@@ -1854,24 +2411,35 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     double *fro2 = (double *)(work + q.off_fro), *fpart = (double *)(work + q.off_fpart);
     TPA_HIP_CHECK(hipMemcpyAsync(qjobs, q.qjobs.data(), q.qjobs.size() * sizeof(QrpJob), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(sjobs, lay.jobs.data(), lay.jobs.size() * sizeof(SvdJob), hipMemcpyHostToDevice, st));
-    svd_fro_kernel<false><<<dim3(FRO_PARTS, n_jobs), NT, 0, st>>>(sjobs, (const double *)a_base, fpart);
+    svd_fro_kernel<CPLX><<<dim3(FRO_PARTS, n_jobs), NT, 0, st>>>(sjobs, (const double *)a_base, fpart);
     svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(fpart, fro2);
     const int nmax = (int)q.n_max;
-    qrp_init_kernel<<<dim3((nmax + 63) / 64, n_jobs), NT, 0, st>>>(qjobs, sjobs, (const double *)a_base, X, cn, cperm, state);
+    if (CPLX)
+        qrp_init_kernel_c<<<dim3((nmax + 63) / 64, n_jobs), NT, 0, st>>>(qjobs, sjobs, (const cd *)a_base, (cd *)X, cn, cperm, state);
+    else
+        qrp_init_kernel<<<dim3((nmax + 63) / 64, n_jobs), NT, 0, st>>>(qjobs, sjobs, (const double *)a_base, (double *)X, cn, cperm, state);
     TPA_LAUNCH_CHECK();
     std::vector<QrpState> hstate(n_jobs);
     const double tol2 = QRP_RANK_TOL * QRP_RANK_TOL;
-    double *Tpan = (double *)(work + q.off_tpan);
+    void *Tpan = work + q.off_tpan;
     for (int k = 0, step = 0;; k += PNB, ++step) {
-        if (q.m_max <= 8 * 256)
-            qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+        if (CPLX) {
+            if (q.m_max <= 4 * 256)
+                qrp_panel_kernel_c<256, 4><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan);
+            else
+                qrp_panel_kernel_c<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan);
+        } else if (q.m_max <= 8 * 256)
+            qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan);
         else if (q.m_max <= 16 * 256)
-            qrp_panel_kernel<256, 16><<<n_jobs, 256, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+            qrp_panel_kernel<256, 16><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan);
         else
-            qrp_panel_kernel<256, 32><<<n_jobs, 256, 0, st>>>(qjobs, k, X, Vall, cn, tau, cperm, state, fro2, tol2, Tpan);
+            qrp_panel_kernel<256, 32><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan);
         if (k >= nmax) break;   // that launch only finalised the states
         const int tiles = (nmax + RCOLS - 1) / RCOLS;   // physical columns; finished ones are skipped inside
-        if (tiles > 0) qrp_update_kernel<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, X, Vall, cn, state, Tpan);
+        if (CPLX)
+            qrp_update_kernel_c<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, (cd *)X, (const cd *)Vall, cn, state, (const cd *)Tpan);
+        else
+            qrp_update_kernel<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, (double *)X, (const double *)Vall, cn, state, (const double *)Tpan);
         if ((step % QRP_POLL) == QRP_POLL - 1) {
             TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
             TPA_HIP_CHECK(hipStreamSynchronize(st));
@@ -1882,7 +2450,10 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     }
     TPA_LAUNCH_CHECK();
     qrp_finish_perm_kernel<<<n_jobs, NT, 0, st>>>(qjobs, state, cn, cperm);
-    qrp_extract_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, X, cperm, Rtop);
+    if (CPLX)
+        qrp_extract_kernel_c<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const cd *)X, cperm, (cd *)Rtop);
+    else
+        qrp_extract_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const double *)X, cperm, (double *)Rtop);
     TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
     TPA_HIP_CHECK(hipStreamSynchronize(st));
     {   // NaN / Inf in the input: ||A||_F^2 is not finite (the pivot search would silently report rank 0)
@@ -1913,22 +2484,31 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     int rc = 0;
     if (sweeps_done) *sweeps_done = 0;
     if (nn > 0) {
-        Layout nlay = make_layout(TPA_F64, nested.data(), nn);
+        Layout nlay = make_layout(dtype, nested.data(), nn);
         if (nlay.total > q.total - q.off_nested) {
             snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: internal work size mismatch");
             return TPA_E_BADARG;
         }
-        rc = svd_run<false>(nlay, nn, Rtop, UR, SR, VHR, work + q.off_nested, max_sweeps, sweeps_done, st, rho);
+        rc = svd_run<CPLX>(nlay, nn, Rtop, UR, SR, VHR, work + q.off_nested, max_sweeps, sweeps_done, st, rho);
         if (rc != 0 && rc != TPA_E_NOCONV) return rc;
-        qrp_form_t_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, UR, X);
-        double *Tfac = (double *)(work + q.off_tfac);
+        void *Tfac = work + q.off_tfac;
         const int nblk = (rmax + QNB - 1) / QNB;
-        qrp_tfactor_kernel<<<dim3(nblk, n_jobs), NTR, 0, st>>>(qjobs, state, Vall, tau, Tfac);
-        for (int blk = nblk - 1; blk >= 0; --blk)
-            qrp_apply_q_block_kernel<<<dim3((rmax + RCOLS - 1) / RCOLS, n_jobs), NTR, 0, st>>>(qjobs, state, blk, X, Vall, Tfac);
+        if (CPLX) {
+            qrp_form_t_kernel_c<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const cd *)UR, (cd *)X);
+            qrp_tfactor_kernel_c<<<dim3(nblk, n_jobs), NTR, 0, st>>>(qjobs, state, (const cd *)Vall, (const cd *)tau, (cd *)Tfac);
+            for (int blk = nblk - 1; blk >= 0; --blk)
+                qrp_apply_q_block_kernel_c<<<dim3((rmax + RCOLS - 1) / RCOLS, n_jobs), NTR, 0, st>>>(qjobs, state, blk, (cd *)X, (const cd *)Vall, (const cd *)Tfac);
+        } else {
+            qrp_form_t_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const double *)UR, (double *)X);
+            qrp_tfactor_kernel<<<dim3(nblk, n_jobs), NTR, 0, st>>>(qjobs, state, (const double *)Vall, (const double *)tau, (double *)Tfac);
+            for (int blk = nblk - 1; blk >= 0; --blk)
+                qrp_apply_q_block_kernel<<<dim3((rmax + RCOLS - 1) / RCOLS, n_jobs), NTR, 0, st>>>(qjobs, state, blk, (double *)X, (const double *)Vall, (const double *)Tfac);
+        }
     }
-    qrp_output_kernel<<<dim3(128, n_jobs), NT, 0, st>>>(qjobs, sjobs, state, X, SR, VHR, cperm, (double *)u_base, s_dev,
-                                                        (double *)vh_base);
+    if (CPLX)
+        qrp_output_kernel_c<<<dim3(128, n_jobs), NT, 0, st>>>(qjobs, sjobs, state, (const cd *)X, SR, (const cd *)VHR, cperm, (cd *)u_base, s_dev, (cd *)vh_base);
+    else
+        qrp_output_kernel<<<dim3(128, n_jobs), NT, 0, st>>>(qjobs, sjobs, state, (const double *)X, SR, (const double *)VHR, cperm, (double *)u_base, s_dev, (double *)vh_base);
     TPA_LAUNCH_CHECK();
     TPA_HIP_CHECK(hipStreamSynchronize(st));
     return rc;
@@ -1939,7 +2519,7 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
 extern "C" int64_t tpa_svd_worksize(int dtype, const int64_t *jobs_host, int n_jobs) {
     if (n_jobs <= 0) return 256;
     int64_t total = make_layout(dtype, jobs_host, n_jobs).total;
-    if (dtype == TPA_F64) total = std::max(total, make_qrp_layout(jobs_host, n_jobs).total);
+    total = std::max(total, make_qrp_layout(dtype, jobs_host, n_jobs).total);
     return total;
 }
 
@@ -1956,11 +2536,14 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
     hipStream_t st = (hipStream_t)stream;
     int64_t dim_max = 0;
     for (int b = 0; b < n_jobs; ++b) dim_max = std::max(dim_max, std::max(jobs_host[8 * b + 1], jobs_host[8 * b + 2]));
-    if (dtype == TPA_F64 && tpa_svd_use_qrp && !tpa_svd_force_pairwise && lay.rmax_pad >= QRP_MIN_DIM &&
-        dim_max <= (int64_t)NTP_MAX * RPT_MAX) {
-        QrpLayout q = make_qrp_layout(jobs_host, n_jobs);
+    // complex: the panel lives in registers as (re, im) pairs -> max(m, n) <= 2048
+    if (tpa_svd_use_qrp && !tpa_svd_force_pairwise && lay.rmax_pad >= QRP_MIN_DIM &&
+        dim_max <= ((dtype == TPA_F64) ? (int64_t)NTP_MAX * RPT_MAX : (int64_t)2048)) {
+        QrpLayout q = make_qrp_layout(dtype, jobs_host, n_jobs);
         TPA_ARG_CHECK(work_bytes >= q.total);
-        return svd_run_qrp(lay, q, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
+        if (dtype == TPA_F64)
+            return svd_run_qrp<false>(lay, q, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
+        return svd_run_qrp<true>(lay, q, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
     }
     if (dtype == TPA_F64)
         return svd_run<false>(lay, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);

@@ -203,7 +203,9 @@ def test_svd_batch(env, cplx, shapes):
 
 
 def _svd_call(torch, lib, mats, max_sweeps=60, rho=1e-6):
-    """tpa_svd_batch on a list of real host matrices -> list of (u, s, vh) host tensors, return code."""
+    """tpa_svd_batch on a list of host matrices (all real or all complex) -> list of (u, s, vh) host tensors, return code."""
+    cplx = mats[0].is_complex()
+    dt = torch.complex128 if cplx else torch.float64
     jobs, a_off, u_off, s_off, v_off = [], 0, 0, 0, 0
     for x in mats:
         m, n = x.shape
@@ -211,14 +213,14 @@ def _svd_call(torch, lib, mats, max_sweeps=60, rho=1e-6):
         jobs.append([a_off, m, n, u_off, s_off, v_off, 0, 0])
         a_off, u_off, s_off, v_off = a_off + m * n, u_off + m * k, s_off + k, v_off + k * n
     A = torch.cat([x.reshape(-1) for x in mats]).cuda()
-    U = torch.zeros(u_off, dtype=torch.float64).cuda()
+    U = torch.zeros(u_off, dtype=dt).cuda()
     S = torch.zeros(s_off, dtype=torch.float64).cuda()
-    VH = torch.zeros(v_off, dtype=torch.float64).cuda()
+    VH = torch.zeros(v_off, dtype=dt).cuda()
     jh = np.array(jobs, np.int64)
-    wb = lib.tpa_svd_worksize(0, jh.ctypes.data, len(jobs))
+    wb = lib.tpa_svd_worksize(int(cplx), jh.ctypes.data, len(jobs))
     work = torch.empty(wb, dtype=torch.uint8).cuda()
     sw = ctypes.c_int()
-    rc = lib.tpa_svd_batch(0, jh.ctypes.data, len(jobs), A.data_ptr(), U.data_ptr(), S.data_ptr(), VH.data_ptr(),
+    rc = lib.tpa_svd_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), U.data_ptr(), S.data_ptr(), VH.data_ptr(),
                            work.data_ptr(), wb, max_sweeps, rho, ctypes.byref(sw), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     out = []
@@ -229,17 +231,19 @@ def _svd_call(torch, lib, mats, max_sweeps=60, rho=1e-6):
     return out, rc, sw.value
 
 
-def test_svd_rank_revealing_path(env):
+@pytest.mark.parametrize("cplx", [False, True])
+def test_svd_rank_revealing_path(env, cplx):
     """Rank-deficient, graded blocks like DMRG wave functions (pivoted-QR preconditioner + Jacobi on the r x n factor)
     against torch's LAPACK SVD and against the same call with the preconditioner switched off."""
     torch, lib, _lib = env
     g = torch.Generator(device="cpu").manual_seed(11)
     mats = []
     for (m, n, r) in [(300, 300, 160), (200, 333, 90), (333, 200, 200), (70, 40, 1), (1, 1, 1), (5, 90, 5), (64, 64, 0)]:
-        u, _ = torch.linalg.qr(torch.randn(m, max(r, 1), dtype=torch.float64, generator=g))
-        v, _ = torch.linalg.qr(torch.randn(n, max(r, 1), dtype=torch.float64, generator=g))
+        dt = torch.complex128 if cplx else torch.float64
+        u, _ = torch.linalg.qr(torch.randn(m, max(r, 1), dtype=dt, generator=g))
+        v, _ = torch.linalg.qr(torch.randn(n, max(r, 1), dtype=dt, generator=g))
         sv = torch.logspace(0, -9, max(r, 1), dtype=torch.float64) * (1. if r > 0 else 0.)
-        mats.append((u * sv) @ v.T)
+        mats.append((u * sv.to(dt)) @ v.conj().T)
     res, rc, sweeps = _svd_call(torch, lib, mats)
     assert rc == 0
     lib.tpa_svd_set_algorithm(512)        # same kernels without the pivoted-QR preconditioner
@@ -256,15 +260,15 @@ def test_svd_rank_revealing_path(env):
         assert (s - ref).abs().max().item() <= 1e-13 * scale * max(m, n)          # absolute accuracy eps ||A||
         assert (s - s2).abs().max().item() <= 1e-13 * scale * max(m, n)
         assert bool((s[:-1] >= s[1:]).all())
-        assert ((u * s) @ vh - x).abs().max().item() <= 1e-12 * scale * max(m, n)
+        assert ((u * s.to(u.dtype)) @ vh - x).abs().max().item() <= 1e-12 * scale * max(m, n)
         # vectors of sigma >= rho ||A|| (rho = 1e-6, the absolute floor of the stopping rule) are orthonormal to
         # working precision, the ones below it to ~ eps rho ||A|| / sigma  
         for thresh, tol in ((1e-6, 1e-12), (1e-12, 1e-9)):
             nz = s > thresh * scale
             k = int(nz.sum())
             if k:
-                assert (u[:, nz].T @ u[:, nz] - torch.eye(k, dtype=torch.float64)).abs().max().item() < tol
-                assert (vh[nz] @ vh[nz].T - torch.eye(k, dtype=torch.float64)).abs().max().item() < tol
+                assert (u[:, nz].conj().T @ u[:, nz] - torch.eye(k, dtype=u.dtype)).abs().max().item() < tol
+                assert (vh[nz] @ vh[nz].conj().T - torch.eye(k, dtype=u.dtype)).abs().max().item() < tol
         # beyond the numerical rank: exact zeros, zero vectors (documented in include/tenpy_amd.h)
         dead = s == 0
         assert u[:, dead].abs().max().item() == 0.0 if bool(dead.any()) else True
