@@ -153,6 +153,9 @@ int tpa_svd_set_algorithm(int pairwise);
  *   Q_b m x k row-major, R_b k x n row-major, k = min(m,n).  A not overwritten. */
 int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base,
                  void *r_base, void *stream);
+/* Test hook: bit 0 = always use the one-workgroup Householder kernel (default: blocked compact-WY QR on the matrix
+ * cores when min(m,n) >= 32 and m <= 8192 (real) / 2048 (complex)). */
+int tpa_qr_set_algorithm(int v);
 
 /* ---- K7: batched Hermitian eigendecomposition, cyclic Jacobi (np.linalg.eigh per block,
  *      np_conserved.py:5059-5061) ----------------------------------------------------------

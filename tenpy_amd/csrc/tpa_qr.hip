@@ -205,11 +205,31 @@ __global__ __launch_bounds__(NT) void qr_kernel(const QrJob *__restrict__ jobs,
 }
 }  // namespace
 
+int tpa_qr_wy_internal(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base, void *r_base,
+                       void *stream);
+int tpa_qr_use_wy = 1;   // test hook (tpa_qr_set_algorithm): 0 = always the one-workgroup kernel
+
+extern "C" int tpa_qr_set_algorithm(int v) {
+    tpa_qr_use_wy = (v & 1) ? 0 : 1;
+    return 0;
+}
+
 // workspace requirement: per job 2*m*n + k elements (W, V, tau); allocated internally via hipMallocAsync
 extern "C" int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base,
                             void *q_base, void *r_base, void *stream) {
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
+    {   // large blocks: blocked compact-WY QR on the matrix cores (tpa_svd.hip); this file's one-workgroup kernel is
+        // launch-cheaper for small blocks but streams the whole trailing matrix through ONE CU per column
+        int64_t kmax = 0, dmax = 0;
+        for (int b = 0; b < n_jobs; ++b) {
+            TPA_ARG_CHECK(jobs_host[8 * b + 1] > 0 && jobs_host[8 * b + 2] > 0);
+            kmax = std::max(kmax, std::min(jobs_host[8 * b + 1], jobs_host[8 * b + 2]));
+            dmax = std::max(dmax, jobs_host[8 * b + 1]);
+        }
+        if (tpa_qr_use_wy && kmax >= 32 && dmax <= ((dtype == TPA_F64) ? 8192 : 2048))
+            return tpa_qr_wy_internal(dtype, jobs_host, n_jobs, a_base, q_base, r_base, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     const int64_t esz = (dtype == TPA_C128) ? 16 : 8;
     std::vector<QrJob> jobs(n_jobs);

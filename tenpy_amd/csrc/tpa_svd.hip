@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                                                        double *__restrict__ Vall, double *__restrict__ cn,
                                                        double *__restrict__ tau, int64_t *__restrict__ cperm,
                                                        QrpState *__restrict__ state, const double *__restrict__ fro2,
-                                                       double tol2, double *__restrict__ Tpan) {
+                                                       double tol2, double *__restrict__ Tpan, int pivot) {
     __shared__ double rv[NTP / 64];
     __shared__ int64_t ri[NTP / 64];
     __shared__ double red[NTP / 64][PNB + 1];
@@ -1076,8 +1076,9 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
     if (st0.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t M = J.M, N = J.N;
-    if (st0.last || k >= N) {
-        if (tid == 0) state[b] = QrpState{st0.last ? st0.rank : (int)N, 1, 0, 0};
+    const int64_t Kmax = (M < N) ? M : N;      // number of reflectors (N <= M in the pivoted use)
+    if (st0.last || k >= Kmax) {
+        if (tid == 0) state[b] = QrpState{st0.last ? st0.rank : (int)Kmax, 1, 0, 0};
         return;
     }
     // ---- the PNB largest residual norms among the unprocessed columns (ties -> smallest index: deterministic)
@@ -1089,6 +1090,14 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
     }
     const double thresh = tol2 * fro2[b];
     if (tid == 0) s_nbk = 0;
+    if (!pivot) {   // plain QR: the next PNB columns in their natural order, no rank test
+        if (tid == 0) {
+            const int nb_ = (int)((Kmax - k < PNB) ? (Kmax - k) : PNB);
+            for (int l = 0; l < nb_; ++l) s_p[l] = (int64_t)k + l;
+            s_nbk = nb_;
+        }
+        __syncthreads();
+    } else
     for (int l = 0; l < PNB; ++l) {
         double bv = -3.0;
         int64_t bidx = N;
@@ -1633,7 +1642,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel_c(const QrpJob *__restri
                                                           cd *__restrict__ Vall, double *__restrict__ cn,
                                                           cd *__restrict__ tau, int64_t *__restrict__ cperm,
                                                           QrpState *__restrict__ state, const double *__restrict__ fro2,
-                                                          double tol2, cd *__restrict__ Tpan) {
+                                                          double tol2, cd *__restrict__ Tpan, int pivot) {
     __shared__ double rv[NTP / 64];
     __shared__ int64_t ri[NTP / 64];
     __shared__ double red[NTP / 64][KC];
@@ -1646,8 +1655,9 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel_c(const QrpJob *__restri
     if (st0.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t M = J.M, N = J.N;
-    if (st0.last || k >= N) {
-        if (tid == 0) state[b] = QrpState{st0.last ? st0.rank : (int)N, 1, 0, 0};
+    const int64_t Kmax = (M < N) ? M : N;      // number of reflectors (N <= M in the pivoted use)
+    if (st0.last || k >= Kmax) {
+        if (tid == 0) state[b] = QrpState{st0.last ? st0.rank : (int)Kmax, 1, 0, 0};
         return;
     }
     double cand[RPT];
@@ -1658,6 +1668,14 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel_c(const QrpJob *__restri
     }
     const double thresh = tol2 * fro2[b];
     if (tid == 0) s_nbk = 0;
+    if (!pivot) {   // plain QR: the next PNB columns in their natural order, no rank test
+        if (tid == 0) {
+            const int nb_ = (int)((Kmax - k < PNB) ? (Kmax - k) : PNB);
+            for (int l = 0; l < nb_; ++l) s_p[l] = (int64_t)k + l;
+            s_nbk = nb_;
+        }
+        __syncthreads();
+    } else
     for (int l = 0; l < PNB; ++l) {
         double bv = -3.0;
         int64_t bidx = N;
@@ -2425,15 +2443,15 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     for (int k = 0, step = 0;; k += PNB, ++step) {
         if (CPLX) {
             if (q.m_max <= 4 * 256)
-                qrp_panel_kernel_c<256, 4><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan);
+                qrp_panel_kernel_c<256, 4><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan, 1);
             else
-                qrp_panel_kernel_c<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan);
+                qrp_panel_kernel_c<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan, 1);
         } else if (q.m_max <= 8 * 256)
-            qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan);
+            qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan, 1);
         else if (q.m_max <= 16 * 256)
-            qrp_panel_kernel<256, 16><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan);
+            qrp_panel_kernel<256, 16><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan, 1);
         else
-            qrp_panel_kernel<256, 32><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan);
+            qrp_panel_kernel<256, 32><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan, 1);
         if (k >= nmax) break;   // that launch only finalised the states
         const int tiles = (nmax + RCOLS - 1) / RCOLS;   // physical columns; finished ones are skipped inside
         if (CPLX)
@@ -2514,7 +2532,154 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     return rc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Blocked Householder QR (no pivoting) on the same panel / compact-WY kernels: np.linalg.qr per block for the large
+// blocks of the QR-based truncation (np_conserved.py:4190; truncation.py:473-711).  Called from tpa_qr_batch (tpa_qr.hip)
+// when min(m, n) >= 32; the one-workgroup kernel there stays for small blocks.
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void qr_identity_kernel(const QrpJob *__restrict__ jobs, double *__restrict__ T) {
+    const QrpJob J = jobs[blockIdx.y];
+    const int64_t K = (J.M < J.N) ? J.M : J.N;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < J.M * K; e += (int64_t)gridDim.x * NT) {
+        const int64_t i = e / K, j = e - i * K;
+        if (CPLX)
+            reinterpret_cast<cd *>(T)[J.x_off + e] = cd{(i == j) ? 1.0 : 0.0, 0.0};
+        else
+            T[J.x_off + e] = (i == j) ? 1.0 : 0.0;
+    }
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void qr_copy_q_kernel(const QrpJob *__restrict__ jobs, const int64_t *__restrict__ q_offs,
+                                                       const double *__restrict__ T, double *__restrict__ Q) {
+    const QrpJob J = jobs[blockIdx.y];
+    const int64_t K = (J.M < J.N) ? J.M : J.N, qo = q_offs[blockIdx.y];
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < J.M * K; e += (int64_t)gridDim.x * NT) {
+        if (CPLX)
+            reinterpret_cast<cd *>(Q)[qo + e] = reinterpret_cast<const cd *>(T)[J.x_off + e];
+        else
+            Q[qo + e] = T[J.x_off + e];
+    }
+}
+
+template <bool CPLX>
+int qr_run_wy(const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base, void *r_base, hipStream_t st) {
+    const int64_t esz = CPLX ? 16 : 8;
+    std::vector<QrpJob> qj(n_jobs);
+    std::vector<SvdJob> sj(n_jobs);
+    std::vector<int64_t> qoffs(n_jobs);
+    int64_t x_elems = 0, c_elems = 0, tf_blocks = 0, nmax = 0, kmax = 0, mmax = 0;
+    for (int b = 0; b < n_jobs; ++b) {
+        const int64_t *j = jobs_host + 8 * b;
+        QrpJob &J = qj[b];
+        J.tr = 0;
+        J.M = j[1];
+        J.N = j[2];
+        J.x_off = x_elems;
+        J.r_off = j[4];
+        J.c_off = c_elems;
+        J.pad0 = tf_blocks;
+        J.pad1 = 0;
+        const int64_t K = std::min(J.M, J.N);
+        tf_blocks += (K + QNB - 1) / QNB;
+        x_elems += J.M * J.N;
+        c_elems += J.N;
+        nmax = std::max(nmax, J.N);
+        kmax = std::max(kmax, K);
+        mmax = std::max(mmax, J.M);
+        qoffs[b] = j[3];
+        SvdJob S{};
+        S.a_off = j[0];
+        S.m = J.M;
+        S.n = J.N;
+        sj[b] = S;
+    }
+    int64_t o = 0;
+    auto take = [&o](int64_t bytes) {
+        const int64_t at = o;
+        o = align_up(o + bytes, 256);
+        return at;
+    };
+    const int64_t off_x = take(x_elems * esz), off_v = take(x_elems * esz), off_tau = take(c_elems * esz),
+                  off_cn = take(c_elems * 8), off_cperm = take(c_elems * 8), off_qj = take(n_jobs * sizeof(QrpJob)),
+                  off_sj = take(n_jobs * sizeof(SvdJob)), off_state = take(n_jobs * sizeof(QrpState)),
+                  off_fro = take(n_jobs * 8), off_qo = take(n_jobs * 8), off_tfac = take(tf_blocks * QNB * QNB * esz),
+                  off_tpan = take((int64_t)n_jobs * PNB * PNB * esz);
+    char *work = nullptr;
+    TPA_HIP_CHECK(hipMallocAsync((void **)&work, (size_t)o, st));
+    void *X = work + off_x, *Vall = work + off_v, *tau = work + off_tau, *Tfac = work + off_tfac, *Tpan = work + off_tpan;
+    double *cn = (double *)(work + off_cn), *fro2 = (double *)(work + off_fro);
+    int64_t *cperm = (int64_t *)(work + off_cperm), *qo_dev = (int64_t *)(work + off_qo);
+    QrpJob *qjobs = (QrpJob *)(work + off_qj);
+    SvdJob *sjobs = (SvdJob *)(work + off_sj);
+    QrpState *state = (QrpState *)(work + off_state);
+    int rc = 0;
+    auto fail = [&](hipError_t e) {
+        snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_qr_batch: %s", hipGetErrorString(e));
+        rc = (int)e;
+    };
+    hipError_t e;
+    if ((e = hipMemcpyAsync(qjobs, qj.data(), n_jobs * sizeof(QrpJob), hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+    if (!rc && (e = hipMemcpyAsync(sjobs, sj.data(), n_jobs * sizeof(SvdJob), hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+    if (!rc && (e = hipMemcpyAsync(qo_dev, qoffs.data(), n_jobs * 8, hipMemcpyHostToDevice, st)) != hipSuccess) fail(e);
+    if (!rc && (e = hipMemsetAsync(fro2, 0, n_jobs * 8, st)) != hipSuccess) fail(e);
+    if (!rc) {
+        const dim3 gcol((unsigned)((nmax + 63) / 64), n_jobs);
+        if (CPLX)
+            qrp_init_kernel_c<<<gcol, NT, 0, st>>>(qjobs, sjobs, (const cd *)a_base, (cd *)X, cn, cperm, state);
+        else
+            qrp_init_kernel<<<gcol, NT, 0, st>>>(qjobs, sjobs, (const double *)a_base, (double *)X, cn, cperm, state);
+        const int tiles = (int)((nmax + RCOLS - 1) / RCOLS);
+        for (int k = 0;; k += PNB) {
+            if (CPLX) {
+                if (mmax <= 4 * 256)
+                    qrp_panel_kernel_c<256, 4><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, 0.0, (cd *)Tpan, 0);
+                else
+                    qrp_panel_kernel_c<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, 0.0, (cd *)Tpan, 0);
+            } else if (mmax <= 8 * 256)
+                qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, 0.0, (double *)Tpan, 0);
+            else if (mmax <= 16 * 256)
+                qrp_panel_kernel<256, 16><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, 0.0, (double *)Tpan, 0);
+            else
+                qrp_panel_kernel<256, 32><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, 0.0, (double *)Tpan, 0);
+            if (k >= kmax) break;   // that launch only finalised the states (rank = min(m, n))
+            if (CPLX)
+                qrp_update_kernel_c<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, (cd *)X, (const cd *)Vall, cn, state, (const cd *)Tpan);
+            else
+                qrp_update_kernel<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, (double *)X, (const double *)Vall, cn, state, (const double *)Tpan);
+        }
+        const int nblk = (int)((kmax + QNB - 1) / QNB);
+        const dim3 gq((unsigned)((kmax + RCOLS - 1) / RCOLS), n_jobs);
+        if (CPLX) {
+            qrp_extract_kernel_c<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const cd *)X, cperm, (cd *)r_base);
+            qr_identity_kernel<true><<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, (double *)X);
+            qrp_tfactor_kernel_c<<<dim3(nblk, n_jobs), NTR, 0, st>>>(qjobs, state, (const cd *)Vall, (const cd *)tau, (cd *)Tfac);
+            for (int blk = nblk - 1; blk >= 0; --blk)
+                qrp_apply_q_block_kernel_c<<<gq, NTR, 0, st>>>(qjobs, state, blk, (cd *)X, (const cd *)Vall, (const cd *)Tfac);
+            qr_copy_q_kernel<true><<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, qo_dev, (const double *)X, (double *)q_base);
+        } else {
+            qrp_extract_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const double *)X, cperm, (double *)r_base);
+            qr_identity_kernel<false><<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, (double *)X);
+            qrp_tfactor_kernel<<<dim3(nblk, n_jobs), NTR, 0, st>>>(qjobs, state, (const double *)Vall, (const double *)tau, (double *)Tfac);
+            for (int blk = nblk - 1; blk >= 0; --blk)
+                qrp_apply_q_block_kernel<<<gq, NTR, 0, st>>>(qjobs, state, blk, (double *)X, (const double *)Vall, (const double *)Tfac);
+            qr_copy_q_kernel<false><<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, qo_dev, (const double *)X, (double *)q_base);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) fail(e);
+    }
+    hipFreeAsync(work, st);
+    return rc;
+}
+
 }  // namespace
+
+// internal entry used by tpa_qr_batch (tpa_qr.hip)
+int tpa_qr_wy_internal(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base, void *r_base,
+                       void *stream) {
+    if (dtype == TPA_F64) return qr_run_wy<false>(jobs_host, n_jobs, a_base, q_base, r_base, (hipStream_t)stream);
+    return qr_run_wy<true>(jobs_host, n_jobs, a_base, q_base, r_base, (hipStream_t)stream);
+}
 
 extern "C" int64_t tpa_svd_worksize(int dtype, const int64_t *jobs_host, int n_jobs) {
     if (n_jobs <= 0) return 256;

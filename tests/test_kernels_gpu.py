@@ -286,14 +286,18 @@ def test_svd_nan_input_is_an_error(env):
             _lib.check(rc, "svd")
 
 
+@pytest.mark.parametrize("wy", [True, False])
 @pytest.mark.parametrize("cplx", [False, True])
-def test_qr_batch(env, cplx):
+def test_qr_batch(env, cplx, wy):
+    """wy: blocked compact-WY QR on the matrix cores (whole batch, because min(m,n) >= 32 for some block) / the
+    one-workgroup Householder kernel; both follow LAPACK's reflector convention, so R agrees between them."""
     torch, lib, _lib = env
     g = torch.Generator(device="cpu").manual_seed(9)
     dt = torch.complex128 if cplx else torch.float64
-    shapes = [(1, 1), (7, 3), (3, 7), (50, 50), (130, 40), (33, 90)]
+    shapes = [(1, 1), (7, 3), (3, 7), (50, 50), (130, 40), (33, 90), (300, 200), (200, 300), (257, 64)]
     mats = [torch.randn(m, n, dtype=dt, generator=g) for (m, n) in shapes]
     mats[3][:, 1] = 0  # zero column
+    mats[6][:, 5] = mats[6][:, 4]  # linearly dependent columns
     jobs, a_off, q_off, r_off = [], 0, 0, 0
     for (m, n) in shapes:
         k = min(m, n)
@@ -302,20 +306,32 @@ def test_qr_batch(env, cplx):
         q_off += m * k
         r_off += k * n
     A = torch.cat([x.reshape(-1) for x in mats]).cuda()
-    Q = torch.zeros(q_off, dtype=dt).cuda()
-    R = torch.zeros(r_off, dtype=dt).cuda()
     jh = np.array(jobs, np.int64)
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.tpa_qr_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), Q.data_ptr(), R.data_ptr(), st))
-    torch.cuda.synchronize()
+    res = {}
+    for mode in ([0, 1] if wy else [1]):
+        lib.tpa_qr_set_algorithm(mode)
+        try:
+            Q = torch.zeros(q_off, dtype=dt).cuda()
+            R = torch.zeros(r_off, dtype=dt).cuda()
+            _lib.check(lib.tpa_qr_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), Q.data_ptr(), R.data_ptr(), st))
+            torch.cuda.synchronize()
+        finally:
+            lib.tpa_qr_set_algorithm(0)
+        res[mode] = (Q.cpu(), R.cpu())
+    Qc, Rc = res[0 if wy else 1]
     for b, (m, n) in enumerate(shapes):
         k = min(m, n)
         j = jobs[b]
-        q = Q[j[3]:j[3] + m * k].reshape(m, k).cpu()
-        r = R[j[4]:j[4] + k * n].reshape(k, n).cpu()
+        q = Qc[j[3]:j[3] + m * k].reshape(m, k)
+        r = Rc[j[4]:j[4] + k * n].reshape(k, n)
         assert (q @ r - mats[b]).abs().max().item() < 1e-12 * max(m, n)
         assert (q.conj().T @ q - torch.eye(k, dtype=dt)).abs().max().item() < 1e-13 * max(m, n)
         assert torch.tril(r, -1).abs().max().item() == 0.0
+        assert r.diagonal().imag.abs().max().item() == 0.0 if cplx else True
+        if wy and b not in (3, 6):      # (rank-deficient blocks: R beyond the rank is rounding noise in both)
+            r_old = res[1][1][j[4]:j[4] + k * n].reshape(k, n)
+            assert (r - r_old).abs().max().item() < 1e-12 * max(m, n)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
