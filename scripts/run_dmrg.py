@@ -36,7 +36,10 @@ while _c < chi:
     chi_list[_s] = _c
     _s += 1
 print('chi_list', chi_list)
-eng = TwoSiteDMRGEngine(psi, H, {'chi_list': chi_list, 'trunc_params': {'chi_max': chi, 'svd_min': float(os.environ.get('SVD_MIN', 1e-10))}, 'lanczos_params': {}, 'profile': True})
+eng = TwoSiteDMRGEngine(psi, H, {'chi_list': chi_list, 'trunc_params': {'chi_max': chi, 'svd_min': float(os.environ.get('SVD_MIN', 1e-10))}, 'lanczos_params': ({'N_min': int(os.environ['NLANCZOS']), 'N_max': int(os.environ['NLANCZOS'])} if os.environ.get('NLANCZOS') else {}),
+                                 'profile': True, 'mixer': bool(os.environ.get('MIXER')), 'mixer_params': {'amplitude': 1.e-5, 'decay': 2., 'disable_after': 15}})
+if os.environ.get('MIXER'):
+    eng.mixer_activate()
 for s in range(ns):
     torch.cuda.synchronize()
     t = time.time()

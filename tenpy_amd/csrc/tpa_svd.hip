@@ -245,6 +245,7 @@ __device__ __forceinline__ void svd_local_solve(double (*Sm)[TRJ + 1], double (*
         for (int sweep = 0; sweep < local_sweeps; ++sweep) {
             bool rotated = false;
             for (int rr = 0; rr < n_local; ++rr) {
+                bool rot_now = false;
                 if (lane < TRJ) {
                     const int i = lane;
                     int pi;
@@ -271,11 +272,13 @@ __device__ __forceinline__ void svd_local_solve(double (*Sm)[TRJ + 1], double (*
                         c = c0 * fma(-0.5 * x * c0, c0, 1.5);
                         s = c * t;
                         rotated = true;
+                        rot_now = true;
                     }
                     partA[i] = pi;
                     csA[i] = c;
                     cpA[i] = (i == p) ? -s : s;
                 }
+                if (!__any(rot_now)) continue;   // no pair of this local round needs a rotation: skip the update passes
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 {
                     const int pi = partA[ei];
