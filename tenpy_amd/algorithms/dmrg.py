@@ -176,6 +176,7 @@ class TwoSiteDMRGEngine:
         tick('heff')
         lanczos = LanczosGroundState(eff_H, theta, self.lanczos_params)
         E0, theta, N = lanczos.run()
+        theta = eff_H.prepare_svd(theta)          # fused matrix [(vL.p0), (p1.vR)] for the SVD / mixer
         tick('lanczos')
         i1 = i0 + 1
         qtotal_i0 = psi.get_B(i0, None).qtotal

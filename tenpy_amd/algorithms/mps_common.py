@@ -10,7 +10,12 @@ MI355X-first differences:
   (the reference calls ``itranspose`` inside ``matvec`` :1339): LHeff = [(vR*.p0), wR, (vR.p0*)],
   RHeff = [wL, (p1*.vL), (p1.vL*)];
 * both contraction plans are built once per bond and replayed for every Lanczos step: one matvec is
-  exactly two grouped-GEMM launches, no host planning, no allocation besides the result arena.
+  exactly two grouped-GEMM launches, no host planning, no allocation besides the result arena;
+* ``factored`` mode (default when every block of W0, W1 is a single number): the same operator applied as
+  ``LP . theta . (W0 W1) . RP`` -- two GEMM launches with a factor d fewer flops (the physical legs are not fused into
+  the contracted index) plus one block-level linear combination for the two MPO tensors; LHeff / RHeff are then only
+  built on demand (mixer, tests).  theta stays in its un-fused form (vL, p0, p1, vR) during the Lanczos iteration and
+  is fused once for the SVD (``prepare_svd``).  Same result as the fused path to rounding (tests/test_heff.py).
 """
 import numpy as np
 
@@ -20,6 +25,7 @@ __all__ = ['TwoSiteH', 'DensityMatrixMixer']
 
 
 FUSED_HEFF = True     # tuning / test hook: False forces the generic tensordot + combine_legs construction
+FACTORED_MATVEC = True   # tuning / test hook: False = always LHeff . theta . RHeff (the reference's combine=True form)
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Fused construction of LHeff / RHeff:  LP.W0 (resp. W1.RP) + combine_legs in ONE kernel launch.
@@ -134,11 +140,161 @@ def _fused_heff(env_t, W, left):
     return res, pipe
 
 
+def _relabel_view(A, labels):
+    """``A`` with its legs in the order ``labels`` WITHOUT moving data: allowed when only legs with 1-wide blocks change
+    their position relative to the others (the memory layout of every block is then unchanged); bookkeeping only."""
+    perm = [A.get_leg_index(l) for l in labels]
+    if perm == list(range(A.rank)):
+        return A
+    big = [a for a in range(A.rank) if not np.all(A.legs[a].get_block_sizes() == 1)]
+    assert [a for a in perm if a in big] == big, "only legs with 1-wide blocks may be moved"
+    B = A.copy(deep=False)
+    B.legs = [A.legs[a] for a in perm]
+    B._set_shape()
+    B._labels = [A._labels[a] for a in perm]
+    B._qdata = np.ascontiguousarray(A._qdata[:, perm])
+    B._offsets = A._offsets.copy()
+    B._qdata_sorted = False
+    B._skey = None
+    B.isort_qdata()
+    return B
+
+
+class MpoApplyPlan:
+    """``Y[.., w', p, ..] = sum_{w, p'} W[w, w', p, p'] X[.., w, p', ..]`` for an MPO tensor whose blocks are single
+    numbers: every block of Y is a linear combination of whole blocks of X (the w and p legs of X have 1-wide blocks, so
+    a block of X and the blocks of Y it feeds have the same memory layout).  One ``tpa_lincomb_batch`` launch; the job
+    tables are built once from the block structure of X and replayed.  With ``W2`` the two neighbouring MPO tensors
+    W W2 (summed over their common bond) are applied in the same single pass.
+
+    ``x_w``, ``x_p`` (, ``x_p2``) : labels of X's MPO leg and physical leg(s) to be contracted.
+    ``w_in`` / ``w_out``          : labels of the MPO legs contracted with X / left open ('wL', 'wR' when going left to right).
+    ``p_out`` / ``p_in``          : labels of W's physical legs left open / contracted ('p0', 'p0*'); ``p2_out`` / ``p2_in`` for W2.
+    ``out_labels``                : order of the legs of Y (must keep the relative order of X's non-trivial legs).
+    """
+    _cache = {}
+
+    @classmethod
+    def get(cls, X, W, *args, W2=None, **kwargs):
+        """Cached constructor: the plan depends on the block structure of X and on the MPO tensors only."""
+        key = (X._struct_key(), str(X.dtype), id(_mpo_entries(W)), None if W2 is None else id(_mpo_entries(W2)), args,
+               tuple(sorted(kwargs.items())), tuple(X.get_leg_labels()))
+        plan = cls._cache.get(key)
+        if plan is None:
+            if len(cls._cache) > 512:
+                cls._cache.clear()
+            plan = cls._cache[key] = cls(X, W, *args, W2=W2, **kwargs)
+        return plan
+
+    def __init__(self, X, W, x_w, x_p, w_in, w_out, p_out, p_in, out_labels, W2=None, x_p2=None, p2_out=None, p2_in=None):
+        from ..linalg import _device as dev
+        ent = _mpo_entries(W)
+        assert ent is not None
+        wq, wv = ent
+        wl = list(W.get_leg_labels())
+        ci, co, po, pi = wl.index(w_in), wl.index(w_out), wl.index(p_out), wl.index(p_in)
+        xa_w, xa_p = X.get_leg_index(x_w), X.get_leg_index(x_p)
+        assert np.all(X.legs[xa_w].get_block_sizes() == 1) and np.all(X.legs[xa_p].get_block_sizes() == 1)
+        # entry table: (w_in, w_out, p_out, p_in [, p2_out, p2_in]) -> value
+        e_in_w, e_out_w, e_po, e_pi, e_val = wq[:, ci], wq[:, co], wq[:, po], wq[:, pi], np.asarray(wv)
+        e_p2o = e_p2i = None
+        w_leg_out, xa_p2 = W.get_leg(w_out), None
+        if W2 is not None:
+            wq2, wv2 = _mpo_entries(W2)
+            wl2 = list(W2.get_leg_labels())
+            ci2, co2, po2, pi2 = wl2.index(w_in), wl2.index(w_out), wl2.index(p2_out), wl2.index(p2_in)
+            xa_p2 = X.get_leg_index(x_p2)
+            assert np.all(X.legs[xa_p2].get_block_sizes() == 1)
+            i1, i2 = np.nonzero(e_out_w[:, None] == wq2[:, ci2][None, :])        # join over the common MPO bond
+            keys = np.stack([e_in_w[i1], wq2[i2, co2], e_po[i1], e_pi[i1], wq2[i2, po2], wq2[i2, pi2]], axis=1)
+            vals = e_val[i1] * np.asarray(wv2)[i2]
+            uk, inv = np.unique(keys, axis=0, return_inverse=True)
+            tot = np.zeros(len(uk), dtype=vals.dtype)
+            np.add.at(tot, inv.reshape(-1), vals)
+            keep = tot != 0
+            uk, tot = uk[keep], tot[keep]
+            e_in_w, e_out_w, e_po, e_pi, e_p2o, e_p2i, e_val = uk[:, 0], uk[:, 1], uk[:, 2], uk[:, 3], uk[:, 4], uk[:, 5], tot
+            w_leg_out = W2.get_leg(w_out)
+        xq = X._qdata
+        match = (xq[:, xa_w][:, None] == e_in_w[None, :]) & (xq[:, xa_p][:, None] == e_pi[None, :])
+        if W2 is not None:
+            match &= (xq[:, xa_p2][:, None] == e_p2i[None, :])
+        ib, ie = np.nonzero(match)
+        oq = xq[ib].copy()
+        oq[:, xa_w] = e_out_w[ie]
+        oq[:, xa_p] = e_po[ie]
+        legs = list(X.legs)
+        legs[xa_w] = w_leg_out
+        legs[xa_p] = W.get_leg(p_out)
+        labels = list(X.get_leg_labels())
+        labels[xa_w], labels[xa_p] = w_out, p_out
+        if W2 is not None:
+            oq[:, xa_p2] = e_p2o[ie]
+            legs[xa_p2] = W2.get_leg(p2_out)
+            labels[xa_p2] = p2_out
+        wv = e_val
+        perm = [labels.index(l) for l in out_labels]
+        big = [a for a in range(X.rank) if not np.all(legs[a].get_block_sizes() == 1)]
+        assert [a for a in perm if a in big] == big, "out_labels must keep the order of the non-trivial legs"
+        oq = oq[:, perm]
+        self.legs = [legs[a] for a in perm]
+        self.labels = list(out_labels)
+        self.dtype = np.result_type(X.dtype, W.dtype) if W2 is None else np.result_type(X.dtype, W.dtype, W2.dtype)
+        self.qtotal = X.chinfo.make_valid(X.qtotal + W.qtotal + (0 if W2 is None else W2.qtotal))
+        self.empty = len(ib) == 0
+        if self.empty:
+            return
+        uq, inv = np.unique(oq, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        order = np.lexsort(uq.T)
+        rank_of = np.empty(len(order), dtype=np.int64)
+        rank_of[order] = np.arange(len(order))
+        self.qdata = np.ascontiguousarray(uq[order], dtype=np.intp)
+        blk = rank_of[inv]
+        sizes_x = X._block_sizes_flat()
+        proto = npc.Array(self.legs, self.dtype, self.qtotal, self.labels)
+        sizes = proto._set_blocks(self.qdata, arena=dev.empty(0, self.dtype), qdata_sorted=True)
+        self.offsets = proto._offsets
+        self.total = int(np.sum(sizes))
+        key = np.lexsort((np.arange(len(blk)), blk))
+        b_sorted = blk[key]
+        first = np.concatenate([[True], b_sorted[1:] != b_sorted[:-1]])
+        starts = np.nonzero(first)[0]
+        counts = np.diff(np.concatenate([starts, [len(key)]]))
+        jobs = np.zeros((len(starts), 8), dtype=np.int64)
+        sz = sizes[b_sorted[starts]]
+        jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3] = self.offsets[b_sorted[starts]], 1, sz, sz
+        jobs[:, 4], jobs[:, 5] = starts, counts
+        terms = np.zeros((len(key), 4), dtype=np.int64)
+        terms[:, 0] = X._offsets[ib[key]]
+        terms[:, 1] = sizes_x[ib[key]]
+        alpha = np.asarray(wv[ie[key]], dtype=np.complex128)
+        terms[:, 2] = np.ascontiguousarray(alpha.real).view(np.int64)
+        terms[:, 3] = np.ascontiguousarray(alpha.imag).view(np.int64)
+        assert len(jobs) <= 60000
+        self.jobs_dev, self.terms_dev = dev.to_device(jobs), dev.to_device(terms)
+        self.n_jobs, self.max_elems = len(jobs), int(np.max(sz))
+        self.x_key = X._struct_key()
+        self.bytes = 8 * (2 if self.dtype.kind == 'c' else 1) * (self.total + int(np.sum(sizes_x[ib])))
+
+    def apply(self, X):
+        from ..linalg import _device as dev
+        res = npc.Array(self.legs, self.dtype, self.qtotal, self.labels)
+        if self.empty:
+            return res
+        if X.dtype != self.dtype:
+            X = X.astype(self.dtype)
+        res._set_blocks(self.qdata, arena=dev.empty(self.total, self.dtype), qdata_sorted=True)
+        dev.check(dev.lib().tpa_lincomb_batch(dev.code(self.dtype), self.jobs_dev.data_ptr(), self.n_jobs, self.terms_dev.data_ptr(),
+                                              self.max_elems, X._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "lincomb")
+        return res
+
+
 class TwoSiteH:
     length = 2
     acts_on = ['(vL.p0)', '(p1.vR)']
 
-    def __init__(self, env, i0, combine=True, move_right=True, tensors=None):
+    def __init__(self, env, i0, combine=True, move_right=True, tensors=None, factored=None):
         if not combine:
             raise NotImplementedError("tenpy_amd.TwoSiteH: only combine=True")
         self.i0 = i0
@@ -154,11 +310,63 @@ class TwoSiteH:
             self.dtype = env.H.dtype
         self.W0 = W0.replace_labels(['p', 'p*'], ['p0', 'p0*'])
         self.W1 = W1.replace_labels(['p', 'p*'], ['p1', 'p1*'])
-        self.combine_Heff(env if tensors is None else None)
+        # the host copy of the MPO entries is cached on the MPO's own tensors (one D2H read per site for the whole run)
+        self.W0._tpa_entries, self.W1._tpa_entries = _mpo_entries(W0), _mpo_entries(W1)
+        self._env = env if tensors is None else None
+        self._LHeff = self._RHeff = None
         self._plans = None
+        self._fplans = None
+        want = FACTORED_MATVEC if factored is None else factored
+        self.factored = bool(want) and self._factored_possible()
+        if self.factored:       # pipes only (host bookkeeping); LHeff / RHeff are built on first access
+            from ..linalg.charges import LegPipe
+            self._LPf = _relabel_view(self.LP, ['vR*', 'wR', 'vR'])      # leg orders the two GEMM steps want (views)
+            self._RPf = _relabel_view(self.RP, ['wL', 'vL', 'vL*'])
+            self.pipeL = LegPipe([self.LP.get_leg('vR*'), self.W0.get_leg('p0')], qconj=+1)
+            self.pipeR = LegPipe([self.W1.get_leg('p1'), self.RP.get_leg('vL*')], qconj=-1)
+            self._LHeff = self._RHeff = None
+            self.acts_on = ['vL', 'p0', 'p1', 'vR']
+        else:
+            self.combine_Heff(self._env)
         self.N = self.pipeL.ind_len * self.pipeR.ind_len
         self.flops_per_matvec = None
         self.bytes_per_matvec = None
+
+    def _factored_possible(self):
+        lp, rp = list(self.LP.get_leg_labels()), list(self.RP.get_leg_labels())
+        return (_mpo_entries(self.W0) is not None and _mpo_entries(self.W1) is not None and
+                sorted(lp) == sorted(['vR*', 'wR', 'vR']) and lp.index('vR*') < lp.index('vR') and
+                sorted(rp) == sorted(['wL', 'vL', 'vL*']) and rp.index('vL') < rp.index('vL*') and
+                np.all(self.LP.get_leg('wR').get_block_sizes() == 1) and np.all(self.RP.get_leg('wL').get_block_sizes() == 1) and
+                list(self.W0.get_leg_labels()) == ['wL', 'wR', 'p0', 'p0*'] and list(self.W1.get_leg_labels()) == ['wL', 'wR', 'p1', 'p1*'])
+
+    # LHeff / RHeff: attributes in the fused mode, built lazily in the factored mode (mixer, tests)
+    @property
+    def LHeff(self):
+        if self._LHeff is None:
+            self._build_heff_lazily()
+        return self._LHeff
+
+    @LHeff.setter
+    def LHeff(self, value):
+        self._LHeff = value
+
+    @property
+    def RHeff(self):
+        if self._RHeff is None:
+            self._build_heff_lazily()
+        return self._RHeff
+
+    @RHeff.setter
+    def RHeff(self, value):
+        self._RHeff = value
+
+    def _build_heff_lazily(self):
+        pL, pR = self.pipeL, self.pipeR
+        self.combine_Heff(self._env)
+        pL.test_equal(self.pipeL)
+        pR.test_equal(self.pipeR)
+        self.pipeL, self.pipeR = pL, pR      # keep the pipe objects theta was fused with
 
     def combine_Heff(self, env=None):
         """LHeff = LP.W0 and RHeff = W1.RP with the (virtual, physical) legs fused into pipes.
@@ -199,11 +407,53 @@ class TwoSiteH:
                 cache[('R', self.i0 + 1)] = (self.RP, self.RHeff, self.pipeR)
 
     def combine_theta(self, theta):
-        """theta (vL, p0, p1, vR) -> matrix [(vL.p0), (p1.vR)] using the pipes of Heff."""
+        """theta (vL, p0, p1, vR) -> the form the matvec acts on: the matrix [(vL.p0), (p1.vR)] (pipes of Heff), or --
+        factored mode -- the un-fused tensor itself (an already fused theta is split)."""
+        if self.factored:
+            if theta.rank == 2:
+                theta = theta.split_legs()
+            return theta if list(theta.get_leg_labels()) == ['vL', 'p0', 'p1', 'vR'] else theta.transpose(['vL', 'p0', 'p1', 'vR'])
         return theta.combine_legs([['vL', 'p0'], ['p1', 'vR']], pipes=[self.pipeL, self.pipeR])
 
+    def prepare_svd(self, theta):
+        """The matrix [(vL.p0), (p1.vR)] that svd_theta / the mixer expect (fused once per bond in the factored mode)."""
+        if theta.rank == 2:
+            return theta
+        return theta.combine_legs([['vL', 'p0'], ['p1', 'vR']], pipes=[self.pipeL, self.pipeR])
+
+    def _matvec_factored(self, theta):
+        """theta [vL, p0, p1, vR] -> LP . theta . W0 W1 . RP with the same legs:
+        T1 = LP . theta (GEMM, contracted index = chi, not d chi);  T3 = MPO tensors applied blockwise (lincomb);
+        theta' = T3 . RP (GEMM, chain over wR and the bond sector)."""
+        fp = self._fplans
+        if fp is None or fp['key'] != theta._struct_key() or fp['dtype'] != theta.dtype:
+            p1, l_use, t_use = npc.plan_tensordot(self._LPf, theta, axes=['vR', 'vL'])
+            assert l_use is self._LPf and t_use is theta, "factored matvec step 1 must not need a transpose"
+            T1 = p1.apply(self._LPf, theta)                                    # vR*, wR, p0, p1, vR
+            a01 = MpoApplyPlan.get(T1, self.W0, 'wR', 'p0', 'wL', 'wR', 'p0', 'p0*', ('vR*', 'p0', 'p1', 'wR', 'vR'),
+                                   W2=self.W1, x_p2='p1', p2_out='p1', p2_in='p1*')   # both MPO tensors in ONE pass
+            T3 = a01.apply(T1)
+            p2, t3_use, r_use = npc.plan_tensordot(T3, self._RPf, axes=(['wR', 'vR'], ['wL', 'vL']))
+            assert t3_use is T3 and r_use is self._RPf, "factored matvec step 2 must not need a transpose"
+            self._fplans = dict(key=theta._struct_key(), dtype=theta.dtype, p1=p1, a01=a01, p2=p2)
+            if not p1.empty and not p2.empty:
+                self.flops_per_matvec = p1.flops + p2.flops
+                self.bytes_per_matvec = p1.bytes_min + p2.bytes_min + a01.bytes
+                self.gemm_shapes = (p1.gemm_shapes, p2.gemm_shapes)
+            res = p2.apply(T3, self._RPf)
+        else:
+            T1 = fp['p1'].apply(self._LPf, theta)
+            T3 = fp['a01'].apply(T1)
+            res = fp['p2'].apply(T3, self._RPf)
+        res.iset_leg_labels(['vL', 'p0', 'p1', 'vR'])
+        return res
+
     def matvec(self, theta):
-        """theta [(vL.p0), (p1.vR)] -> H_eff theta, same legs and labels."""
+        """theta [(vL.p0), (p1.vR)] (fused mode) or [vL, p0, p1, vR] (factored mode) -> H_eff theta, same legs and labels."""
+        if self.factored:
+            if theta.rank == 2:      # a fused vector handed to a factored operator (tests, parity checks)
+                return self.prepare_svd(self._matvec_factored(self.combine_theta(theta)))
+            return self._matvec_factored(theta)
         if self._plans is None or not self._plan_matches(theta):
             p1, l_use, t_use = npc.plan_tensordot(self.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])
             assert l_use is self.LHeff and t_use is theta, "matvec step 1 must not need a transpose"
@@ -229,6 +479,14 @@ class TwoSiteH:
     def update_LP(self, env, i, U=None):
         """LP(i0+1) = U^dagger LHeff U   (reference :1421)."""
         assert i == self.i0 + 1
+        if self.factored:       # LP' = A^dagger (LP . A) W0 without LHeff (reference MPOEnvironment._contract_LP, mpo.py:3087)
+            A = U.split_legs(['(vL.p0)'])                                        # vL, p0, vR
+            X = npc.tensordot(self.LP, A, axes=['vR', 'vL'])                     # vR*, wR, p0, vR
+            X = MpoApplyPlan.get(X, self.W0, 'wR', 'p0', 'wL', 'wR', 'p0', 'p0*', ('vR*', 'p0', 'wR', 'vR')).apply(X)
+            LP = npc.tensordot(A.conj(), X, axes=(['vL*', 'p0*'], ['vR*', 'p0']))   # vR*, wR, vR
+            LP = _relabel_view(LP, list(self.LP.get_leg_labels()))
+            env.set_LP(i, LP)
+            return LP
         LP = npc.tensordot(self.LHeff, U, axes=['(vR.p0*)', '(vL.p0)'])
         LP = npc.tensordot(U.conj(), LP, axes=['(vL*.p0*)', '(vR*.p0)'])      # vR*, wR, vR
         env.set_LP(i, LP)
@@ -237,6 +495,14 @@ class TwoSiteH:
     def update_RP(self, env, i, VH=None):
         """RP(i0) = RHeff VH VH^dagger   (reference :1430)."""
         assert i == self.i0
+        if self.factored:       # RP' = (B . RP) W1 B^dagger without RHeff (reference _contract_RP, mpo.py:3097)
+            B = VH.split_legs(['(p1.vR)'])                                       # vL, p1, vR
+            X = npc.tensordot(B, self.RP, axes=['vR', 'vL'])                     # vL, p1, wL, vL*
+            X = MpoApplyPlan.get(X, self.W1, 'wL', 'p1', 'wR', 'wL', 'p1', 'p1*', ('vL', 'wL', 'p1', 'vL*')).apply(X)
+            RP = npc.tensordot(X, B.conj(), axes=(['p1', 'vL*'], ['p1*', 'vR*']))   # vL, wL, vL*
+            RP = _relabel_view(RP, list(self.RP.get_leg_labels()))
+            env.set_RP(i, RP)
+            return RP
         RP = npc.tensordot(VH, self.RHeff, axes=['(p1.vR)', '(p1*.vL)'])      # vL, wL, (p1.vL*)
         RP = npc.tensordot(RP, VH.conj(), axes=['(p1.vL*)', '(p1*.vR*)'])     # vL, wL, vL*
         env.set_RP(i, RP)

@@ -100,7 +100,7 @@ class ShardedTwoSiteH(TwoSiteH):
     """TwoSiteH whose matvec is sharded over ``torch.distributed`` ranks by rows of theta'."""
 
     def __init__(self, env, i0, combine=True, move_right=True, group=None):
-        super().__init__(env, i0, combine, move_right)
+        super().__init__(env, i0, combine, move_right, factored=False)   # the row panels are panels of LHeff
         d = _dist()
         self.group = group
         self.world = d.get_world_size(group)

@@ -62,3 +62,48 @@ def test_fused_heff_equals_generic(backend, model, monkeypatch):
         fast.pipeL.test_equal(slow.pipeL)
         fast.pipeR.test_equal(slow.pipeR)
     assert used > 0, "the fused path must apply to fully charge-resolved MPOs"
+
+
+@pytest.mark.parametrize("model", ['xxz', 'tfi', 'hubbard'])
+def test_factored_matvec_equals_fused(backend, model):
+    """LP . theta . (W0 W1) . RP (two GEMM launches on the un-fused theta + one block-level linear combination per MPO
+    tensor) against LHeff . theta . RHeff, and the environment updates of both modes, on the environments of a DMRG state."""
+    from tenpy_amd.linalg import np_conserved as npc
+    eng = _engine(model)
+    L = eng.psi.L
+    for i0 in (0, 1, L // 2 - 1, L - 3, L - 2):
+        tensors = (eng.env.get_LP(i0), eng.env.get_RP(i0 + 1), eng.H.get_W(i0), eng.H.get_W(i0 + 1))
+        fac = mps_common.TwoSiteH(None, i0, tensors=tensors, factored=True)
+        fus = mps_common.TwoSiteH(None, i0, tensors=tensors, factored=False)
+        assert fac.factored and not fus.factored
+        th4 = eng.psi.get_theta(i0, n=2)
+        x4, x2 = fac.combine_theta(th4), fus.combine_theta(th4)
+        assert x4.rank == 4 and x2.rank == 2
+        for _ in range(2):                      # second call: cached plans
+            y4, y2 = fac.matvec(x4), fus.matvec(x2)
+        assert y4.get_leg_labels() == ['vL', 'p0', 'p1', 'vR']
+        a, b = fac.prepare_svd(y4).to_ndarray(), y2.to_ndarray()
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-13 * max(1., np.max(np.abs(b))))
+        # a fused vector handed to the factored operator
+        np.testing.assert_allclose(fac.matvec(x2).to_ndarray(), b, rtol=0, atol=1e-13 * max(1., np.max(np.abs(b))))
+        # Krylov-vector algebra on the un-fused form: same block structure in and out
+        z = y4.copy()
+        z.iadd_prefactor_other(-0.5, x4)
+        assert abs(npc.inner(z, z, axes='range', do_conj=True) - np.vdot(a - 0.5 * x2.to_ndarray(), a - 0.5 * x2.to_ndarray())) < 1e-10
+        # environment updates with isometries from an SVD of theta
+        U, S, VH = npc.svd(x2, inner_labels=['vR', 'vL'])
+
+        class Env:
+            def set_LP(self, i, t):
+                self.LP = t
+
+            def set_RP(self, i, t):
+                self.RP = t
+        e1, e2 = Env(), Env()
+        fac.update_LP(e1, i0 + 1, U)
+        fus.update_LP(e2, i0 + 1, U)
+        fac.update_RP(e1, i0, VH)
+        fus.update_RP(e2, i0, VH)
+        for t1, t2 in ((e1.LP, e2.LP), (e1.RP, e2.RP)):
+            assert t1.get_leg_labels() == t2.get_leg_labels()
+            np.testing.assert_allclose(t1.to_ndarray(), t2.to_ndarray(), rtol=0, atol=1e-12 * max(1., np.max(np.abs(t2.to_ndarray()))))

@@ -39,7 +39,7 @@ def _worker(rank, world, port, ret):
             assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= 1e-10 * abs(rec['E_sweeps'][s])
         # matvec: sharded == unsharded on this rank
         i0 = L // 2 - 1
-        ref_H = TwoSiteH(eng.env, i0)
+        ref_H = TwoSiteH(eng.env, i0, factored=False)      # same (fused) form as the sharded operator
         sh_H = ShardedTwoSiteH(eng.env, i0)
         theta = ref_H.combine_theta(psi.get_theta(i0, n=2))
         a, b = ref_H.matvec(theta), sh_H.matvec(theta)
