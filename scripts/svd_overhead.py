@@ -24,9 +24,11 @@ while c < chi:
     c = min(2 * c, chi)
     eng.trunc_params['chi_max'] = c
     eng.sweep()
+for _ in range(int(os.environ.get('EXTRA_SWEEPS', 0))):
+    eng.sweep()
 i0 = L // 2 - 1
 eff = TwoSiteH(eng.env, i0)
-theta = eff.combine_theta(psi.get_theta(i0, n=2))
+theta = eff.prepare_svd(eff.combine_theta(psi.get_theta(i0, n=2)))
 print("theta blocks", sorted([tuple(int(x) for x in s) for s in theta._block_shapes()], reverse=True)[:6], flush=True)
 
 
