@@ -480,6 +480,26 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__re
 // row reload and one pass over W.  Requirements (checked by the host, else the two-kernel round is used): every
 // workgroup of the launch is resident at the same time (spin wait!) and a part has at most 4 * FIT chunks.
 // A bounded spin (FUSED_SPIN_MAX polls) turns a lost sibling into an error code instead of a hang.
+// Up to 8 agent-coherent (sc1) loads issued back to back, ONE wait: reads data that sibling workgroups published with
+// write-through stores.  (A chain of __hip_atomic_load costs one memory round trip EACH; an acquire fence + plain loads
+// invalidates the XCD's L2 under every other workgroup: +25 % on the whole SVD.)
+__device__ __forceinline__ double sum_coherent(const double *base, int64_t stride, int n) {
+    double v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        v[p] = 0.0;
+        if (p < n) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[p]) : "v"(base + p * stride) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 :
+                 : "memory");
+    double t = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += v[p];      // fixed order; the slots p >= n hold 0
+    return t;
+}
+
 constexpr int FIT = 2;                      // chunks per wavefront kept in LDS
 constexpr unsigned FUSED_SPIN_MAX = 4000000u;
 
@@ -579,9 +599,7 @@ __global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__re
     }
     // ---- full Gram = sum of the partials in a fixed order (identical in every part)
     {
-        double sacc = 0;
-        for (int p = 0; p < E.nparts; ++p)     // coherent (sc1) loads: never served from a stale L1 / foreign-L2 line
-            sacc += __hip_atomic_load(&gpart[(first + p) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double sacc = sum_coherent(gpart + first * 256 + tid, 256, E.nparts);   // never served from a stale L1 / foreign-L2 line
         Sm[tid >> 4][tid & 15] = sacc;
         Qm[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
     }
