@@ -173,7 +173,7 @@ def main():
         per_launch_ms = gemm_ms / max(gt.n_launch, 1)
         traffic, traffic_note = None, None
         try:     # L2-miss traffic of the matvec GEMM measured with rocprofv3 PMC passes (committed profile, not live)
-            with open(os.path.join(ROOT, 'profiles', 'r01_gemm_pmc_matvec_chi2048.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r01_gemm_pmc_matvec_factored_chi2048.json')) as f:
                 pm = json.load(f)
             if chi == 2048:
                 traffic, traffic_note = pm["traffic_bytes_per_launch"], pm["how"]
