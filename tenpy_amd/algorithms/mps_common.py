@@ -272,6 +272,7 @@ class MpoApplyPlan:
         terms[:, 2] = np.ascontiguousarray(alpha.real).view(np.int64)
         terms[:, 3] = np.ascontiguousarray(alpha.imag).view(np.int64)
         assert len(jobs) <= 60000
+        self.jobs_host, self.terms_host, self.sizes = jobs, terms, sizes      # (row-restricted copies: algorithms/sharded.py)
         self.jobs_dev, self.terms_dev = dev.to_device(jobs), dev.to_device(terms)
         self.n_jobs, self.max_elems = len(jobs), int(np.max(sz))
         self.x_key = X._struct_key()

@@ -12,6 +12,10 @@ carries ~45 % of the flops, so sectors are split by rows, not assigned whole.  R
   2. computes theta'_r = T_r . RHeff                 (RHeff replicated; no exchange between the steps),
   3. takes part in ONE all-gather of the row panels  (the only collective on the data path).
 
+With the factored operator (``TwoSiteH.factored``, the default for charge-resolved MPOs) the same row partition is applied
+to its three steps: ``LP[rows_r] . theta`` (row panel of LP), the blockwise MPO application restricted to the rows of the
+panel, ``T3[rows_r] . RP``; every step is row-local, so there is again exactly one all-gather per matvec.
+
 Every rank then holds the full theta' and executes the (HBM-bound, cheap) Lanczos vector kernels and the
 tridiagonal eigen-solve redundantly on identical data, so alpha/beta need no scalar all-reduce and the
 control flow is identical on all ranks by construction.  SVD and environment update are replicated.
@@ -100,7 +104,7 @@ class ShardedTwoSiteH(TwoSiteH):
     """TwoSiteH whose matvec is sharded over ``torch.distributed`` ranks by rows of theta'."""
 
     def __init__(self, env, i0, combine=True, move_right=True, group=None):
-        super().__init__(env, i0, combine, move_right, factored=False)   # the row panels are panels of LHeff
+        super().__init__(env, i0, combine, move_right)      # factored when the MPO allows it, else row panels of LHeff
         d = _dist()
         self.group = group
         self.world = d.get_world_size(group)
@@ -141,9 +145,112 @@ class ShardedTwoSiteH(TwoSiteH):
         return dict(p1=p1, p2=p2, sp1=sp1, sp2=sp2, segs=all_segs, maxlen=max(maxlen, 1), tmp=tmp_full,
                     key=(theta._struct_key(), theta.dtype), bounds=bounds)
 
+    # ---- factored operator: LP[rows] . theta -> (W0 W1) blockwise on the panel rows -> T3[rows] . RP ---------------
+    def _build_sharded_factored(self, theta):
+        from .mps_common import MpoApplyPlan
+        p1, _, _ = npc.plan_tensordot(self._LPf, theta, axes=['vR', 'vL'])
+        if p1.empty:
+            return None
+        T1 = p1.apply(self._LPf, theta)                     # full product once per bond: fixes the block structure
+        a01 = MpoApplyPlan.get(T1, self.W0, 'wR', 'p0', 'wL', 'wR', 'p0', 'p0*', ('vR*', 'p0', 'p1', 'wR', 'vR'),
+                               W2=self.W1, x_p2='p1', p2_out='p1', p2_in='p1*')
+        if a01.empty:
+            return None
+        T3 = a01.apply(T1)
+        p2, _, _ = npc.plan_tensordot(T3, self._RPf, axes=(['wR', 'vR'], ['wL', 'vL']))
+        if p2.empty:
+            return None
+        leg0 = self._LPf.legs[0]
+        weights = np.zeros(leg0.ind_len)
+        for plan in (p1, p2):
+            tasks, links = plan.tasks_host, plan.links_host
+            for t in range(len(tasks)):
+                q = int(plan.res_qdata[t, 0])
+                s0, s1 = int(leg0.slices[q]), int(leg0.slices[q + 1])
+                ksum = float(np.sum(links[int(tasks[t][4]):int(tasks[t][4]) + int(tasks[t][5]), 2]))
+                weights[s0:s1] += ksum * float(tasks[t][2]) * (int(tasks[t][1]) // (s1 - s0))
+        bounds = row_partition(weights, self.world)
+        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        sp1 = restrict_plan_rows(p1, leg0, lo, hi)
+        sp2 = restrict_plan_rows(p2, leg0, lo, hi)
+        # the MPO application restricted to the panel rows: blocks are (n_a x ... x n_b) with the bond index a slowest
+        jobs, terms = a01.jobs_host.copy(), a01.terms_host.copy()
+        blk_of_job = np.searchsorted(a01.offsets, jobs[:, 0], side='right') - 1
+        keep = np.zeros(len(jobs), dtype=bool)
+        for jdx in range(len(jobs)):
+            b = int(blk_of_job[jdx])
+            q = int(a01.qdata[b, 0])
+            s0 = int(leg0.slices[q])
+            na = int(leg0.slices[q + 1]) - s0
+            rowlen = int(a01.sizes[b]) // na
+            r0, r1 = max(lo, s0) - s0, min(hi, s0 + na) - s0
+            if r1 <= r0:
+                continue
+            keep[jdx] = True
+            jobs[jdx, 0] += r0 * rowlen
+            jobs[jdx, 2] = jobs[jdx, 3] = (r1 - r0) * rowlen
+            tb, tc = int(jobs[jdx, 4]), int(jobs[jdx, 5])
+            terms[tb:tb + tc, 0] += r0 * rowlen
+            terms[tb:tb + tc, 1] = (r1 - r0) * rowlen
+        jobs = np.ascontiguousarray(jobs[keep])
+        all_segs = [restrict_plan_rows_segments(p2, leg0, int(bounds[r]), int(bounds[r + 1])) for r in range(self.world)]
+        maxlen = max(sum(n for _, n in segs) for segs in all_segs)
+        return dict(p1=p1, p2=p2, sp1=sp1, sp2=sp2, a01=a01, T1=T1, T3=T3, segs=all_segs, maxlen=max(maxlen, 1),
+                    key=(theta._struct_key(), theta.dtype), bounds=bounds, n_lin=len(jobs),
+                    lin_jobs=dev.to_device(jobs) if len(jobs) else None, lin_terms=dev.to_device(terms),
+                    lin_max=int(np.max(jobs[:, 2])) if len(jobs) else 0)
+
+    def _matvec_sharded_factored(self, theta):
+        if self._sharded is None or self._sharded['key'] != (theta._struct_key(), theta.dtype):
+            self._sharded = self._build_sharded_factored(theta)
+            if self._sharded is None:
+                return super().matvec(theta)
+            s = self._sharded
+            self.flops_per_matvec = s['p1'].flops + s['p2'].flops
+            self.bytes_per_matvec = s['p1'].bytes_min + s['p2'].bytes_min + s['a01'].bytes
+        s = self._sharded
+        T1, T3 = s['T1'], s['T3']
+        if not s['sp1'].local_empty:
+            s['sp1'].apply(self._LPf, theta, out_arena=T1._arena)
+        if s['n_lin']:
+            dev.check(dev.lib().tpa_lincomb_batch(dev.code(T3.dtype), s['lin_jobs'].data_ptr(), s['n_lin'], s['lin_terms'].data_ptr(),
+                                                  s['lin_max'], T1._arena.data_ptr(), T3._arena.data_ptr(), dev.stream()), "lincomb")
+        out_arena = dev.empty(s['p2'].res_total, s['p2'].dtype)
+        res = None
+        if not s['sp2'].local_empty:
+            res = s['sp2'].apply(T3, self._RPf, out_arena=out_arena)
+        if res is None:
+            res = npc.Array(list(theta.legs), s['p2'].dtype, theta.qtotal)
+            res._qdata, res._offsets, res._arena = s['p2'].res_qdata, s['p2'].res_offsets, out_arena
+            res._qdata_sorted = True
+        self._gather_rows(s, out_arena)
+        res.iset_leg_labels(['vL', 'p0', 'p1', 'vR'])
+        return res
+
+    def _gather_rows(self, s, out_arena):
+        """The one collective of a matvec: all-gather of the row panels (padded to the largest share)."""
+        send = dev.empty(s['maxlen'], s['p2'].dtype)
+        at = 0
+        for off, n in s['segs'][self.rank]:
+            send[at:at + n].copy_(out_arena[off:off + n])
+            at += n
+        recv = dev.empty(s['maxlen'] * self.world, s['p2'].dtype)
+        _dist().all_gather_into_tensor(recv, send, group=self.group)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            at = r * s['maxlen']
+            for off, n in s['segs'][r]:
+                out_arena[off:off + n].copy_(recv[at:at + n])
+                at += n
+
     def matvec(self, theta):
         if self.world == 1:
             return super().matvec(theta)
+        if self.factored:
+            if theta.rank == 2:
+                return self.prepare_svd(self._matvec_sharded_factored(self.combine_theta(theta)))
+            return self._matvec_sharded_factored(theta)
         if self._sharded is None or self._sharded['key'] != (theta._struct_key(), theta.dtype):
             self._sharded = self._build_sharded(theta)
             if self._sharded is None:
@@ -163,22 +270,7 @@ class ShardedTwoSiteH(TwoSiteH):
             res = npc.Array([self.LHeff.legs[0], self.RHeff.legs[2]], s['p2'].dtype, theta.qtotal)
             res._qdata, res._offsets, res._arena = s['p2'].res_qdata, s['p2'].res_offsets, out_arena
             res._qdata_sorted = True
-        # ---- the one collective: all-gather of the row panels (padded to the largest share) ----------
-        t = dev.torch()
-        send = dev.empty(s['maxlen'], s['p2'].dtype)
-        at = 0
-        for off, n in s['segs'][self.rank]:
-            send[at:at + n].copy_(out_arena[off:off + n])
-            at += n
-        recv = dev.empty(s['maxlen'] * self.world, s['p2'].dtype)
-        _dist().all_gather_into_tensor(recv, send, group=self.group)
-        for r in range(self.world):
-            if r == self.rank:
-                continue
-            at = r * s['maxlen']
-            for off, n in s['segs'][r]:
-                out_arena[off:off + n].copy_(recv[at:at + n])
-                at += n
+        self._gather_rows(s, out_arena)
         res.iset_leg_labels(['(vL.p0)', '(p1.vR)'])
         return res
 

@@ -39,14 +39,22 @@ def _worker(rank, world, port, ret):
             assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= 1e-10 * abs(rec['E_sweeps'][s])
         # matvec: sharded == unsharded on this rank
         i0 = L // 2 - 1
-        ref_H = TwoSiteH(eng.env, i0, factored=False)      # same (fused) form as the sharded operator
-        sh_H = ShardedTwoSiteH(eng.env, i0)
-        theta = ref_H.combine_theta(psi.get_theta(i0, n=2))
-        a, b = ref_H.matvec(theta), sh_H.matvec(theta)
-        np.testing.assert_array_equal(a._qdata, b._qdata)
-        np.testing.assert_array_equal(a.to_ndarray(), b.to_ndarray())
-        bounds = sh_H._sharded['bounds']
-        assert bounds[0] == 0 and bounds[-1] == ref_H.LHeff.legs[0].ind_len and np.all(np.diff(bounds) >= 0)
+        from tenpy_amd.algorithms import mps_common
+        for factored in (True, False):
+            mps_common.FACTORED_MATVEC = factored            # both forms of the operator, sharded vs unsharded
+            ref_H = TwoSiteH(eng.env, i0)
+            sh_H = ShardedTwoSiteH(eng.env, i0)
+            assert ref_H.factored == factored and sh_H.factored == factored
+            theta = ref_H.combine_theta(psi.get_theta(i0, n=2))
+            a, b = ref_H.matvec(theta), sh_H.matvec(theta)
+            a2, b2 = ref_H.matvec(theta), sh_H.matvec(theta)    # cached plans
+            np.testing.assert_array_equal(a._qdata, b._qdata)
+            np.testing.assert_array_equal(a.to_ndarray(), b.to_ndarray())
+            np.testing.assert_array_equal(a2.to_ndarray(), b2.to_ndarray())
+            bounds = sh_H._sharded['bounds']
+            n_rows = (ref_H._LPf if factored else ref_H.LHeff).legs[0].ind_len
+            assert bounds[0] == 0 and bounds[-1] == n_rows and np.all(np.diff(bounds) >= 0)
+        mps_common.FACTORED_MATVEC = True
         # every element of theta' is produced by exactly one rank
         segs = sh_H._sharded['segs']
         cover = np.zeros(sh_H._sharded['p2'].res_total, dtype=int)
