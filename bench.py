@@ -15,9 +15,9 @@ chi = 64, 128, ..., chi/2, followed by W warm-up sweeps at the target chi; then 
 timed between barrier + torch.cuda.synchronize() on both sides.
 
 Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU over RCCL): the Lanczos matvec is
-sharded over the ranks by rows of theta' (tenpy_amd/algorithms/sharded.py: row panels of both tensordots +
-one all-gather per matvec); SVD, environment update and the Lanczos vector kernels are replicated (DESIGN.md
-section 5).  Total work is fixed -> "scaling": "strong"; the value is the max over ranks of the time per sweep.
+sharded over the ranks by rows of theta' (tenpy_amd/algorithms/sharded.py: row panels of both GEMM steps +
+one all-gather per matvec), the charge blocks of every SVD are distributed (one all-gather); environment update and
+the Lanczos vector kernels are replicated.  Total work is fixed -> "scaling": "strong"; the value is the max over ranks of the time per sweep.
 
 One JSON line on rank 0; `roofline` is for the grouped MFMA GEMM (tensordot / Lanczos matvec kernel),
 `cpu_baseline` is the numpy oracle (oracle/npc_oracle.py) timed on the host cores on a bounded sample.
@@ -196,7 +196,7 @@ def main():
                "config": {"workload": "two-site DMRG sweep, spin-1/2 Heisenberg chain (XXZ Jxx=Jz=1, Sz conserved), L=%d, "
                                       "chi_max=%d (reached %d), Lanczos N=%d per bond, svd_min=1e-14, no mixer, combine=True interface (theta fused for the SVD; matvec applied in factored form); 1 step = 1 sweep = %d bond updates"
                                       % (L, chi, chi_reached, args.lanczos_N, 2 * (L - 2)),
-                          "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD/env replicated" % world},
+                          "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge blocks distributed (LPT + all-gather), env update replicated" % world},
                "E": E, "chi_reached": chi_reached, "prep_s": t_prep, "roofline": roof}
         if os.environ.get('TPA_BENCH_PHASES'):   # diagnostic run only: the phase timers synchronise the device
             out["phases_s"] = {k: round(v / max(args.steps, 1), 4) for k, v in eng.phase_time.items()}

@@ -40,6 +40,10 @@ class TwoSiteDMRGEngine:
         self.matvec_log = []
         self.hooks = {}
         self.shard_matvec = options.get('shard_matvec', False)
+        if self.shard_matvec:       # multi-GPU: also distribute the independent charge blocks of every SVD over the ranks
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                npc.SVD_DIST_GROUP = (None, dist.get_rank(), dist.get_world_size())
         self.profile = options.get('profile', False)
         self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
         self.mixer = None            # activated by run() / mixer_activate() (reference: pre_run_initialize :829)

@@ -1758,6 +1758,70 @@ def _blocked_matrix_jobs(a):
     return a._offsets.astype(np.int64), sh[:, 0].astype(np.int64), sh[:, 1].astype(np.int64)
 
 
+SVD_DIST_GROUP = None     # (torch.distributed group, rank, world) while a multi-GPU engine is active: charge blocks are independent
+
+
+def svd_block_owners(ms, ns, world):
+    """Longest-processing-time assignment of the charge blocks to ``world`` ranks (cost ~ m n min(m, n)); identical on all ranks."""
+    cost = ms.astype(np.float64) * ns * np.minimum(ms, ns)
+    owner = np.zeros(len(ms), dtype=np.int64)
+    load = np.zeros(world)
+    for b in np.argsort(-cost, kind='stable'):
+        r = int(np.argmin(load))
+        owner[b] = r
+        load[r] += cost[b]
+    return owner
+
+
+def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, sweeps):
+    """Every rank decomposes its share of the (independent) charge blocks, then ONE all-gather of the packed
+    [U blocks | S | VH blocks] of each rank makes the three result arenas complete and bit-identical everywhere
+    ("SVD: blocks distributed by LPT ... gather U/S/VH panels afterwards")."""
+    import torch
+    import torch.distributed as dist
+    group, rank, world = SVD_DIST_GROUP
+    owner = svd_block_owners(ms, ns, world)
+    mine = np.nonzero(owner == rank)[0]
+    if len(mine):
+        lj = np.ascontiguousarray(jobs[mine])
+        wb = L.tpa_svd_worksize(code, lj.ctypes.data, len(mine))
+        work = dev.empty(int(wb), np.uint8)
+        dev.check(L.tpa_svd_batch(code, lj.ctypes.data, len(mine), a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
+                                  V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
+                  "svd_batch")
+    cplx = 2 if np.dtype(a.dtype).kind == 'c' else 1
+    Uf = U_arena.view(torch.float64) if cplx == 2 else U_arena     # interleaved (re, im)
+    Vf = V_arena.view(torch.float64) if cplx == 2 else V_arena
+    # packed layout per rank: for each of its blocks (in block order)  U block, S block, VH block  as float64
+    sizes = cplx * (ms * ks + ks * ns) + ks
+    per_rank = [int(np.sum(sizes[owner == r])) for r in range(world)]
+    maxlen = max(max(per_rank), 1)
+    send = dev.zeros(maxlen, np.float64)
+
+    def pieces(b):
+        return ((Uf, cplx * int(jobs[b, 3]), cplx * int(ms[b] * ks[b])), (S_dev, int(jobs[b, 4]), int(ks[b])),
+                (Vf, cplx * int(jobs[b, 5]), cplx * int(ks[b] * ns[b])))
+    at = 0
+    for b in mine:
+        for buf, off, n in pieces(b):
+            send[at:at + n].copy_(buf[off:off + n])
+            at += n
+    recv = dev.empty(maxlen * world, np.float64)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    for r in range(world):
+        if r == rank:
+            continue
+        at = r * maxlen
+        for b in np.nonzero(owner == r)[0]:
+            for buf, off, n in pieces(b):
+                buf[off:off + n].copy_(recv[at:at + n])
+                at += n
+    sw = dev.zeros(1, np.float64)
+    sw.fill_(float(sweeps.value))
+    dist.all_reduce(sw, op=dist.ReduceOp.MAX, group=group)
+    sweeps.value = int(sw.item())
+
+
 def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, None], inner_labels=[None, None],
         inner_qconj=+1):
     """Block-wise SVD ``a = U diag(S) VH`` (reference np_conserved.py:3676, worker :4950).
@@ -1802,9 +1866,12 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
     work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
     sweeps = dev.c_int()
-    dev.check(L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
-                              V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
-              "svd_batch")
+    if SVD_DIST_GROUP is not None and nblk > 1:
+        _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, sweeps)
+    else:
+        dev.check(L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
+                                  V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
+                  "svd_batch")
     svd_stats['calls'] += 1
     svd_stats['sweeps'] += sweeps.value
     svd_stats['max_block'] = max(svd_stats['max_block'], int(np.max(ks)))

@@ -55,6 +55,19 @@ def _worker(rank, world, port, ret):
             n_rows = (ref_H._LPf if factored else ref_H.LHeff).legs[0].ind_len
             assert bounds[0] == 0 and bounds[-1] == n_rows and np.all(np.diff(bounds) >= 0)
         mps_common.FACTORED_MATVEC = True
+        # block SVD distributed over the ranks (LPT by block cost + one all-gather) == the local SVD, bit for bit
+        from tenpy_amd.linalg import np_conserved as npc
+        th2 = ref_H.prepare_svd(ref_H.combine_theta(psi.get_theta(i0, n=2)))
+        assert npc.SVD_DIST_GROUP is not None and npc.SVD_DIST_GROUP[2] == world
+        Ud, Sd, Vd = npc.svd(th2, inner_labels=['vR', 'vL'])
+        grp, npc.SVD_DIST_GROUP = npc.SVD_DIST_GROUP, None
+        Ul, Sl, Vl = npc.svd(th2, inner_labels=['vR', 'vL'])
+        npc.SVD_DIST_GROUP = grp
+        np.testing.assert_array_equal(Sd, Sl)
+        np.testing.assert_array_equal(Ud.to_ndarray(), Ul.to_ndarray())
+        np.testing.assert_array_equal(Vd.to_ndarray(), Vl.to_ndarray())
+        owners = npc.svd_block_owners(np.array([9, 5, 5, 2, 2, 1]), np.array([9, 5, 5, 2, 2, 1]), world)
+        assert set(owners.tolist()) == set(range(world))
         # every element of theta' is produced by exactly one rank
         segs = sh_H._sharded['segs']
         cover = np.zeros(sh_H._sharded['p2'].res_total, dtype=int)
