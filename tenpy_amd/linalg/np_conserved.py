@@ -1785,7 +1785,7 @@ def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, swee
     if len(mine):
         lj = np.ascontiguousarray(jobs[mine])
         wb = L.tpa_svd_worksize(code, lj.ctypes.data, len(mine))
-        work = dev.empty(int(wb), np.uint8)
+        work = dev.empty((int(wb) + 7) // 8, np.float64)        # wb bytes
         dev.check(L.tpa_svd_batch(code, lj.ctypes.data, len(mine), a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
                                   V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
                   "svd_batch")
