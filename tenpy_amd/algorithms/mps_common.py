@@ -25,7 +25,12 @@ __all__ = ['TwoSiteH', 'DensityMatrixMixer']
 
 
 FUSED_HEFF = True     # tuning / test hook: False forces the generic tensordot + combine_legs construction
-FACTORED_MATVEC = True   # tuning / test hook: False = always LHeff . theta . RHeff (the reference's combine=True form)
+import os as _os
+FACTORED_MATVEC = _os.environ.get('TPA_FACTORED_MATVEC', '1') != '0'   # tuning / test hook: False = always LHeff . theta . RHeff (the reference's combine=True form)
+# The factored form trades d times fewer flops for more and smaller GEMMs plus one extra pass: it pays when the GEMMs are
+# compute bound (Heisenberg chi=2048: 0.80 vs 1.37 ms per matvec) and loses when they are launch bound (chi=256: 0.75 vs
+# 0.54 s per sweep; Hubbard ladder chi=1024 with sectors <= 100 wide: 3.7 vs 1.5 s).  Automatic choice: largest bond sector.
+FACTORED_MIN_SECTOR = 200
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Fused construction of LHeff / RHeff:  LP.W0 (resp. W1.RP) + combine_legs in ONE kernel launch.
@@ -317,7 +322,10 @@ class TwoSiteH:
         self._LHeff = self._RHeff = None
         self._plans = None
         self._fplans = None
-        want = FACTORED_MATVEC if factored is None else factored
+        if factored is None:
+            want = FACTORED_MATVEC and int(np.max(self.LP.get_leg('vR').get_block_sizes())) >= FACTORED_MIN_SECTOR
+        else:
+            want = factored
         self.factored = bool(want) and self._factored_possible()
         if self.factored:       # pipes only (host bookkeeping); LHeff / RHeff are built on first access
             from ..linalg.charges import LegPipe

@@ -54,3 +54,28 @@ def test_dmrg_energies(backend, name):
         # every single bond update: same energy and same number of Lanczos iterations as the reference
         np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-10)
     assert abs(psi.norm_test() - 1.) < 1e-10
+
+
+@pytest.mark.parametrize("name", ['xxz_L12_chi20_hz', 'tfi_parity_L12_chi16'])
+def test_dmrg_energies_factored_operator(backend, name, monkeypatch):
+    """Same golden runs with the factored effective Hamiltonian LP . theta . (W0 W1) . RP forced on (by default it is
+    chosen only for bond sectors >= 200 wide): un-fused Krylov vectors, factored environment updates, theta fused for the SVD."""
+    from tenpy_amd.algorithms import mps_common
+    monkeypatch.setattr(mps_common, 'FACTORED_MIN_SECTOR', 0)
+    rec = RECS[name]
+    eng, psi = _setup(rec)
+    used = []
+    orig = mps_common.TwoSiteH.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        used.append(self.factored)
+    monkeypatch.setattr(mps_common.TwoSiteH, '__init__', spy)
+    for s in range(rec['n_sweeps']):
+        eng.sweep()
+        E, Eref = eng.sweep_stats['E'][-1], rec['E_sweeps'][s]
+        assert abs(E - Eref) <= 1e-10 * abs(Eref), (s, E, Eref)
+    assert used and all(used)
+    if backend == 'mock':
+        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-8)

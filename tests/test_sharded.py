@@ -40,6 +40,7 @@ def _worker(rank, world, port, ret):
         # matvec: sharded == unsharded on this rank
         i0 = L // 2 - 1
         from tenpy_amd.algorithms import mps_common
+        mps_common.FACTORED_MIN_SECTOR = 0                   # (small test blocks: do not fall back to the fused form)
         for factored in (True, False):
             mps_common.FACTORED_MATVEC = factored            # both forms of the operator, sharded vs unsharded
             ref_H = TwoSiteH(eng.env, i0)
