@@ -14,7 +14,7 @@ import numpy as np
 
 from ..linalg import np_conserved as npc
 from ..linalg.krylov_based import LanczosGroundState
-from ..linalg.truncation import svd_theta, TruncationError
+from ..linalg.truncation import svd_theta
 from ..networks.mpo import MPOEnvironment
 from .mps_common import DensityMatrixMixer, TwoSiteH
 

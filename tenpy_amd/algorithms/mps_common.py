@@ -19,6 +19,7 @@ MI355X-first differences:
 """
 import numpy as np
 
+from ..linalg import _device as dev
 from ..linalg import np_conserved as npc
 
 __all__ = ['TwoSiteH', 'DensityMatrixMixer']
@@ -53,7 +54,6 @@ def _mpo_entries(W):
 
 
 def _lincomb_into(dst, src, jobs, terms, max_elems):
-    from ..linalg import _device as dev
     if len(jobs) == 0:
         return
     L = dev.lib()
@@ -68,7 +68,6 @@ def _fused_heff(env_t, W, left):
     """``left``: LHeff [(vR*.p0), wR, (vR.p0*)] from LP [vR*, wR, vR] and W0 [wL, wR, p0, p0*];
     else RHeff [wL, (p1*.vL), (p1.vL*)] from RP [wL, vL, vL*] and W1 [wL, wR, p1, p1*].
     Returns (Heff, pipe) or ``None`` when the fast path does not apply (generic tensordot + combine_legs then)."""
-    from ..linalg import _device as dev
     from ..linalg.charges import LegPipe
     ent = _mpo_entries(W)
     pl = 'p0' if left else 'p1'
@@ -192,7 +191,6 @@ class MpoApplyPlan:
         return plan
 
     def __init__(self, X, W, x_w, x_p, w_in, w_out, p_out, p_in, out_labels, W2=None, x_p2=None, p2_out=None, p2_in=None):
-        from ..linalg import _device as dev
         ent = _mpo_entries(W)
         assert ent is not None
         wq, wv = ent
@@ -284,7 +282,6 @@ class MpoApplyPlan:
         self.bytes = 8 * (2 if self.dtype.kind == 'c' else 1) * (self.total + int(np.sum(sizes_x[ib])))
 
     def apply(self, X):
-        from ..linalg import _device as dev
         res = npc.Array(self.legs, self.dtype, self.qtotal, self.labels)
         if self.empty:
             return res

@@ -14,14 +14,13 @@ for the hot path of DMRG/TEBD, but with an MI355X-first data layout:
 
 Floating point data never goes through numpy on the product path; there is no CPU fallback.
 """
-import itertools
 import warnings
 from collections import OrderedDict
 
 import numpy as np
 
 from . import _device as dev
-from .charges import ChargeInfo, LegCharge, LegPipe, QTYPE, _find_row_differences, _partial_qtotal
+from .charges import ChargeInfo, LegCharge, LegPipe, _find_row_differences, _partial_qtotal
 
 __all__ = ['lq', 'eigvalsh', 'QCUTOFF', 'ChargeInfo', 'LegCharge', 'LegPipe', 'Array', 'zeros', 'eye_like', 'diag', 'outer', 'inner',
            'tensordot', 'svd', 'qr', 'eigh', 'norm', 'trace', 'to_iterable_arrays', 'TensordotPlan']
