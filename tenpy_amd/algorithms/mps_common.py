@@ -185,7 +185,7 @@ class MpoApplyPlan:
                tuple(sorted(kwargs.items())), tuple(X.get_leg_labels()))
         plan = cls._cache.get(key)
         if plan is None:
-            if len(cls._cache) > 512:
+            if len(cls._cache) > 4096:
                 cls._cache.clear()
             plan = cls._cache[key] = cls(X, W, *args, W2=W2, **kwargs)
         return plan

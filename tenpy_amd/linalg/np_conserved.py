@@ -1343,7 +1343,8 @@ class TensordotPlan:
 
 
 _plan_cache = OrderedDict()
-_PLAN_CACHE_SIZE = 512
+_PLAN_CACHE_SIZE = 8192     # a sweep over L=100 touches ~3000 distinct (bond, contraction) structures: an LRU smaller than that
+                            # never hits; the device tables of a plan are ~100 KB (<= 1 GB in total, HBM is 288 GB)
 
 
 class KernelTimer:
