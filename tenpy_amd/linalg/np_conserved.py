@@ -103,16 +103,30 @@ class Array:
         return sizes
 
     def _block_sizes_flat(self):
+        """Number of elements of every stored block.  Memoised on the identity of ``_qdata`` and of the legs (both are
+        replaced, never modified in place): the Lanczos vector kernels ask for it ~60 times per bond."""
+        c = self.__dict__.get('_sz_cache')
+        if c is not None and c[0] is self._qdata and len(c[1]) == len(self.legs) and all(x is y for x, y in zip(c[1], self.legs)):
+            return c[2]
         shapes = self._block_shapes()
-        return np.prod(shapes, axis=1) if len(shapes) else np.zeros(0, np.int64)
+        sizes = np.prod(shapes, axis=1) if len(shapes) else np.zeros(0, np.int64)
+        self._sz_cache = (self._qdata, tuple(self.legs), sizes)
+        return sizes
 
     def _is_packed(self):
-        """True if blocks are packed back to back in qdata order (then the arena is a flat vector)."""
+        """True if blocks are packed back to back in qdata order (then the arena is a flat vector).  Memoised like
+        ``_block_sizes_flat`` (plus the identity of ``_offsets`` and the arena size)."""
         sizes = self._block_sizes_flat()
         if len(sizes) == 0:
             return True
+        numel = self._arena.numel()
+        c = self.__dict__.get('_pk_cache')
+        if c is not None and c[0] is sizes and c[1] is self._offsets and c[2] == numel:
+            return c[3]
         exp = np.concatenate([[0], np.cumsum(sizes)[:-1]])
-        return np.array_equal(exp, self._offsets) and self._arena.numel() == int(np.sum(sizes))
+        res = bool(np.array_equal(exp, self._offsets) and numel == int(np.sum(sizes)))
+        self._pk_cache = (sizes, self._offsets, numel, res)
+        return res
 
     def _struct_key(self):
         """Hashable key of everything a contraction plan depends on (blocks, offsets, leg block sizes)."""
@@ -399,6 +413,8 @@ class Array:
         state = dict(self.__dict__)
         state['_arena'] = None if self._arena is None else dev.to_host(self._arena)
         state['_skey'] = None
+        state.pop('_sz_cache', None)
+        state.pop('_pk_cache', None)
         return state
 
     def __setstate__(self, state):
