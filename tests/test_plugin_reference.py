@@ -28,9 +28,14 @@ def _run_reference(tenpy, L, chi, n_sweeps, mixer=None):
             [np.array(psi.get_SL(i)) for i in range(1, L)], list(eng.update_stats['N_lanczos']))
 
 
-def test_plugin_reproduces_reference_dmrg(backend):
+@pytest.mark.parametrize("factored", [False, True])
+def test_plugin_reproduces_reference_dmrg(backend, factored, monkeypatch):
+    """factored: the device twin applies LP . theta . (W0 W1) . RP instead of LHeff . theta . RHeff (forced on here; by
+    default it is chosen for bond sectors >= 200 wide) -- the reference's own run is the judge for both forms."""
     if backend != 'mock':
         pytest.skip("reference tree is not on the GPU box")
+    from tenpy_amd.algorithms import mps_common
+    monkeypatch.setattr(mps_common, 'FACTORED_MIN_SECTOR', 0 if factored else 10**9)
     if REF not in sys.path:
         sys.path.insert(0, REF)
     with warnings.catch_warnings():
