@@ -14,6 +14,7 @@ for the hot path of DMRG/TEBD, but with an MI355X-first data layout:
 
 Floating point data never goes through numpy on the product path; there is no CPU fallback.
 """
+import functools
 import warnings
 from collections import OrderedDict
 
@@ -30,8 +31,9 @@ QCUTOFF = np.finfo(np.float64).eps * 10
 COPY_MAXDIM = 6
 
 
+@functools.lru_cache(maxsize=256)
 def _calc_dtype(*dtypes):
-    """float64 or complex128, like ``_find_calc_dtype`` (np_conserved.py:4396)."""
+    """float64 or complex128, like ``_find_calc_dtype`` (np_conserved.py:4396).  (Memoised: called ~50 times per bond.)"""
     res = np.result_type(*dtypes, np.float64)
     return np.dtype(np.complex128) if res.kind == 'c' else np.dtype(np.float64)
 
