@@ -32,3 +32,22 @@ for alg in [int(x) for x in os.environ.get('ALGS', '0,2').split(',')]:
     wr = np.linalg.eigvalsh(dense)
     print("alg=%d  eigh %.2f ms  max|w - w_ref| = %.2e" % (alg, dt * 1e3, np.abs(np.sort(w) - wr).max()), flush=True)
 _lib.load().tpa_svd_set_algorithm(0)
+
+# the mixer's case: rank-deficient graded PSD (theta theta^dagger + small perturbation), eigh vs the rank-revealing SVD route
+if os.environ.get('PSD', '1') == '1':
+    from tenpy_amd.algorithms.mps_common import DensityMatrixMixer
+    dense2 = dense - 1e-5 * np.eye(len(dense))
+    a2 = npc.Array.from_ndarray(dense2, [leg, leg.conj()])
+    wr = np.linalg.eigvalsh(dense2)
+    for via in (False, True):
+        mx = DensityMatrixMixer(1e-5, eigh_via_svd=via)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            w, v = mx._eigh_psd(a2)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+        vd = v.to_ndarray()
+        res = np.abs(dense2 @ vd - vd * w[None, :]).max()
+        print("psd via_svd=%s  %.2f ms  max|w - w_ref| = %.2e  max|A v - v w| = %.2e" %
+              (via, dt * 1e3, np.abs(np.sort(w) - wr).max(), res), flush=True)

@@ -144,6 +144,28 @@ def _fused_heff(env_t, W, left):
     return res, pipe
 
 
+def _reverse_columns(U):
+    """Rank-2 ``U`` with the columns of every block in reversed order (one strided slab copy per column, one launch)."""
+    res = npc.Array(U.legs, U.dtype, U.qtotal, list(U._labels))
+    res._set_blocks(U._qdata, zero=False, qdata_sorted=U._qdata_sorted)
+    if U.stored_blocks == 0:
+        return res
+    shapes = U._block_shapes()
+    m, k = shapes[:, 0], shapes[:, 1]
+    blk = np.repeat(np.arange(len(k)), k)
+    col = np.arange(len(blk)) - np.repeat(np.cumsum(k) - k, k)
+    jobs = np.zeros((len(blk), 8), dtype=np.int64)
+    jobs[:, 0] = res._offsets[blk] + col
+    jobs[:, 1], jobs[:, 2], jobs[:, 3] = m[blk], 1, k[blk]
+    jobs[:, 4], jobs[:, 5] = np.arange(len(blk)), 1
+    terms = np.zeros((len(blk), 4), dtype=np.int64)
+    terms[:, 0] = U._offsets[blk] + (k[blk] - 1 - col)
+    terms[:, 1] = k[blk]
+    terms[:, 2] = np.array([1.0]).view(np.int64)[0]
+    _lincomb_into(res, U, jobs, terms, int(np.max(m)))
+    return res
+
+
 def _relabel_view(A, labels):
     """``A`` with its legs in the order ``labels`` WITHOUT moving data: allowed when only legs with 1-wide blocks change
     their position relative to the others (the memory layout of every block is then unchanged); bookkeeping only."""
@@ -533,8 +555,9 @@ class DensityMatrixMixer:
     """
 
     def __init__(self, amplitude=1.e-5, IdL=0, IdR=-1, explicit_plus_hc=False, decay=2., disable_after=15,
-                 sweep_activated=0):
+                 sweep_activated=0, eigh_via_svd=True):
         assert amplitude <= 1.
+        self.eigh_via_svd = eigh_via_svd
         self.amplitude = amplitude
         self.IdL, self.IdR = IdL, IdR
         self.explicit_plus_hc = explicit_plus_hc
@@ -593,6 +616,26 @@ class DensityMatrixMixer:
             rho_R = npc.tensordot(theta.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
         return rho_L, rho_R
 
+    def _eigh_psd(self, rho):
+        """Eigenvalues and eigenvectors (as columns) of a positive semi-definite density matrix.
+
+        ``npc.eigh`` (reference :2047 / :2055) runs an un-preconditioned Jacobi iteration on the shifted matrix: ~22 sweeps
+        over ALL rows.  The density matrices of the mixer are theta theta^dagger plus a small perturbation: rank <= chi
+        of d chi and strongly graded, i.e. exactly what the rank-revealing path of the block SVD is made for -- and for a
+        PSD matrix the SVD ``rho = U S U^dagger`` IS the eigendecomposition (S = eigenvalues, U = eigenvectors).
+        Eigenvalues below 1e-15 ||rho|| come back as exact zeros with zero vectors; they are masked out by the caller
+        (with ``npc.eigh`` they are rounding noise that the truncation discards as well)."""
+        if not self.eigh_via_svd:
+            return npc.eigh(rho)
+        U, S, _ = npc.svd(rho, inner_labels=[None, None], inner_qconj=rho.legs[0].qconj)   # -> U.legs[1] == legs[0].conj()
+        # ascending order inside every block, as LAPACK's / the reference's eigh returns it (the order of the new bond
+        # basis inside a charge sector is a gauge choice, but a deterministic one of the reference: keep it)
+        val = np.array(S, dtype=np.float64)
+        sl = U.legs[1].slices
+        for q in range(len(sl) - 1):
+            val[sl[q]:sl[q + 1]] = val[sl[q]:sl[q + 1]][::-1]
+        return val, _reverse_columns(U)
+
     def svd_from_rho(self, rho_L, rho_R, theta, trunc_params, qtotal_LR=None):
         """Diagonalise rho_L / rho_R and rewrite theta = U S VH with isometric U, VH and a bond MATRIX S."""
         from ..linalg.truncation import truncate
@@ -606,20 +649,22 @@ class DensityMatrixMixer:
             qR = chinfo.make_valid(theta.qtotal - qL)
         rho_L = rho_L.transpose(['(vL.p0)', '(vL*.p0*)'])
         rho_R = rho_R.transpose(['(p1.vR)', '(p1*.vR*)'])
-        val_L, U = npc.eigh(rho_L)
+        val_L, U = self._eigh_psd(rho_L)
         U.iset_leg_labels(['(vL.p0)', 'vR'])
         val_L[val_L < 0.] = 0.
         val_L /= np.sum(val_L)
         S_a = np.sqrt(val_L)
         keep_L, _, err_L = truncate(S_a, trunc_params)
+        keep_L = keep_L & (val_L > 0.)          # (exact zeros of the rank-revealing path carry zero vectors)
         U.iproject(keep_L, axes='vR')
         U = U.gauge_total_charge(1, qL)
-        val_R, Vc = npc.eigh(rho_R)
+        val_R, Vc = self._eigh_psd(rho_R)
         Vc.iset_leg_labels(['(p1.vR)', 'vL'])
         VH = Vc.itranspose(['vL', '(p1.vR)'])
         val_R[val_R < 0.] = 0.
         val_R /= np.sum(val_R)
         keep_R, _, err_R = truncate(np.sqrt(val_R), trunc_params)
+        keep_R = keep_R & (val_R > 0.)
         VH.iproject(keep_R, axes='vL')
         VH = VH.gauge_total_charge(0, qR)
         S = npc.tensordot(U.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
