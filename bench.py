@@ -201,7 +201,7 @@ def main():
         if os.environ.get('TPA_BENCH_PHASES'):   # diagnostic run only: the phase timers synchronise the device
             out["phases_s"] = {k: round(v / max(args.steps, 1), 4) for k, v in eng.phase_time.items()}
             out["svd_stats"] = dict(npc.svd_stats)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the other ranks would idle at the barrier)
             try:
                 out["cpu_baseline"] = cpu_baseline(eng, args, gpu_bond_s)
             except Exception as e:  # the baseline must never kill the bench line

@@ -235,7 +235,12 @@ class ShardedTwoSiteH(TwoSiteH):
             send[at:at + n].copy_(out_arena[off:off + n])
             at += n
         recv = dev.empty(s['maxlen'] * self.world, s['p2'].dtype)
-        _dist().all_gather_into_tensor(recv, send, group=self.group)
+        if np.dtype(s['p2'].dtype).kind == 'c':       # RCCL has no complex type: ship interleaved (re, im) doubles
+            import torch
+            f64 = torch.float64
+            _dist().all_gather_into_tensor(recv.view(f64), send.view(f64), group=self.group)
+        else:
+            _dist().all_gather_into_tensor(recv, send, group=self.group)
         for r in range(self.world):
             if r == self.rank:
                 continue
