@@ -16,9 +16,9 @@ from ..linalg import np_conserved as npc
 from ..linalg.krylov_based import LanczosGroundState
 from ..linalg.truncation import svd_theta
 from ..networks.mpo import MPOEnvironment
-from .mps_common import DensityMatrixMixer, TwoSiteH
+from .mps_common import DensityMatrixMixer, OneSiteH, SubspaceExpansion, TwoSiteH
 
-__all__ = ['TwoSiteDMRGEngine', 'run']
+__all__ = ['TwoSiteDMRGEngine', 'SingleSiteDMRGEngine', 'run']
 
 
 class TwoSiteDMRGEngine:
@@ -261,6 +261,107 @@ class TwoSiteDMRGEngine:
             E_old = E
         self.mixer_cleanup()
         return self.sweep_stats['E'][-1], self.psi
+
+
+class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
+    """Single-site DMRG (reference dmrg.py:955-1139): the effective Hamiltonian acts on ONE site (``OneSiteH``), the SVD
+    of the optimised theta shifts the orthogonality centre, and the subspace expansion (default mixer, switched on by
+    default like ``use_mixer_by_default = True`` :976) lets the bond dimension grow.  Moving right the bond (i0, i0+1)
+    and the tensors of sites i0 and i0+1 are updated, moving left the bond (i0-1, i0) and sites i0-1, i0
+    (``_update_env_inds``, mps_common.py:595).  Shares sweep / run / checkpoint / mixer-cleanup logic with the two-site
+    engine."""
+
+    def mixer_activate(self):
+        which = self.options.get('mixer', True)
+        if not which:
+            return
+        mp = dict(self.options.get('mixer_params', {}))
+        kw = dict(decay=mp.get('decay', 2.), disable_after=mp.get('disable_after', 15), sweep_activated=self.sweeps)
+        if which is True or which == 'SubspaceExpansion':
+            self.mixer = SubspaceExpansion(mp.get('amplitude', 1.e-5), self.H.IdL, self.H.IdR, **kw)
+        else:
+            raise NotImplementedError("tenpy_amd: single-site DMRG supports the SubspaceExpansion mixer (or none)")
+
+    def get_sweep_schedule(self):
+        L = self.psi.L                      # reference mps_common.py:438-443 with n = 1
+        i0s = list(range(0, L - 1)) + list(range(L - 1, 0, -1))
+        move_right = [True] * (L - 1) + [False] * (L - 1)
+        update_LP_RP = [[True, False]] * (L - 1) + [[False, True]] * (L - 1)
+        return list(zip(i0s, move_right, update_LP_RP))
+
+    def mixed_svd(self, eff_H, theta, i0, move_right):
+        """Reference dmrg.py:996-1110.  Returns U [(vL.p), vR], S (1-D host array, or a 2-D bond matrix with a mixer),
+        VH [vL, (p.vR)], err, S_approx."""
+        psi = self.psi
+        if move_right:
+            nxt = psi.get_B(i0 + 1, 'B').combine_legs(['p', 'vR'], qconj=-1, new_axes=1)
+        else:
+            nxt = psi.get_B(i0 - 1, 'A').combine_legs(['vL', 'p'], qconj=+1, new_axes=0)
+        if self.mixer is None:
+            qtotal = [theta.qtotal, None] if move_right else [None, theta.qtotal]
+            U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=qtotal, inner_labels=['vR', 'vL'])
+            S_a = S
+            if move_right:       # VH is at most a truncation: VH.next_B stays right-canonical
+                VH = npc.tensordot(VH, nxt, axes=['vR', 'vL'])
+                U.ireplace_label('(vL.p0)', '(vL.p)')
+            else:
+                U = npc.tensordot(nxt, U, axes=['vR', 'vL'])
+                VH.ireplace_label('(p0.vR)', '(p.vR)')
+        else:
+            U, S, VH, err = self.mixer.mix_and_decompose_1site(eff_H, theta, self.trunc_params, move_right)
+            S_a = S
+            if move_right:       # the (non-isometric) VH goes into the bond matrix; the old next_B stays
+                S = VH.scale_axis(S, 'vL')
+                VH = nxt
+                U.ireplace_label('(vL.p0)', '(vL.p)')
+            else:
+                S = U.scale_axis(S, 'vR')
+                U = nxt
+                VH.ireplace_label('(p0.vR)', '(p.vR)')
+        return U, S, VH, err, S_a
+
+    def update_bond(self, i0, move_right=True, update_LP=True, update_RP=False):
+        t0 = time.time()
+        psi = self.psi
+        tick = self._tick
+        tick(None)
+        eff_H = OneSiteH(self.env, i0, combine=True, move_right=move_right)
+        theta = eff_H.combine_theta(psi.get_theta(i0, n=1))
+        tick('heff')
+        E0, theta, N = LanczosGroundState(eff_H, theta, self.lanczos_params).run()
+        tick('lanczos')
+        U, S, VH, err, S_a = self.mixed_svd(eff_H, theta, i0, move_right)
+        tick('svd')
+        i_L, i_R = (i0, i0 + 1) if move_right else (i0 - 1, i0)
+        self.env.del_LP(i_R)
+        self.env.del_RP(i_L)
+        if update_LP:
+            eff_H.update_LP(self.env, i_R, U)
+        if update_RP:
+            eff_H.update_RP(self.env, i_L, VH)
+        tick('env')
+        psi.set_B(i_L, U.split_legs(['(vL.p)']), form='A')
+        psi.set_B(i_R, VH.split_legs(['(p.vR)']), form='B')
+        psi.set_SR(i_L, S)
+        tick('setB')
+        for j in range(i_R + 1, psi.L):      # environments built from the old tensors are stale now
+            if self.env._LP[j] is None:
+                break
+            self.env._LP[j] = None
+        for j in range(i_L - 1, -1, -1):
+            if self.env._RP[j] is None:
+                break
+            self.env._RP[j] = None
+        us = self.update_stats
+        us['i0'].append(i0)
+        us['E_total'].append(float(E0))
+        us['N_lanczos'].append(N)
+        us['time'].append(time.time() - t0)
+        us['err'].append(err.eps)
+        us['chi'].append(len(S_a))
+        us['flops'].append(eff_H.flops_per_matvec)
+        us['bytes'].append(eff_H.bytes_per_matvec)
+        return err
 
 
 def run(psi, model_H, options):

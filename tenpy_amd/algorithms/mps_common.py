@@ -22,7 +22,7 @@ import numpy as np
 from ..linalg import _device as dev
 from ..linalg import np_conserved as npc
 
-__all__ = ['TwoSiteH', 'DensityMatrixMixer']
+__all__ = ['TwoSiteH', 'OneSiteH', 'DensityMatrixMixer', 'SubspaceExpansion']
 
 
 FUSED_HEFF = True     # tuning / test hook: False forces the generic tensordot + combine_legs construction
@@ -545,6 +545,124 @@ class TwoSiteH:
         return full.reshape(n, n)
 
 
+class OneSiteH:
+    """One-site effective Hamiltonian ``LP - W0 - RP`` of single-site DMRG (reference mps_common.py:1040-1243), in the
+    ``combine=True`` form: moving right, ``LHeff = LP.W0`` [(vR*.p0), wR, (vR.p0*)] acts on theta [(vL.p0), vR]; moving
+    left, ``RHeff = W0.RP`` [wL, (p0*.vL), (p0.vL*)] acts on theta [vL, (p0.vR)].  Both halves come from the same fused
+    builder (and the same per-(side, site) cache) as the two-site operator; a matvec is two planned block GEMM launches."""
+    length = 1
+
+    def __init__(self, env, i0, combine=True, move_right=True, tensors=None):
+        if not combine:
+            raise NotImplementedError("tenpy_amd.OneSiteH: only combine=True")
+        self.i0 = i0
+        self.combine = combine
+        self.move_right = move_right
+        if tensors is not None:
+            self.LP, self.RP, W0 = tensors
+            self.dtype = W0.dtype
+        else:
+            self.LP = env.get_LP(i0)
+            self.RP = env.get_RP(i0)
+            W0 = env.H.get_W(i0)
+            self.dtype = env.H.dtype
+        self.W0 = W0.replace_labels(['p', 'p*'], ['p0', 'p0*'])
+        self.W0._tpa_entries = _mpo_entries(W0)
+        self._env = env if tensors is None else None
+        self.N = self.LP.get_leg('vR').ind_len * self.W0.get_leg('p0').ind_len * self.RP.get_leg('vL').ind_len
+        self.flops_per_matvec = None
+        self.bytes_per_matvec = None
+        self.combine_Heff(self._env)
+
+    def combine_Heff(self, env=None):
+        cache = getattr(env, '_heff_cache', None) if env is not None else None
+        if self.move_right:
+            hit = cache.get(('L', self.i0)) if cache is not None else None
+            if hit is not None and hit[0] is self.LP:
+                _, self.LHeff, self.pipeL = hit
+            else:
+                fused = _fused_heff(self.LP, self.W0, True) if FUSED_HEFF else None
+                if fused is not None:
+                    self.LHeff, self.pipeL = fused
+                else:
+                    LHeff = npc.tensordot(self.LP, self.W0, axes=['wR', 'wL'])
+                    self.pipeL = pipeL = LHeff.make_pipe(['vR*', 'p0'], qconj=+1)
+                    self.LHeff = LHeff.combine_legs([['vR*', 'p0'], ['vR', 'p0*']], pipes=[pipeL, pipeL.conj()], new_axes=[0, 2])
+                if cache is not None:
+                    cache[('L', self.i0)] = (self.LP, self.LHeff, self.pipeL)
+            self.acts_on = ['(vL.p0)', 'vR']
+        else:
+            W1 = self.W0.replace_labels(['p0', 'p0*'], ['p1', 'p1*'])          # (the right half is built with 'p1' labels)
+            W1._tpa_entries = self.W0._tpa_entries
+            hit = cache.get(('R', self.i0)) if cache is not None else None
+            if hit is not None and hit[0] is self.RP:
+                _, RHeff, pipeR = hit
+            else:
+                fused = _fused_heff(self.RP, W1, False) if FUSED_HEFF else None
+                if fused is not None:
+                    RHeff, pipeR = fused
+                else:
+                    RHeff = npc.tensordot(W1, self.RP, axes=['wR', 'wL'])
+                    pipeR = RHeff.make_pipe(['p1', 'vL*'], qconj=-1)
+                    RHeff = RHeff.combine_legs([['p1*', 'vL'], ['p1', 'vL*']], pipes=[pipeR.conj(), pipeR], new_axes=[1, 2])
+                if cache is not None:
+                    cache[('R', self.i0)] = (self.RP, RHeff, pipeR)
+            self._RHeff_p1 = RHeff                                             # what the mixer asks for (reference :1893)
+            self.RHeff = RHeff.replace_labels(['(p1*.vL)', '(p1.vL*)'], ['(p0*.vL)', '(p0.vL*)'])
+            self.pipeR = pipeR
+            self.acts_on = ['vL', '(p0.vR)']
+
+    def combine_theta(self, theta):
+        if self.move_right:
+            theta = theta.combine_legs(['vL', 'p0'], pipes=self.pipeL)
+        else:
+            theta = theta.combine_legs(['p0', 'vR'], pipes=self.pipeR)
+        return theta if list(theta.get_leg_labels()) == self.acts_on else theta.transpose(self.acts_on)
+
+    def matvec(self, theta):
+        """Reference :1118-1151 (combine branch)."""
+        if self.move_right:
+            tmp = npc.tensordot(self.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])            # (vR*.p0), wR, vR
+            res = npc.tensordot(tmp, self.RP, axes=[['wR', 'vR'], ['wL', 'vL']])            # (vR*.p0), vL*
+            res.ireplace_labels(['(vR*.p0)', 'vL*'], ['(vL.p0)', 'vR'])
+        else:
+            tmp = npc.tensordot(theta, self.RHeff, axes=['(p0.vR)', '(p0*.vL)'])            # vL, wL, (p0.vL*)
+            res = npc.tensordot(self.LP, tmp, axes=[['vR', 'wR'], ['vL', 'wL']])            # vR*, (p0.vL*)
+            res.ireplace_labels(['vR*', '(p0.vL*)'], ['vL', '(p0.vR)'])
+        return res if list(res.get_leg_labels()) == self.acts_on else res.transpose(self.acts_on)
+
+    def update_LP(self, env, i, U=None):
+        """Reference :1226.  Moving right: LP(i0+1) = U^dagger LHeff U; otherwise the generic contraction."""
+        if self.move_right:
+            assert i == self.i0 + 1
+            LP = npc.tensordot(self.LHeff, U, axes=['(vR.p0*)', '(vL.p)'])
+            LP = npc.tensordot(U.conj(), LP, axes=['(vL*.p*)', '(vR*.p0)'])                 # vR*, wR, vR
+            env.set_LP(i, LP)
+            return LP
+        return env.get_LP(i, store=True)
+
+    def update_RP(self, env, i, VH=None):
+        """Reference :1235.  Moving left: RP(i0-1) = RHeff VH VH^dagger."""
+        if self.move_right is False:
+            assert i == self.i0 - 1
+            RP = npc.tensordot(VH, self.RHeff, axes=['(p.vR)', '(p0*.vL)'])                 # vL, wL, (p0.vL*)
+            RP = npc.tensordot(RP, VH.conj(), axes=['(p0.vL*)', '(p*.vR*)'])                # vL, wL, vL*
+            env.set_RP(i, RP)
+            return RP
+        return env.get_RP(i, store=True)
+
+    def to_matrix(self):
+        """Dense effective Hamiltonian on the host (tests only), rows/columns in the order of ``acts_on``."""
+        if self.move_right:
+            full = np.tensordot(self.LHeff.to_ndarray(), self.RP.transpose(['wL', 'vL*', 'vL']).to_ndarray(), axes=([1], [0]))
+        else:
+            full = np.tensordot(self.LP.transpose(['vR*', 'wR', 'vR']).to_ndarray(),
+                                self.RHeff.transpose(['wL', '(p0.vL*)', '(p0*.vL)']).to_ndarray(), axes=([1], [0]))
+        full = full.transpose(0, 2, 1, 3)        # out_L, out_R, in_L, in_R
+        n = full.shape[0] * full.shape[1]
+        return full.reshape(n, n)
+
+
 class DensityMatrixMixer:
     """Density-matrix perturbation ("mixer") of two-site DMRG -- the npc call sequence of the reference's
     ``DensityMatrixMixer.mix_rho`` / ``svd_from_rho`` (mps_common.py:1972-2079): four tensordots with the
@@ -672,3 +790,54 @@ class DensityMatrixMixer:
         S.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
         S.iscale_prefactor(1. / S.norm())
         return U, S, VH, err_L + err_R, S_a[keep_L]
+
+
+class SubspaceExpansion:
+    """Direct subspace expansion (Hubig et al. 2015) -- the default mixer of single-site DMRG; the npc call sequence of
+    the reference's ``SubspaceExpansion.mix_and_decompose_1site`` (mps_common.py:2082-2201): theta is stacked with
+    ``amplitude**0.5 * (H_eff half) theta`` along the MPO leg (one ``scale_axis`` + one tensordot), the stacked
+    matrix goes through ``svd_theta``, and the MPO leg of the non-isometric factor is projected back onto the identity
+    index with ``take_slice``.  MPOs with ``explicit_plus_hc`` (the stacking branch :2152-2167) are not supported."""
+    can_decompose_1site = True
+
+    def __init__(self, amplitude=1.e-5, IdL=0, IdR=-1, explicit_plus_hc=False, decay=2., disable_after=15, sweep_activated=0):
+        assert amplitude <= 1.
+        if explicit_plus_hc or IdL is None or IdR is None:
+            raise NotImplementedError("tenpy_amd.SubspaceExpansion: needs IdL / IdR and an MPO without explicit_plus_hc")
+        self.amplitude = amplitude
+        self.IdL, self.IdR = IdL, IdR
+        self.explicit_plus_hc = explicit_plus_hc
+        self.decay, self.disable_after, self.sweep_activated = decay, disable_after, sweep_activated
+
+    update_amplitude = DensityMatrixMixer.update_amplitude
+
+    def _mix_LR(self, chi_MPO):
+        amp = np.sqrt(self.amplitude)            # sqrt: `amplitude` then means the same as for the density-matrix mixer
+        mix_L, mix_R = np.full((chi_MPO,), amp), np.full((chi_MPO,), amp)
+        mix_L[self.IdL], mix_R[self.IdL] = 1., 0.
+        mix_L[self.IdR], mix_R[self.IdR] = 0., 1.
+        return mix_L, mix_R
+
+    def mix_and_decompose_1site(self, eff_H, theta, trunc_params, move_right):
+        from ..linalg.truncation import svd_theta
+        if move_right:
+            LHeff = eff_H.LHeff
+            chi_MPO = LHeff.get_leg('wR').ind_len
+            mix_L, _ = self._mix_LR(chi_MPO)
+            th = npc.tensordot(LHeff.scale_axis(mix_L, 'wR'), theta, axes=['(vR.p0*)', '(vL.p0)'])   # (vR*.p0), wR, vR
+            th.ireplace_label('(vR*.p0)', '(vL.p0)')
+            th = th.combine_legs(['wR', 'vR'], qconj=-1)
+            U, S, VH, err, _ = svd_theta(th, trunc_params, qtotal_LR=[theta.qtotal, None], inner_labels=['vR', 'vL'])
+            VH = VH.split_legs('(wR.vR)')
+            VH = VH.take_slice(self.IdL % chi_MPO, 'wR')      # back to the original theta = U S VH (up to truncation)
+        else:
+            RHeff = eff_H._RHeff_p1 if getattr(eff_H, 'length', 2) == 1 else eff_H.RHeff
+            chi_MPO = RHeff.get_leg('wL').ind_len
+            _, mix_R = self._mix_LR(chi_MPO)
+            th = npc.tensordot(theta, RHeff.scale_axis(mix_R, 'wL'), axes=['(p0.vR)', '(p1*.vL)'])   # vL, wL, (p1.vL*)
+            th.ireplace_label('(p1.vL*)', '(p0.vR)')
+            th = th.combine_legs(['vL', 'wL'], qconj=+1)
+            U, S, VH, err, _ = svd_theta(th, trunc_params, qtotal_LR=[None, theta.qtotal], inner_labels=['vR', 'vL'])
+            U = U.split_legs('(vL.wL)')
+            U = U.take_slice(self.IdR % chi_MPO, 'wL')
+        return U, S, VH, err

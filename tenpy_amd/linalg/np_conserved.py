@@ -1155,6 +1155,46 @@ class Array:
                                                   self._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "gather")
         return res
 
+    def take_slice(self, indices, axes):
+        """Copy of ``self`` with the (flat) ``indices`` fixed on the legs ``axes``, which are dropped: for rank 4,
+        ``A.take_slice([i, j], [1, 2]) == A[:, i, j, :]`` (reference :1037).  Per axis: the gather kernel of ``iproject``
+        with a one-entry mask, then the leg of length 1 is removed from the bookkeeping (the memory layout of a block does
+        not change when a dimension of size 1 is dropped)."""
+        axes = self.get_leg_indices(_to_iterable(axes))
+        indices = np.asarray(_to_iterable(indices), dtype=np.intp)
+        if len(axes) != len(indices):
+            raise ValueError("len(axes) != len(indices)")
+        if indices.ndim != 1:
+            raise ValueError("indices may only contain ints")
+        if len(axes) == 0:
+            return self.copy(deep=True)
+        if len(axes) == self.rank:
+            raise ValueError("can't have 0-rank tensors")       # (the reference returns a scalar via __getitem__ for this)
+        cur = self
+        qtotal = self.qtotal.copy()
+        for a, i in zip(axes, indices):
+            leg = self.legs[a]
+            if not -leg.ind_len <= i < leg.ind_len:
+                raise IndexError("flat index %d out of bounds for leg of length %d" % (i, leg.ind_len))
+            i = int(i) % leg.ind_len
+            qi, _ = leg.get_qindex(i)
+            qtotal = qtotal - leg.get_charge(qi)
+            m = np.zeros(leg.ind_len, dtype=np.bool_)
+            m[i] = True
+            map_qind, _, new_leg = leg.project(m)
+            cur = cur._project_axis(a, m, map_qind, new_leg)
+        if cur is self or cur._arena is self._arena:
+            cur = cur.copy(deep=True)
+        keep_axes = [a for a in range(self.rank) if a not in axes]
+        res = cur.copy(deep=False)
+        res.legs = [cur.legs[a] for a in keep_axes]
+        res._set_shape()
+        res._labels = [self._labels[a] for a in keep_axes]
+        res.qtotal = self.chinfo.make_valid(qtotal)
+        res._qdata = np.ascontiguousarray(cur._qdata[:, keep_axes])
+        res._skey = None
+        return res
+
     # ---- misc ------------------------------------------------------------------------------------------------------------
     def gauge_total_charge(self, axis, newqtotal=None, new_qconj=None):
         """Change ``qtotal`` by shifting the charges of one leg (reference :1198)."""

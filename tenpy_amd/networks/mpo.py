@@ -32,39 +32,79 @@ class MPO:
         return [W.get_leg('wR').ind_len for W in self._W[:-1]]
 
 
-def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64):
-    """Build a finite MPO from dense ``W[i]`` of shape (D_l, D_r, d, d); the charges of the virtual MPO
-    legs are deduced from the non-zero entries (every entry must conserve charge), first leg = charge 0."""
+def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64, IdL=0, IdR=-1):
+    """Build a finite MPO from dense ``W[i]`` of shape (D_l, D_r, d, d).  The charges of the virtual MPO legs are deduced
+    from the non-zero entries (every entry must conserve charge) in two passes: forward from the left boundary (index
+    ``IdL`` of the first leg = charge 0) and backward from the right boundary (index ``IdR`` of the last leg = charge 0).
+    An index that neither pass reaches cannot contribute to any contraction; its entries are dropped.  An index reached
+    from one side only is kept: e.g. the "only identities to the right" state on the bond right of the first site when
+    no one-site term exists -- the subspace expansion relies on ``W[IdR, IdR] = 1`` being there on every site."""
     L = len(W_dense_list)
+    Ws_d = [np.array(Wd) for Wd in W_dense_list]
+    nq = chinfo.qnumber
+    pqs = [p.to_qflat() * p.qconj for p in p_legs]
+
+    def entries(Wd):
+        nz = np.abs(Wd) > 1e-15
+        out = {}
+        for a, b, s, t in np.argwhere(nz):
+            out.setdefault((int(a), int(b)), (int(s), int(t)))       # first non-zero physical entry of each (a, b)
+        return out
+    ents = [entries(Wd) for Wd in Ws_d]
+    # charge rule of an entry: q_a - q_b + p[s] - p[t] = 0
+    fq = [np.zeros((Ws_d[0].shape[0], nq), dtype=np.int64)]
+    fk = [np.zeros(Ws_d[0].shape[0], dtype=bool)]
+    fk[0][IdL % Ws_d[0].shape[0]] = True
+    if Ws_d[0].shape[0] == 1:
+        fk[0][:] = True
+    for i in range(L):
+        Dr = Ws_d[i].shape[1]
+        q, k = np.zeros((Dr, nq), dtype=np.int64), np.zeros(Dr, dtype=bool)
+        for (a, b), (s_, t_) in sorted(ents[i].items()):
+            if not fk[i][a]:
+                continue
+            qb = chinfo.make_valid(fq[i][a] + pqs[i][s_] - pqs[i][t_])
+            if k[b] and np.any(q[b] != qb):
+                raise ValueError("MPO entry (%d,%d) on site %d violates charge conservation" % (a, b, i))
+            q[b], k[b] = qb, True
+        fq.append(q)
+        fk.append(k)
+    bq = [None] * (L + 1)
+    bk = [None] * (L + 1)
+    Dlast = Ws_d[-1].shape[1]
+    bq[L], bk[L] = np.zeros((Dlast, nq), dtype=np.int64), np.zeros(Dlast, dtype=bool)
+    bk[L][IdR % Dlast] = True
+    if Dlast == 1:
+        bk[L][:] = True
+    for i in range(L - 1, -1, -1):
+        Dl = Ws_d[i].shape[0]
+        q, k = np.zeros((Dl, nq), dtype=np.int64), np.zeros(Dl, dtype=bool)
+        for (a, b), (s_, t_) in sorted(ents[i].items()):
+            if not bk[i + 1][b]:
+                continue
+            qa = chinfo.make_valid(bq[i + 1][b] - pqs[i][s_] + pqs[i][t_])
+            if k[a] and np.any(q[a] != qa):
+                raise ValueError("MPO entry (%d,%d) on site %d violates charge conservation" % (a, b, i))
+            q[a], k[a] = qa, True
+        bq[i], bk[i] = q, k
+    bond_q, bond_k = [], []
+    for j in range(L + 1):
+        both = fk[j] & bk[j]
+        if np.any(fq[j][both] != bq[j][both]):
+            raise ValueError("MPO charges deduced from the left and from the right disagree on bond %d" % j)
+        bond_q.append(np.where(fk[j][:, None], fq[j], bq[j]))
+        bond_k.append(fk[j] | bk[j])
     Ws = []
-    q_left = np.zeros((W_dense_list[0].shape[0], chinfo.qnumber), dtype=np.int64)
-    known_left = np.ones(W_dense_list[0].shape[0], dtype=bool)
-    for i, Wd in enumerate(W_dense_list):
-        Wd = np.array(Wd)
-        Wd[~known_left] = 0.          # states that cannot be reached from the left never contribute
-        Dl, Dr, d, _ = Wd.shape
+    for i, Wd in enumerate(Ws_d):
+        Wd[~bond_k[i]] = 0.
+        Wd[:, ~bond_k[i + 1]] = 0.
         p = p_legs[i]
-        pq = p.to_qflat() * p.qconj
-        q_right = np.zeros((Dr, chinfo.qnumber), dtype=np.int64)
-        known = np.zeros(Dr, dtype=bool)
-        for a in range(Dl):
-            for b in range(Dr):
-                nz = np.argwhere(np.abs(Wd[a, b]) > 1e-15)
-                if len(nz) == 0:
-                    continue
-                s, t = nz[0]
-                # charge rule: q_a*(+1) + q_b*(-1) + p[s] - p[t] = 0
-                qb = chinfo.make_valid(q_left[a] + pq[s] - pq[t])
-                if known[b] and np.any(q_right[b] != qb):
-                    raise ValueError("MPO entry (%d,%d) on site %d violates charge conservation" % (a, b, i))
-                q_right[b], known[b] = qb, True
-        wL = LegCharge.from_qflat(chinfo, chinfo.make_valid(q_left), qconj=+1)
-        wR = LegCharge.from_qflat(chinfo, chinfo.make_valid(q_right), qconj=-1)
-        W = npc.Array.from_ndarray(Wd, [wL, wR, p, p.conj()], dtype=dtype, qtotal=None if chinfo.qnumber == 0 else chinfo.make_valid(),
+        wL = LegCharge.from_qflat(chinfo, chinfo.make_valid(bond_q[i]), qconj=+1)
+        wR = LegCharge.from_qflat(chinfo, chinfo.make_valid(bond_q[i + 1]), qconj=-1)
+        W = npc.Array.from_ndarray(Wd, [wL, wR, p, p.conj()], dtype=dtype, qtotal=None if nq == 0 else chinfo.make_valid(),
                                    labels=['wL', 'wR', 'p', 'p*'])
         Ws.append(W)
-        q_left, known_left = q_right, known
-    return MPO(p_legs, Ws)
+    return MPO(p_legs, Ws, IdL, IdR)
 
 
 class MPOEnvironment:

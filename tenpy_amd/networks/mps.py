@@ -102,7 +102,10 @@ class MPS:
         return B
 
     def get_theta(self, i, n=2, formL=1., formR=1.):
-        """Two-site wave function with labels ``'vL', 'p0', 'p1', 'vR'`` (reference mps.py:3041)."""
+        """Two-site wave function with labels ``'vL', 'p0', 'p1', 'vR'``, or the one-site one ``'vL', 'p0', 'vR'``
+        (reference mps.py:3041; n=1: ``get_B(i, (1., 1.))`` :3075)."""
+        if n == 1:
+            return self.get_B(i, (formL, formR)).replace_label('p', 'p0')
         assert n == 2
         B0 = self._B[i]
         B0 = self._scale_axis_B(B0, self._S[i], formL - self.form[i][0], 'vL')

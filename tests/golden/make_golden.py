@@ -436,7 +436,53 @@ def gen_dmrg_mixer():
     save('dmrg_mixer.pkl', out)
 
 
-GENERATORS = dict(dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_dmrg_single():
+    """Single-site DMRG (OneSiteH, combine=True): (a) from a product state with the SubspaceExpansion mixer,
+    (b) two two-site sweeps first, then single-site sweeps without any mixer.  Energies of every update, truncation
+    errors, mixer schedule, final Schmidt spectra after mixer_cleanup."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for (L, Jz, hz, chi, amp, decay, dis, n_sweeps, pre2) in ((12, 1.3, 0., 16, 1.e-3, 2., 4, 7, 0), (10, 0.7, 0.2, 12, 1.e-2, 1.5, 3, 6, 0),
+                                                                  (12, 1.0, 0., 14, None, None, None, 3, 2)):
+            M = XXZChain({'L': L, 'Jxx': 1., 'Jz': Jz, 'hz': hz, 'bc_MPS': 'finite', 'sort_charge': True})
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+            E_pre = []
+            if pre2:
+                e2 = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
+                                                     'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}})
+                for s in range(pre2):
+                    e2.sweep()
+                    E_pre.append(float(e2.update_stats['E_total'][-1]))
+            opts = {'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6 if amp else 1.e-10}}
+            if amp:
+                opts.update(mixer=True, mixer_params={'amplitude': amp, 'decay': decay, 'disable_after': dis})
+            else:
+                opts.update(mixer=None)
+            eng = dmrg.SingleSiteDMRGEngine(psi, M, opts)
+            eng.mixer_activate()
+            Es, mixer_on = [], []
+            for s in range(n_sweeps):
+                mixer_on.append(eng.mixer is not None)
+                eng.sweep()
+                Es.append(float(eng.update_stats['E_total'][-1]))
+            eng.mixer_cleanup()
+            out.append(dict(L=L, Jxx=1., Jz=Jz, hz=hz, chi=chi, amplitude=amp, decay=decay, disable_after=dis, n_sweeps=n_sweeps,
+                            pre_two_site_sweeps=pre2, E_pre=E_pre, E_sweeps=Es, mixer_on=mixer_on,
+                            i0_updates=[int(i) for i in eng.update_stats['i0']],
+                            E_updates=[float(e) for e in eng.update_stats['E_total']],
+                            err_updates=[float(e.eps) for e in eng.update_stats['err']],
+                            chi_final=[int(c) for c in psi.chi],
+                            S=[np.array(psi.get_SL(i)) for i in range(1, L)], S_ent=np.array(psi.entanglement_entropy()),
+                            E_mpo=float(np.real(M.H_MPO.expectation_value(psi))), svd_min=opts['trunc_params']['svd_min']))
+            print('dmrg_single', L, Es, mixer_on, psi.chi)
+    save('dmrg_single.pkl', out)
+
+
+GENERATORS = dict(dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
