@@ -85,9 +85,13 @@ class TwoSiteDMRGEngine:
         which = self.options.get('mixer', False)
         if not which:
             return
-        if which is not True and which != 'DensityMatrixMixer':
-            raise NotImplementedError("tenpy_amd: only the DensityMatrixMixer is available for the two-site engine")
         mp = dict(self.options.get('mixer_params', {}))
+        if which == 'SubspaceExpansion':
+            self.mixer = SubspaceExpansion(mp.get('amplitude', 1.e-5), self.H.IdL, self.H.IdR, decay=mp.get('decay', 2.),
+                                           disable_after=mp.get('disable_after', 15), sweep_activated=self.sweeps)
+            return
+        if which is not True and which != 'DensityMatrixMixer':
+            raise NotImplementedError("tenpy_amd: mixers are 'DensityMatrixMixer' (default) and 'SubspaceExpansion'")
         self.mixer = DensityMatrixMixer(mp.get('amplitude', 1.e-5), self.H.IdL, self.H.IdR,
                                         decay=mp.get('decay', 2.), disable_after=mp.get('disable_after', 15),
                                         sweep_activated=self.sweeps)
@@ -189,8 +193,13 @@ class TwoSiteDMRGEngine:
             S_a = S
         else:       # reference dmrg.py:921-929: perturbed density matrices, S is a general bond matrix
             qtotal_LR = [qtotal_i0, theta.chinfo.make_valid(theta.qtotal - qtotal_i0)]
-            rho_L, rho_R = self.mixer.mix_rho(eff_H, theta, update_LP, update_RP)
-            U, S, VH, err, S_a = self.mixer.svd_from_rho(rho_L, rho_R, theta, self.trunc_params, qtotal_LR)
+            if isinstance(self.mixer, DensityMatrixMixer):
+                rho_L, rho_R = self.mixer.mix_rho(eff_H, theta, update_LP, update_RP)
+                U, S, VH, err, S_a = self.mixer.svd_from_rho(rho_L, rho_R, theta, self.trunc_params, qtotal_LR)
+            else:   # mixers that only know the one-site decomposition (reference Mixer.mix_and_decompose_2site :1764)
+                U, S, VH, err, S_a = self.mixer.mix_and_decompose_2site(eff_H, theta, self.trunc_params, update_LP, update_RP,
+                                                                        qtotal_LR)
+                # (like the reference, the factor on the non-mixed side is stored as it comes: not an isometry)
         tick('svd')
         if update_LP:
             eff_H.update_LP(self.env, i1, U)

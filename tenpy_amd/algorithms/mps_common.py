@@ -841,3 +841,39 @@ class SubspaceExpansion:
             U = U.split_legs('(vL.wL)')
             U = U.take_slice(self.IdR % chi_MPO, 'wL')
         return U, S, VH, err
+
+    def mix_and_decompose_2site(self, eff_H, theta, trunc_params, mix_left, mix_right, qtotal_LR=None):
+        """Two-site theta [(vL.p0), (p1.vR)] decomposed with the one-site expansion on the side(s) to be mixed (reference
+        ``Mixer.mix_and_decompose_2site`` :1764-1822): only the tensor on a mixed side is an isometry, the other factor
+        goes into the bond matrix / stays non-canonical exactly like in the reference."""
+        if mix_left and mix_right:
+            qtotal_L, qtotal_R = (None, None) if qtotal_LR is None else qtotal_LR
+            if qtotal_L is None and qtotal_R is None:
+                qtotal_L, qtotal_R = theta.chinfo.make_valid(), theta.qtotal
+            elif qtotal_L is None:
+                qtotal_L = theta.chinfo.make_valid(theta.qtotal - qtotal_R)
+            elif qtotal_R is None:
+                qtotal_R = theta.chinfo.make_valid(theta.qtotal - qtotal_L)
+            U, _, _, err_L = self.mix_and_decompose_1site(eff_H, theta.replace_label('(p1.vR)', 'vR'), trunc_params, True)
+            U = U.gauge_total_charge(1, qtotal_L)
+            th_R = theta.replace_labels(['(vL.p0)', '(p1.vR)'], ['vL', '(p0.vR)'])
+            _, S_approx, VH, err_R = self.mix_and_decompose_1site(eff_H, th_R, trunc_params, False)
+            VH = VH.gauge_total_charge(0, qtotal_R)
+            VH.ireplace_label('(p0.vR)', '(p1.vR)')
+            S = npc.tensordot(U.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
+            S = npc.tensordot(S, VH.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
+            S.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
+            _, sv, _ = npc.svd(S)
+            S = S / np.linalg.norm(sv)
+            return U, S, VH, err_L + err_R, S_approx
+        if mix_left:
+            U, S, VH, err = self.mix_and_decompose_1site(eff_H, theta.replace_label('(p1.vR)', 'vR'), trunc_params, True)
+            VH.ireplace_label('vR', '(p1.vR)')          # VH is not isometric
+            return U, S, VH, err, S
+        if mix_right:
+            th_R = theta.replace_labels(['(vL.p0)', '(p1.vR)'], ['vL', '(p0.vR)'])
+            U, S, VH, err = self.mix_and_decompose_1site(eff_H, th_R, trunc_params, False)
+            U.ireplace_label('vL', '(vL.p0)')           # U is not isometric
+            VH.ireplace_label('(p0.vR)', '(p1.vR)')
+            return U, S, VH, err, S
+        raise ValueError("Expected mix_left=True and/or mix_right=True.")

@@ -482,7 +482,36 @@ def gen_dmrg_single():
     save('dmrg_single.pkl', out)
 
 
-GENERATORS = dict(dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_dmrg_two_site_subspace():
+    """Two-site DMRG with mixer='SubspaceExpansion' (Mixer.mix_and_decompose_2site falling back to the one-site
+    decomposition)."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for (L, Jz, hz, chi, amp, decay, dis, n_sweeps) in ((12, 1.3, 0., 16, 1.e-3, 2., 3, 5), ):
+            M = XXZChain({'L': L, 'Jxx': 1., 'Jz': Jz, 'hz': hz, 'bc_MPS': 'finite', 'sort_charge': True})
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+            eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': 'SubspaceExpansion', 'mixer_params': {'amplitude': amp, 'decay': decay, 'disable_after': dis},
+                                                  'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6}})
+            eng.mixer_activate()
+            Es, mixer_on = [], []
+            for s in range(n_sweeps):
+                mixer_on.append(eng.mixer is not None)
+                eng.sweep()
+                Es.append(float(eng.update_stats['E_total'][-1]))
+            eng.mixer_cleanup()
+            out.append(dict(L=L, Jxx=1., Jz=Jz, hz=hz, chi=chi, amplitude=amp, decay=decay, disable_after=dis, n_sweeps=n_sweeps,
+                            E_sweeps=Es, mixer_on=mixer_on, E_updates=[float(e) for e in eng.update_stats['E_total']],
+                            err_updates=[float(e.eps) for e in eng.update_stats['err']],
+                            S=[np.array(psi.get_SL(i)) for i in range(1, L)], svd_min=1.e-6))
+            print('dmrg_two_site_subspace', L, Es, mixer_on)
+    save('dmrg_two_site_subspace.pkl', out)
+
+
+GENERATORS = dict(dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

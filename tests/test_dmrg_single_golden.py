@@ -107,3 +107,22 @@ def test_take_slice(backend):
         np.testing.assert_array_equal(r.to_ndarray(), full[tuple(sl)])
         assert r.get_leg_labels() == [l for l in ['a', 'b', 'c', 'd'] if a.get_leg_index(l) not in a.get_leg_indices(axes)]
     np.testing.assert_array_equal(a.to_ndarray(), full)      # operand untouched
+
+
+def test_two_site_dmrg_with_subspace_expansion(backend):
+    """Two-site engine with mixer='SubspaceExpansion' (reference ``Mixer.mix_and_decompose_2site`` fallback)."""
+    for rec in golden('dmrg_two_site_subspace.pkl'):
+        L, H, psi = _setup(rec)
+        eng = TwoSiteDMRGEngine(psi, H, {'mixer': 'SubspaceExpansion', 'mixer_params': {'amplitude': rec['amplitude'], 'decay': rec['decay'],
+                                                                                         'disable_after': rec['disable_after']},
+                                         'trunc_params': {'chi_max': rec['chi'], 'svd_min': rec['svd_min']}, 'lanczos_params': {}})
+        eng.mixer_activate()
+        for s in range(rec['n_sweeps']):
+            assert (eng.mixer is not None) == rec['mixer_on'][s]
+            eng.sweep()
+            assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= 1e-10 * abs(rec['E_sweeps'][s])
+        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(eng.update_stats['err'], rec['err_updates'], rtol=0, atol=1e-11)
+        eng.mixer_cleanup()
+        for i in range(1, L):
+            np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i - 1])[::-1], rtol=0, atol=1e-9)
