@@ -19,7 +19,7 @@ from . import np_conserved as npc
 
 logger = logging.getLogger(__name__)
 
-__all__ = ['LanczosGroundState', 'lanczos']
+__all__ = ['LanczosGroundState', 'LanczosEvolution', 'lanczos', 'gram_schmidt', 'iscale_prefactor', 'iadd_prefactor_other']
 
 
 class LanczosGroundState:
@@ -173,6 +173,79 @@ class LanczosGroundState:
             beta = h[k, k + 1]
             w.iscale_prefactor(1. / beta)
             psif.iadd_prefactor_other(vf[k + 1], w)
+
+
+class LanczosEvolution(LanczosGroundState):
+    """``exp(delta H) |psi0>`` from the same Krylov recurrence (reference :718-822): instead of the ground state of the
+    tridiagonal ``h`` take ``exp(delta h) e_0``; converged when the last Krylov component drops below ``P_tol``.
+    The device work is identical to the ground-state search (matvec + the fused vector update per iteration)."""
+
+    def __init__(self, H, psi0, options):
+        super().__init__(H, psi0, options)
+        self._result_norm = 1.
+        self.delta = None
+
+    def run(self, delta, normalize=None):
+        """Returns ``(psi_f, N)``; ``normalize`` defaults to ``real(delta) == 0`` (unitary evolution)."""
+        self.delta = delta
+        N = self._build_krylov()
+        if N == 1:
+            result_full = self.psi0 * self._result_krylov[0]      # only a phase
+        else:
+            result_full = self._calc_result_full(N)
+        if normalize is None:
+            normalize = np.real(delta) == 0.
+        if normalize:
+            return result_full, N
+        return result_full * (self._psi0_norm * self._result_norm), N
+
+    def _calc_result_krylov(self, k):
+        h, delta = self._h_krylov, self.delta
+        if k == 0:
+            exp_dE = np.exp(delta * h[0, 0])
+            self._result_norm = np.abs(exp_dE)
+            self._result_krylov = np.array([exp_dE / self._result_norm])
+        else:
+            E_kr, v_kr = np.linalg.eigh(h[:k + 1, :k + 1])
+            exp_dH_e0 = np.dot(v_kr, np.exp(E_kr * delta) * np.conj(v_kr[0, :]))
+            self._result_norm = np.linalg.norm(exp_dH_e0)
+            self._result_krylov = exp_dH_e0 / self._result_norm
+
+    def _converged(self, k):
+        return np.abs(self._result_krylov[k]) < self.P_tol
+
+
+def gram_schmidt(vecs, rcond=1.e-14):
+    """In-place Gram-Schmidt ortho-normalisation of a list of Arrays with the same leg order (reference :858); vectors
+    whose remainder has norm <= ``rcond`` are dropped."""
+    res = []
+    for vec in vecs:
+        for other in res:
+            ov = npc.inner(other, vec, axes='range', do_conj=True)
+            iadd_prefactor_other(vec, -ov, other)
+        n = npc.norm(vec)
+        if n > rcond:
+            iscale_prefactor(vec, 1. / n)
+            res.append(vec)
+    return res
+
+
+def iscale_prefactor(w, scale):
+    """``w *= scale`` for an Array or a list of Arrays (reference :888)."""
+    if not isinstance(w, list):
+        w.iscale_prefactor(scale)
+    else:
+        for a in w:
+            a.iscale_prefactor(scale)
+
+
+def iadd_prefactor_other(w, alpha, v):
+    """``w += alpha v`` for Arrays or lists of Arrays (reference :896)."""
+    if not isinstance(w, list):
+        w.iadd_prefactor_other(alpha, v)
+    else:
+        for a, b in zip(w, v):
+            a.iadd_prefactor_other(alpha, b)
 
 
 def lanczos(H, psi, options={}, orthogonal_to=[]):

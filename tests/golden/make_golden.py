@@ -511,7 +511,42 @@ def gen_dmrg_two_site_subspace():
     save('dmrg_two_site_subspace.pkl', out)
 
 
-GENERATORS = dict(dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_krylov2():
+    """LanczosEvolution (real / imaginary / complex time step, normalised or not, short cache) and gram_schmidt."""
+    out = []
+    ch = charges.ChargeInfo([2])
+    r2 = np.random.RandomState(777)
+    for n, cplx in ((20, False), (30, True)):
+        leg = charges.LegCharge.from_qflat(ch, r2.randint(0, 2, size=n).reshape(n, 1)).bunch()[1]
+
+        def rnd(legs, qtotal=None, labels=None):
+            def f(size):
+                x = r2.standard_normal(size)
+                return x + 1.j * r2.standard_normal(size) if cplx else x
+            a = npc.Array.from_func(f, legs, dtype=np.complex128 if cplx else np.float64, qtotal=qtotal, shape_kw='size')
+            a.iset_leg_labels(labels)
+            return a
+        H = rnd([leg, leg.conj()], labels=['a', 'a*'])
+        H = H + H.conj().itranspose()
+        psi0 = rnd([leg], qtotal=[1], labels=['a'])
+
+        class Op:
+            def matvec(self, v):
+                return npc.tensordot(H, v, axes=['a*', 'a'])
+        for delta, opts, normalize in ((-0.1j, {}, None), (-0.05, {}, None), (0.02 - 0.03j, {'N_max': 30, 'N_cache': 3}, True),
+                                       (-0.2j, {'N_min': 4, 'N_max': 4}, False)):
+            psi, N = krylov_based.LanczosEvolution(Op(), psi0, dict(opts)).run(delta, normalize)
+            out.append(dict(kind='evolution', H=dump_array(H), psi0=dump_array(psi0), options=opts, delta=delta, normalize=normalize,
+                            N=int(N), psi=dump_array(psi)))
+        vecs = [rnd([leg], qtotal=[1], labels=['a']) for _ in range(4)]
+        vecs.insert(2, vecs[0] * 2. - vecs[1] * 0.5)       # linearly dependent: must be dropped
+        dumped = [dump_array(v) for v in vecs]
+        res = krylov_based.gram_schmidt([v.copy(deep=True) for v in vecs])
+        out.append(dict(kind='gram_schmidt', vecs=dumped, res=[dump_array(v) for v in res]))
+    save('krylov2.pkl', out)
+
+
+GENERATORS = dict(krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

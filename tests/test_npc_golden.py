@@ -95,3 +95,26 @@ def test_lanczos_golden(backend):
         ref = rec['psi']['dense']
         ov = abs(np.vdot(ref, psi.to_ndarray()))
         assert abs(ov - 1.) < 1e-10
+
+
+def test_krylov2_golden(backend):
+    """LanczosEvolution and gram_schmidt vs the reference (tests/golden/make_golden.py:gen_krylov2)."""
+    from tenpy_amd.linalg.krylov_based import LanczosEvolution, gram_schmidt
+    for rec in golden('krylov2.pkl'):
+        if rec['kind'] == 'evolution':
+            H, psi0 = load_array(rec['H']), load_array(rec['psi0'])
+
+            class Op:
+                def matvec(self, v):
+                    return npc.tensordot(H, v, axes=['a*', 'a'])
+            psi, N = LanczosEvolution(Op(), psi0, dict(rec['options'])).run(rec['delta'], rec['normalize'])
+            assert N == rec['N']
+            ref = rec['psi']['dense']
+            np.testing.assert_allclose(psi.to_ndarray(), ref, rtol=0, atol=1e-11 * max(1., np.abs(ref).max()))
+            np.testing.assert_array_equal(psi0.to_ndarray(), rec['psi0']['dense'])      # start vector untouched
+        else:
+            vecs = [load_array(v) for v in rec['vecs']]
+            res = gram_schmidt(vecs)
+            assert len(res) == len(rec['res'])
+            for v, r in zip(res, rec['res']):
+                np.testing.assert_allclose(v.to_ndarray(), r['dense'], rtol=0, atol=1e-9)
