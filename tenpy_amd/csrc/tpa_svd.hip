@@ -87,7 +87,13 @@ __global__ __launch_bounds__(64) void svd_fro_sum_kernel(const double *__restric
 // ~eps*||A||_F/tol (strongly graded spectra, e.g. DMRG wave functions) and needs 5x more sweeps.
 __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2, double tol, double floor2) {
     if (!(a > 0.0) || !(b > 0.0)) return false;
-    const double mn = fmin(a, b), mx = fmax(fmax(a, b), floor2);
+    const double mn = fmin(a, b), mx0 = fmax(a, b);
+    // A row 1e-30 times shorter than its partner (<= 1e-30 ||A||_F) is a zero row for every purpose.  Without this cut a
+    // row that lies EXACTLY in the span of the others (exactly rank-deficient block with no room for rounding noise:
+    // zero columns, bond matrices of the subspace expansion) shrinks by ~eps per sweep until |row|^2 is denormal;
+    // there tol^2*mn*mx underflows to 0, zeta^2 overflows (rotation angle 0) and the pair is "rotated" forever.
+    if (mn < 1.0e-60 * mx0) return false;
+    const double mx = fmax(mx0, floor2);
     return g2 > tol * tol * mn * mx;
 }
 

@@ -24,7 +24,8 @@ from . import _device as dev
 from .charges import ChargeInfo, LegCharge, LegPipe, _find_row_differences, _partial_qtotal
 
 __all__ = ['lq', 'eigvalsh', 'QCUTOFF', 'ChargeInfo', 'LegCharge', 'LegPipe', 'Array', 'zeros', 'eye_like', 'diag', 'outer', 'inner',
-           'tensordot', 'svd', 'qr', 'eigh', 'norm', 'trace', 'to_iterable_arrays', 'TensordotPlan']
+           'tensordot', 'svd', 'qr', 'eigh', 'norm', 'trace', 'to_iterable_arrays', 'TensordotPlan', 'ones', 'concatenate',
+           'expm', 'pinv', 'polar']
 
 QCUTOFF = np.finfo(np.float64).eps * 10
 
@@ -1195,6 +1196,47 @@ class Array:
         res._skey = None
         return res
 
+    # ---- element-wise functions --------------------------------------------------------------------------------------------
+    def iunary_blockwise(self, func, *args, **kwargs):
+        """``block = func(block, *args, **kwargs)`` on every stored block (reference :2152).  On the device the blocks
+        are one arena, so ``func`` is applied ONCE to the flat arena by the element-wise function of the same name
+        (``np.conj, np.real, np.imag, np.abs, np.angle, np.sqrt, np.exp, np.log, np.square, np.negative, np.sign``,
+        ...: everything that maps 0 to 0 or not is the caller's business, like in the reference).  There is no host
+        fallback: a Python callable without a device counterpart raises ``NotImplementedError``."""
+        name = getattr(func, '__name__', None)
+        name = {'conjugate': 'conj', 'absolute': 'abs'}.get(name, name)
+        import torch as t
+        f = getattr(t, name, None) if name else None
+        if f is None or name not in _UNARY_OK:
+            raise NotImplementedError("tenpy_amd: no device implementation of the element-wise function %r" % (func,))
+        if self._arena is not None and self._arena.numel() > 0:
+            if name == 'imag' and not self._arena.is_complex():
+                out = t.zeros_like(self._arena)
+            elif name == 'angle' and not self._arena.is_complex():
+                out = t.angle(self._arena)          # 0 or pi
+            else:
+                out = f(self._arena, *args, **kwargs)
+            if out.is_conj():
+                out = out.resolve_conj()
+            if out.dtype not in (t.float64, t.complex128):
+                out = out.to(t.complex128 if out.is_complex() else t.float64)
+            self._arena = out.contiguous()
+            self.dtype = np.dtype(np.complex128 if out.is_complex() else np.float64)
+        elif name in ('real', 'imag', 'abs', 'angle'):
+            self.dtype = np.dtype(np.float64)
+        self._skey = None
+        return self
+
+    def unary_blockwise(self, func, *args, **kwargs):
+        """Copy of ``self`` with ``func`` applied to every stored block (reference :2196)."""
+        res = self.copy(deep=True)
+        return res.iunary_blockwise(func, *args, **kwargs)
+
+    def matvec(self, other):
+        """``tensordot(self, other, axes=1)``: rank-2 matrix times rank-1 vector, the interface the Krylov solvers
+        call (reference :2364)."""
+        return tensordot(self, other, axes=1)
+
     # ---- misc ------------------------------------------------------------------------------------------------------------
     def gauge_total_charge(self, axis, newqtotal=None, new_qconj=None):
         """Change ``qtotal`` by shifting the charges of one leg (reference :1198)."""
@@ -1332,6 +1374,134 @@ def diag(s, leg, dtype=None, labels=None):
     if keep:
         res._set_blocks(qdata[keep], arena=dev.to_device(np.concatenate([blocks[i] for i in keep])), qdata_sorted=True)
     return res
+
+
+_UNARY_OK = {'conj', 'real', 'imag', 'abs', 'angle', 'sqrt', 'exp', 'log', 'square', 'negative', 'sign', 'sin', 'cos', 'tanh',
+             'reciprocal'}
+
+
+def ones(legcharges, dtype=np.float64, qtotal=None, labels=None):
+    """All charge-allowed blocks filled with 1 (reference :2959)."""
+    res = Array(legcharges, dtype, qtotal, labels)
+    qdata = res._allowed_qdata()
+    if len(qdata):
+        res._set_blocks(qdata, qdata_sorted=True)
+        res._arena.fill_(1.)
+    return res
+
+
+def concatenate(arrays, axis=0, copy=True):
+    """Stack Arrays along ``axis`` like ``np.concatenate`` (reference :3027): the sectors of that leg are appended
+    without sorting / bunching, so every block keeps its shape and the result arena is the operands' arenas one after
+    the other (one contiguous block copy per operand block, a single launch per operand).  ``copy`` is accepted for
+    signature compatibility; the device result always owns a new arena."""
+    arrays = list(arrays)
+    first = arrays[0]
+    axis = first.get_leg_index(axis)
+    not_axis = [a for a in range(first.rank) if a != axis]
+    for a in arrays:
+        if a.shape[:axis] != first.shape[:axis] or a.shape[axis + 1:] != first.shape[axis + 1:]:
+            raise ValueError("wrong shape to fit " + repr(a.shape) + " into " + repr(first.shape))
+        if a.chinfo != first.chinfo:
+            raise ValueError("wrong ChargeInfo")
+        if np.any(a.qtotal != first.qtotal):
+            raise ValueError("wrong qtotal")
+        for l in not_axis:
+            a.legs[l].test_equal(first.legs[l])
+    dtype = _calc_dtype(*[a.dtype for a in arrays])
+    axis_qconj = first.legs[axis].qconj
+    bl_sizes, charges, qdatas = [], [], []
+    shift = 0
+    for a in arrays:
+        leg = a.legs[axis]
+        bl_sizes.extend(leg.get_block_sizes())
+        charges.append(leg.charges if leg.qconj == axis_qconj else first.chinfo.make_valid(-leg.charges))
+        q = a._qdata.copy()
+        q[:, axis] += shift
+        qdatas.append(q)
+        shift += leg.block_number
+    legs = list(first.legs)
+    legs[axis] = LegCharge.from_qind(first.chinfo, np.append([0], np.cumsum(bl_sizes)), np.concatenate(charges, axis=0), axis_qconj)
+    res = Array(legs, dtype, first.qtotal, list(first._labels))
+    res._set_blocks(np.concatenate(qdatas, axis=0), qdata_sorted=False)
+    at = 0
+    for a in arrays:
+        if a.stored_blocks == 0:
+            continue
+        src = a if a.dtype == dtype else a.astype(dtype)
+        sizes = src._block_sizes_flat()
+        n = len(sizes)
+        jobs = _copy_jobs_contiguous(res._offsets[at:at + n], src._offsets, sizes)
+        _run_copy(dtype, jobs, int(np.max(sizes)), src._arena, res._arena)
+        at += n
+    return res
+
+
+def expm(a):
+    """Matrix exponential of a square block-diagonal matrix (reference :4103, which calls scipy.linalg.expm per block).
+
+    Device version: scaling and squaring with a Taylor polynomial, all in block GEMMs -- ``X = a / 2**s`` with
+    ``||X||_F <= 1/2``, ``T = sum_{k<=18} X**k / k!`` by Horner's rule (truncation error 0.5**19 / 19! < 1e-22),
+    then ``T <- T T`` s times.  Sectors without a stored block get the identity, like the reference."""
+    if a.rank != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError("expect a square matrix!")
+    a.legs[0].test_contractible(a.legs[1])
+    if np.any(a.qtotal != a.chinfo.make_valid()):
+        raise NotImplementedError("A*A has different qtotal than A; nilpotent matrix")
+    labels = list(a._labels)
+    piped_axes, a = a.as_completely_blocked()
+    res_dtype = _calc_dtype(a.dtype)
+    eye = diag(1., a.legs[0], dtype=res_dtype)
+    nrm = float(norm(a)) if a.stored_blocks else 0.
+    if nrm == 0.:
+        T = eye
+    else:
+        if not np.isfinite(nrm):
+            raise ValueError("expm of a matrix with non-finite entries")
+        s_pow = max(0, int(np.ceil(np.log2(nrm / 0.5))))
+        X = a.astype(res_dtype, copy=True)
+        X.idrop_labels()
+        X.iscale_prefactor(0.5**s_pow)
+        order = 18
+        T = eye.copy(deep=True)
+        for k in range(order, 0, -1):
+            T = tensordot(X, T, axes=1)
+            T.iscale_prefactor(1. / k)
+            T.iadd_prefactor_other(1., eye)
+        for _ in range(s_pow):
+            T = tensordot(T, T, axes=1)
+    if len(piped_axes) > 0:
+        T = T.split_legs(piped_axes)
+    T.iset_leg_labels(labels)
+    return T
+
+
+def pinv(a, cutoff=1.e-15):
+    """Moore-Penrose pseudo-inverse through the block SVD (reference :3821)."""
+    if cutoff <= 0.:
+        raise ValueError("invalid cutoff")
+    U, S, VH = svd(a, cutoff=cutoff)
+    X = VH.itranspose().iconj().iscale_axis(1. / S, axis=-1)
+    Z = U.itranspose().iconj()
+    return tensordot(X, Z, axes=1)
+
+
+def polar(a, cutoff=1.e-16, left=False, inner_labels=[None, None]):
+    """Polar decomposition ``a = u p`` (``left=False``) or ``a = p u`` through the block SVD (reference :3762).
+    Returns ``(u, p, s)``."""
+    if a.rank != 2:
+        raise ValueError("Polar is only defined for a 2D matrix. Use LegPipes!")
+    if cutoff < 0.:
+        raise ValueError("invalid cutoff")
+    W, s, VH = svd(a, cutoff=cutoff, inner_labels=inner_labels)
+    u = tensordot(W, VH, axes=([1, 0]))
+    if not left:
+        labels = VH.conj().get_leg_labels()[1], VH.get_leg_labels()[1]
+        p = tensordot(VH.conj().itranspose().iscale_axis(s), VH, axes=([1, 0])).iset_leg_labels(labels)
+    else:
+        labels = u.get_leg_labels()[0], u.conj().get_leg_labels()[0]
+        p = tensordot(W.iscale_axis(s), W.conj().itranspose(), axes=([1, 0])).iset_leg_labels(labels)
+    return u, p, s
 
 
 def detect_qtotal(flat_array, legcharges, cutoff=None):

@@ -546,7 +546,62 @@ def gen_krylov2():
     save('krylov2.pkl', out)
 
 
-GENERATORS = dict(krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_api2():
+    """More of the Array API: take_slice, concatenate, expm, pinv, polar, unary_blockwise, ones, Array.matvec."""
+    out = []
+    r3 = np.random.RandomState(4242)
+
+    def rleg(ch, n, qconj=1):
+        qflat = np.stack([r3.randint(0, m, size=n) if m > 1 else r3.randint(-1, 2, size=n) for m in ch.mod], axis=1)
+        return charges.LegCharge.from_qflat(ch, qflat, qconj).bunch()[1]
+
+    def rarr(legs, cplx, qtotal=None, labels=None):
+        def f(size):
+            x = r3.standard_normal(size)
+            return x + 1.j * r3.standard_normal(size) if cplx else x
+        a = npc.Array.from_func(f, legs, dtype=np.complex128 if cplx else np.float64, qtotal=qtotal, shape_kw='size')
+        if labels is not None:
+            a.iset_leg_labels(labels)
+        return a
+    for mod, cplx in (([1], False), ([3, 1], True)):
+        ch = charges.ChargeInfo(mod)
+        legs = [rleg(ch, n, q) for n, q in ((5, 1), (4, -1), (6, 1))]
+        a = rarr(legs, cplx, labels=['a', 'b', 'c'])
+        for idx, axes in (([2], ['b']), ([4, 0], ['a', 'c']), ([3], [2])):
+            out.append(dict(op='take_slice', a=dump_array(a), indices=idx, axes=axes, res=dump_array(a.take_slice(idx, axes))))
+        # concatenate along the middle leg: operands with different middle legs (one with opposite qconj)
+        b = rarr([legs[0], rleg(ch, 3, -1), legs[2]], cplx, labels=['a', 'b', 'c'])
+        c = rarr([legs[0], rleg(ch, 2, -1), legs[2]], False, labels=['x', 'y', 'z'])
+        out.append(dict(op='concatenate', arrays=[dump_array(x) for x in (a, b, c)], axis='b',
+                        res=dump_array(npc.concatenate([a, b, c], axis='b'))))
+        out.append(dict(op='concatenate', arrays=[dump_array(x) for x in (b, a)], axis=1,
+                        res=dump_array(npc.concatenate([b, a], axis=1))))
+        # square matrices
+        leg = rleg(ch, 9)
+        m = rarr([leg, leg.conj()], cplx, labels=['p', 'p*'])
+        out.append(dict(op='expm', a=dump_array(m), res=dump_array(npc.expm(m))))
+        big = m * 7.3                                   # needs several squarings
+        out.append(dict(op='expm', a=dump_array(big), res=dump_array(npc.expm(big))))
+        pipe = charges.LegPipe([legs[0], legs[1].conj()], qconj=+1)
+        mp = rarr([pipe, pipe.conj()], cplx, labels=['(a.b)', '(a*.b*)']) * 0.3
+        out.append(dict(op='expm', a=dump_array(mp), res=dump_array(npc.expm(mp)), pipes=True))
+        herm = (m + m.conj().itranspose()) * (-0.2j if cplx else -0.2)     # a TEBD-like gate  exp(-i dt H)
+        out.append(dict(op='expm', a=dump_array(herm), res=dump_array(npc.expm(herm))))
+        r = rarr([rleg(ch, 8), rleg(ch, 5, -1)], cplx, labels=['l', 'r'])
+        out.append(dict(op='pinv', a=dump_array(r), res=dump_array(npc.pinv(r))))
+        for left in (False, True):
+            u, pm, sv = npc.polar(r, left=left)
+            out.append(dict(op='polar', a=dump_array(r), left=left, u=dump_array(u), p=dump_array(pm), s=np.array(sv)))
+        for fn in ('real', 'imag', 'abs', 'conj', 'angle'):
+            out.append(dict(op='unary', a=dump_array(a), func=fn, res=dump_array(a.unary_blockwise(getattr(np, fn)))))
+        out.append(dict(op='ones', legs=[dump_leg(l) for l in legs], qtotal=np.array(a.qtotal),
+                        res=dump_array(npc.ones(legs, qtotal=a.qtotal))))
+        v = rarr([leg], cplx, qtotal=ch.make_valid(np.ones(len(mod), dtype=int)), labels=['v'])
+        out.append(dict(op='matvec', a=dump_array(m), v=dump_array(v), res=dump_array(m.matvec(v))))
+    save('api2.pkl', out)
+
+
+GENERATORS = dict(api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

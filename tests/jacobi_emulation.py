@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE: numpy emulation of the device block-Jacobi SVD iteration (tenpy_amd/csrc/tpa_svd.hip:
+8-row blocks, 16 x 16 Gram per block pair recomputed from the data every round, in-LDS two-sided Jacobi on the Gram
+with the Hestenes angle, cross-only rounds after the first round of a sweep, rotation counter as convergence test).
+It exists to pin the STOPPING RULE on the CPU: tests/test_svd_rule.py runs it on matrices on which the rule without the
+null-row cut never terminates (found on the GPU: SVDs of the subspace expansion).  Not used by the product."""
+import numpy as np
+EPS = 2.220446049250313e-16
+BRJ, TRJ = 8, 16
+
+NULL_ROW_CUT = 1.0e-60      # svd_needs_rotation: |row|^2 below this fraction of the partner's -> zero row
+
+
+def needs(a, b, g2, tol, floor2):
+    """svd_needs_rotation of tpa_svd.hip, operation for operation."""
+    if not (a > 0.0) or not (b > 0.0):
+        return False
+    mn = min(a, b)
+    mx0 = max(a, b)
+    if mn < NULL_ROW_CUT * mx0:
+        return False
+    mx = max(mx0, floor2)
+    return g2 > tol * tol * mn * mx
+
+def block_pair_of(R, pair, rnd):
+    NB = (R + BRJ - 1) // BRJ
+    NBp = (NB + 1) // 2 * 2
+    mod = NBp - 1
+    r = rnd % mod if mod > 0 else 0
+    if pair == 0:
+        bi, bj = NBp - 1, r
+    else:
+        bi, bj = (r + pair) % mod, (r - pair + mod) % mod
+    if bi > bj:
+        bi, bj = bj, bi
+    return bi, bj, NB
+
+def local_solve(Sm, Q, full_local, tol, floor2, local_sweeps=1):
+    n_local = TRJ - 1 if full_local else BRJ
+    for sw in range(local_sweeps):
+        rotated = False
+        for rr in range(n_local):
+            part = np.zeros(TRJ, int); cs = np.ones(TRJ); cp = np.zeros(TRJ)
+            rot_now = False
+            for i in range(TRJ):
+                if full_local:
+                    if i == TRJ - 1: pi = rr
+                    elif i == rr: pi = TRJ - 1
+                    else: pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1)
+                else:
+                    pi = (BRJ + ((i + rr) & (BRJ - 1))) if i < BRJ else (((i - BRJ) - rr) & (BRJ - 1))
+                p, q = (i, pi) if i < pi else (pi, i)
+                a, b, g = Sm[p, p], Sm[q, q], Sm[p, q]
+                c, s = 1.0, 0.0
+                if needs(a, b, g * g, tol, floor2):
+                    zeta = (b - a) / (2.0 * g)
+                    h = np.sqrt(zeta * zeta + 1.0)
+                    t = np.copysign(1.0, zeta) / (abs(zeta) + h)
+                    c = 1.0 / np.sqrt(t * t + 1.0)
+                    s = c * t
+                    rotated = True; rot_now = True
+                part[i] = pi; cs[i] = c; cp[i] = -s if i == p else s
+            if not rot_now:
+                continue
+            Sn = cs[:, None] * Sm + cp[:, None] * Sm[part, :]
+            Qn = cs[:, None] * Q + cp[:, None] * Q[part, :]
+            Sm[:] = Sn; Q[:] = Qn
+            Sn = cs[None, :] * Sm + cp[None, :] * Sm[:, part]
+            Sm[:] = Sn
+        if not rotated:
+            break
+
+def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False):
+    m, n = A.shape
+    W = (A if m <= n else A.T).copy()
+    R, L = W.shape
+    fro2 = float((A * A).sum())
+    tol = EPS * np.sqrt(L); floor2 = rho * rho * fro2
+    NB = (R + 7) // 8; NBp = (NB + 1) // 2 * 2
+    rounds = max(NBp - 1, 1)
+    if R < 2:
+        return 0, W
+    for sweep in range(max_sweeps):
+        cnt = 0
+        for r in range(rounds):
+            full_local = 0 if (cross_only and r > 0) else 1
+            for pair in range(NBp // 2):
+                bi, bj, NB_ = block_pair_of(R, pair, r)
+                rows = []
+                for t in range(TRJ):
+                    b = bi if t < BRJ else bj
+                    rr_ = b * BRJ + (t % BRJ)
+                    rows.append(rr_ if (b < NB_ and rr_ < R) else -1)
+                X = np.zeros((TRJ, L))
+                for t, rw in enumerate(rows):
+                    if rw >= 0: X[t] = W[rw]
+                Sm = X @ X.T
+                flag = False
+                for ei in range(TRJ):
+                    for ej in range(TRJ):
+                        rel = (ei < ej) if full_local else (ei < BRJ and ej >= BRJ)
+                        if rel and needs(Sm[ei, ei], Sm[ej, ej], Sm[ei, ej] ** 2, tol, floor2):
+                            flag = True
+                if not flag:
+                    continue
+                cnt += 1
+                Q = np.eye(TRJ)
+                local_solve(Sm, Q, full_local, tol, floor2)
+                Xn = Q @ X
+                for t, rw in enumerate(rows):
+                    if rw >= 0: W[rw] = Xn[t]
+        if verbose:
+            print(sweep, cnt, np.sort(np.linalg.norm(W, axis=1))[::-1][:8])
+        if cnt == 0:
+            return sweep + 1, W
+    return -1, W

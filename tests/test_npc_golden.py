@@ -118,3 +118,53 @@ def test_krylov2_golden(backend):
             assert len(res) == len(rec['res'])
             for v, r in zip(res, rec['res']):
                 np.testing.assert_allclose(v.to_ndarray(), r['dense'], rtol=0, atol=1e-9)
+
+
+def test_api2_golden(backend):
+    """take_slice / concatenate / expm / pinv / polar / unary_blockwise / ones / Array.matvec vs the reference
+    (tests/golden/make_golden.py:gen_api2): integer bookkeeping exact, data within tolerance."""
+    seen = set()
+    for rec in golden('api2.pkl'):
+        op = rec['op']
+        seen.add(op)
+        if op == 'take_slice':
+            a = load_array(rec['a'])
+            assert_array_matches(a.take_slice(rec['indices'], rec['axes']), rec['res'])
+        elif op == 'concatenate':
+            arrs = [load_array(x) for x in rec['arrays']]
+            res = npc.concatenate(arrs, axis=rec['axis'])
+            assert not res._qdata_sorted
+            assert_array_matches(res, rec['res'])
+            for x, d in zip(arrs, rec['arrays']):
+                np.testing.assert_array_equal(x.to_ndarray(), d['dense'])
+        elif op == 'expm':
+            a = load_array(rec['a'])
+            res = npc.expm(a)
+            ref = rec['res']['dense']
+            assert_array_matches(res, rec['res'], data=False)
+            # (1e-11: the ||a|| ~ 40 case is squared 7 times; scipy's Pade result carries an error of the same size)
+            np.testing.assert_allclose(res.to_ndarray(), ref, rtol=0, atol=1e-11 * max(1., np.abs(ref).max()))
+            np.testing.assert_array_equal(a.to_ndarray(), rec['a']['dense'])
+        elif op == 'pinv':
+            a = load_array(rec['a'])
+            assert_array_matches(npc.pinv(a), rec['res'], rtol=1e-11)
+        elif op == 'polar':
+            a = load_array(rec['a'])
+            u, p, s = npc.polar(a, left=rec['left'])
+            assert_array_matches(u, rec['u'], rtol=1e-11)
+            assert_array_matches(p, rec['p'], rtol=1e-11)
+            np.testing.assert_allclose(np.sort(s), np.sort(rec['s']), rtol=1e-11)
+        elif op == 'unary':
+            a = load_array(rec['a'])
+            assert_array_matches(a.unary_blockwise(getattr(np, rec['func'])), rec['res'])
+            np.testing.assert_array_equal(a.to_ndarray(), rec['a']['dense'])
+        elif op == 'ones':
+            from helpers import load_leg
+            legs = [load_leg(x) for x in rec['legs']]
+            assert_array_matches(npc.ones(legs, qtotal=rec['qtotal']), rec['res'])
+        elif op == 'matvec':
+            a, v = load_array(rec['a']), load_array(rec['v'])
+            assert_array_matches(a.matvec(v), rec['res'], rtol=1e-12)
+    assert seen == {'take_slice', 'concatenate', 'expm', 'pinv', 'polar', 'unary', 'ones', 'matvec'}
+    with pytest.raises(NotImplementedError):
+        load_array(golden('api2.pkl')[0]['a']).unary_blockwise(lambda x: x + 1)

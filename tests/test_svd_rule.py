@@ -1,0 +1,62 @@
+"""The stopping rule of the device Jacobi SVD, pinned on the CPU with a numpy emulation of the iteration
+(tests/jacobi_emulation.py), and the same matrices through ``npc.svd`` on both backends.
+
+The fixture ``golden/svd_rankdef.npz`` holds blocks from a single-site DMRG run with the subspace expansion: exactly
+rank-deficient (zero columns), so a null row has no orthogonal complement to park its rounding noise in and shrinks by
+~eps per sweep.  Without the null-row cut the iteration hangs once |row|^2 is denormal (seen on the MI355X:
+"no convergence in 80 sweeps")."""
+import os
+
+import numpy as np
+import pytest
+
+import jacobi_emulation as je
+from tenpy_amd.linalg import np_conserved as npc
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'svd_rankdef.npz')
+
+
+def _mats():
+    with np.load(FIX) as z:
+        return [z[k] for k in sorted(z.files)]
+
+
+def test_rule_terminates_on_exactly_rank_deficient_blocks():
+    for A in _mats():
+        sweeps, W = je.jacobi(A)
+        assert 0 < sweeps <= 12
+        s = np.sort(np.linalg.norm(W, axis=1))[::-1]
+        ref = np.linalg.svd(A, compute_uv=False)
+        assert np.abs(s - ref).max() <= 1e-14 * ref.max()
+
+
+def test_rule_without_cut_hangs(monkeypatch):
+    """Documents the failure mode the cut removes (so that nobody 'simplifies' it away)."""
+    monkeypatch.setattr(je, 'NULL_ROW_CUT', 0.)
+    with np.errstate(over='ignore'):
+        hung = [je.jacobi(A, max_sweeps=40)[0] < 0 for A in _mats()]
+    assert any(hung)
+
+
+def test_rule_unchanged_on_generic_blocks():
+    rng = np.random.RandomState(11)
+    for m, n, r in ((24, 24, 24), (20, 33, 9), (40, 17, 17)):
+        A = rng.standard_normal((m, r)) @ np.diag(np.logspace(0, -12, r)) @ rng.standard_normal((r, n))
+        sweeps, W = je.jacobi(A)
+        assert 0 < sweeps <= 20
+        s = np.sort(np.linalg.norm(W, axis=1))[::-1]
+        ref = np.linalg.svd(A, compute_uv=False)
+        assert np.abs(s - ref[:len(s)]).max() <= 1e-13 * ref.max()
+
+
+def test_npc_svd_of_rank_deficient_blocks(backend):
+    from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
+    ch = ChargeInfo([1])
+    for A in _mats():
+        m, n = A.shape
+        a = npc.Array.from_ndarray(A, [LegCharge.from_qflat(ch, np.zeros((m, 1), int)), LegCharge.from_qflat(ch, np.zeros((n, 1), int), -1)])
+        U, S, VH = npc.svd(a)
+        ref = np.linalg.svd(A, compute_uv=False)
+        np.testing.assert_allclose(np.sort(S)[::-1], ref[:len(S)], rtol=0, atol=1e-13 * ref.max())
+        rec = (U.to_ndarray() * S) @ VH.to_ndarray()
+        np.testing.assert_allclose(rec, A, rtol=0, atol=1e-13 * ref.max())
