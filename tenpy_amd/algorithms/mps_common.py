@@ -203,13 +203,17 @@ class MpoApplyPlan:
     @classmethod
     def get(cls, X, W, *args, W2=None, **kwargs):
         """Cached constructor: the plan depends on the block structure of X and on the MPO tensors only."""
-        key = (X._struct_key(), str(X.dtype), id(_mpo_entries(W)), None if W2 is None else id(_mpo_entries(W2)), args,
+        e1, e2 = _mpo_entries(W), (None if W2 is None else _mpo_entries(W2))
+        key = (X._struct_key(), str(X.dtype), id(e1), None if e2 is None else id(e2), args,
                tuple(sorted(kwargs.items())), tuple(X.get_leg_labels()))
         plan = cls._cache.get(key)
-        if plan is None:
+        if plan is None or plan._entries_alive[0] is not e1 or plan._entries_alive[1] is not e2:
             if len(cls._cache) > 4096:
                 cls._cache.clear()
             plan = cls._cache[key] = cls(X, W, *args, W2=W2, **kwargs)
+            # the key holds id()s: keep the entry tables alive as long as the plan is cached, so that the id of a dead
+            # MPO's table can never be handed to a new one (a stale plan would apply the OLD couplings)
+            plan._entries_alive = (e1, e2)
         return plan
 
     def __init__(self, X, W, x_w, x_p, w_in, w_out, p_out, p_in, out_labels, W2=None, x_p2=None, p2_out=None, p2_in=None):

@@ -1438,7 +1438,7 @@ def concatenate(arrays, axis=0, copy=True):
 
 
 def expm(a):
-    """Matrix exponential of a square block-diagonal matrix (reference :4103, which calls scipy.linalg.expm per block).
+    """Matrix exponential of a square block-diagonal matrix (reference :4103, which runs scipy's Pade ``expm`` block by block on the host).
 
     Device version: scaling and squaring with a Taylor polynomial, all in block GEMMs -- ``X = a / 2**s`` with
     ``||X||_F <= 1/2``, ``T = sum_{k<=18} X**k / k!`` by Horner's rule (truncation error 0.5**19 / 19! < 1e-22),
