@@ -67,6 +67,86 @@ class TEBDEngine:
         self.trunc_err = self.trunc_err + err
         return err
 
+    # ---- general Suzuki-Trotter evolution (reference tebd.py:183-414) -------------------------------------------------
+    @staticmethod
+    def suzuki_trotter_time_steps(order):
+        """Fractions of dt for which bond gates are needed (reference :183)."""
+        if order == 1:
+            return [1.]
+        if order == 2:
+            return [0.5, 1.]
+        if order == 4:
+            t1 = 1. / (4. - 4.**(1 / 3.))
+            t3 = 1. - 4. * t1
+            return [t1 / 2., t1, (t1 + t3) / 2., t3]
+        if order == '4_opt':            # Eq. (30a) of Barthel & Zhang 2020
+            a1, b1 = 0.095848502741203681182, 0.42652466131587616168
+            a2, b2 = -0.078111158921637922695, -0.12039526945509726545
+            return [a1, b1, a2, b2, 0.5 - a1 - a2, 1. - 2 * (b1 + b2), 2 * a1]
+        raise ValueError("Unknown order %r for Suzuki Trotter decomposition" % (order,))
+
+    @staticmethod
+    def suzuki_trotter_decomposition(order, N_steps):
+        """List of (index into the time steps, 0 = even / 1 = odd bonds) for ``N_steps`` steps, with the last layer of
+        one step merged into the first layer of the next (reference :219)."""
+        even, odd = 0, 1
+        if N_steps == 0:
+            return []
+        if order == 1:
+            return [(0, odd), (0, even)] * N_steps
+        if order == 2:
+            a, a2, b = (0, odd), (1, odd), (1, even)
+            return [a, b] + [a2, b] * (N_steps - 1) + [a]
+        if order == 4:
+            a, a2, b, c, d = (0, odd), (1, odd), (1, even), (2, odd), (3, even)
+            steps = [a, b, a2, b, c, d, c, b, a2, b]
+            return steps + [a2, b, a2, b, c, d, c, b, a2, b] * (N_steps - 1) + [a]
+        if order == '4_opt':
+            a1, b1, a2, b2, a3, b3, a1_twice = (0, odd), (1, even), (2, odd), (3, even), (4, odd), (5, even), (6, odd)
+            steps = [a1, b1, a2, b2, a3, b3, a3, b2, a2, b1]
+            return steps + [a1_twice, b1, a2, b2, a3, b3, a3, b2, a2, b1] * (N_steps - 1) + [a1]
+        raise ValueError("Unknown order %r for Suzuki Trotter decomposition" % (order,))
+
+    def calc_U(self, order, delta_t, type_evo='real'):
+        """Bond gates ``exp(-i delta_t f h)`` (``type_evo='real'``) or ``exp(-delta_t f h)`` (``'imag'``) for every fraction
+        f of the decomposition (reference :297); kept until the parameters change."""
+        if type_evo not in ('real', 'imag'):
+            raise ValueError("Invalid value for `type_evo`: " + repr(type_evo))
+        param = dict(order=order, delta_t=delta_t, type_evo=type_evo)
+        if getattr(self, '_U_param', None) is not None and all(self._U_param.get(k) == v for k, v in param.items()):
+            return
+        param['tau'] = delta_t if type_evo == 'real' else -1.j * delta_t
+        self._U_param = param
+        p = self.psi.p_legs[0]
+        self._U_list = [[None if h is None else bond_gate(h, p, delta_t * f, imaginary=(type_evo == 'imag')) for h in self.h_bonds]
+                        for f in self.suzuki_trotter_time_steps(order)]
+
+    def evolve(self, N_steps, dt=None):
+        """``N_steps`` time steps with the gates prepared by :meth:`calc_U` (reference :346).  Returns the truncation error."""
+        if dt is not None:
+            assert dt == self._U_param['delta_t']
+        trunc_err = TruncationError()
+        for U_idx_dt, odd in self.suzuki_trotter_decomposition(self._U_param['order'], N_steps):
+            trunc_err = trunc_err + self.evolve_step(U_idx_dt, odd)
+        self.evolved_time = self.evolved_time + N_steps * self._U_param['tau']
+        return trunc_err
+
+    def evolve_step(self, U_idx_dt, odd):
+        """One layer: all even (``odd=0``) or odd bonds ``(i-1, i)`` (reference :374)."""
+        Us = self._U_list[U_idx_dt]
+        trunc_err = TruncationError()
+        for i_bond in range(int(odd) % 2, self.psi.L, 2):
+            if Us[i_bond] is None:
+                continue
+            trunc_err = trunc_err + self.update_bond(i_bond, Us[i_bond])
+        return trunc_err
+
+    def run_evolution(self):
+        """What the reference's ``TEBDEngine.run()`` does: ``options['N_steps']`` (1) steps of ``options['dt']`` at
+        ``options['order']`` (2), real time."""
+        self.calc_U(self.options.get('order', 2), self.dt, 'real')
+        return self.evolve(self.options.get('N_steps', 1), self.dt)
+
     def evolve_step_order2(self):
         """One time step dt: half step on even bonds, full step on odd bonds, half step on even bonds."""
         L = self.psi.L

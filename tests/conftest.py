@@ -15,11 +15,11 @@ def pytest_configure(config):
 
 # GPU variants written after this round's GPU budget was spent (never run on the MI355X by the author): collected LAST,
 # so that with ``-x`` a surprise in them cannot hide the validated part of the suite.  
-_LATE_FILES = ('test_dmrg_single_golden.py', 'test_svd_rule.py')
+_LATE_FILES = ('test_dmrg_single_golden.py', 'test_svd_rule.py', 'test_tebd_orders_and_imaginary_time')
 
 
 def pytest_collection_modifyitems(config, items):
-    items.sort(key=lambda it: any(it.nodeid.split('::')[0].endswith(f) for f in _LATE_FILES))
+    items.sort(key=lambda it: any(f in it.nodeid for f in _LATE_FILES))
     try:
         import torch
         have_gpu = torch.cuda.is_available()

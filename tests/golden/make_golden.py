@@ -601,7 +601,37 @@ def gen_api2():
     save('api2.pkl', out)
 
 
-GENERATORS = dict(api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_tebd2():
+    """TEBD with the other Suzuki-Trotter orders (1, 4, '4_opt'; 3 merged steps per evolve call) and imaginary time."""
+    from tenpy.algorithms import tebd
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 8
+        M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': 'parity', 'sort_charge': True})
+        h_bond = [None if h is None else h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond]
+        labels = list(M.lat.mps_sites()[0].state_labels.items())
+        for order, type_evo in ((1, 'real'), (2, 'real'), (4, 'real'), ('4_opt', 'real'), (2, 'imag'), (4, 'imag')):
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+            eng = tebd.TEBDEngine(psi, M, {'order': order, 'dt': 0.05, 'N_steps': 3, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}})
+            eng.calc_U(order, 0.05, type_evo=type_evo)
+            S_t, chi_t, errs = [], [], []
+            for rep in range(4):
+                err = eng.evolve(3, 0.05)
+                S_t.append(np.array(psi.entanglement_entropy()))
+                chi_t.append(int(max(psi.chi)))
+                errs.append(float(err.eps))
+            out.append(dict(order=order, type_evo=type_evo, L=L, dt=0.05, chi=12, N_steps=3, S_t=np.array(S_t), chi_t=chi_t, err_t=errs,
+                            evolved_time=complex(eng.evolved_time), decomposition=list(tebd.TEBDEngine.suzuki_trotter_decomposition(order, 3)),
+                            time_steps=list(tebd.TEBDEngine.suzuki_trotter_time_steps(order)),
+                            S_mid=np.array(psi.get_SL(L // 2)), h_bond=h_bond, state_labels=labels, conserve='parity'))
+            print('tebd2', order, type_evo, chi_t, S_t[-1][L // 2 - 1])
+    save('tebd2.pkl', out)
+
+
+GENERATORS = dict(tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

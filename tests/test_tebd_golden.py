@@ -50,3 +50,25 @@ def test_qr_tebd_quench(backend, name):
         eng.evolve_step_order2()
         assert max(psi.chi) == rec['chi_qr'][step]
         np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_qr'][step], rtol=0, atol=1e-9)
+
+
+def test_tebd_orders_and_imaginary_time(backend):
+    """Suzuki-Trotter orders 1, 2, 4, '4_opt' (three merged steps per ``evolve`` call) in real time and orders 2, 4 in
+    imaginary time vs the reference's ``TEBDEngine.calc_U`` + ``evolve`` (tests/golden/make_golden.py:gen_tebd2)."""
+    for rec in golden('tebd2.pkl'):
+        L = rec['L']
+        _, p = spin_half_leg(rec['conserve'])
+        up = dict(rec['state_labels'])['up']
+        psi = MPS.from_product_state([p] * L, [up] * L, dtype=np.complex128 if rec['type_evo'] == 'real' else np.float64)
+        eng = TEBDEngine(psi, rec['h_bond'], {'dt': rec['dt'], 'order': rec['order'], 'N_steps': rec['N_steps'],
+                                              'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}})
+        assert [tuple(x) for x in eng.suzuki_trotter_decomposition(rec['order'], rec['N_steps'])] == [tuple(x) for x in rec['decomposition']]
+        np.testing.assert_array_equal(eng.suzuki_trotter_time_steps(rec['order']), rec['time_steps'])
+        eng.calc_U(rec['order'], rec['dt'], type_evo=rec['type_evo'])
+        for rep in range(len(rec['chi_t'])):
+            err = eng.evolve(rec['N_steps'], rec['dt'])
+            assert max(psi.chi) == rec['chi_t'][rep]
+            np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_t'][rep], rtol=0, atol=1e-10)
+            assert abs(err.eps - rec['err_t'][rep]) < 1e-11
+        assert abs(complex(eng.evolved_time) - rec['evolved_time']) < 1e-14
+        np.testing.assert_allclose(np.sort(psi.get_SL(L // 2))[::-1], np.sort(rec['S_mid'])[::-1], rtol=0, atol=1e-10)
