@@ -97,6 +97,14 @@ __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2
     return g2 > tol * tol * mn * mx;
 }
 
+// "Big" rotation: scaled cosine above 1e-7.  A sweep without any big rotation leaves all cosines at ~1e-14 or below
+// (quadratic convergence), so the host may skip the verification sweep (tpa_svd_set_algorithm bit 10, off by default;
+// tests/jacobi_emulation.py `predict`: one sweep of ~7 saved on chi=2048 theta blocks, identical singular values and
+// orthogonality).  Counted in n_rot[1].
+__device__ __forceinline__ bool svd_big_rotation(double a, double b, double g2, double floor2) {
+    return g2 > 1.0e-14 * fmin(a, b) * fmax(fmax(a, b), floor2);
+}
+
 template <bool CPLX>
 __global__ __launch_bounds__(NT) void svd_round_kernel(const SvdJob *__restrict__ jobs,
                                                        const int2 *__restrict__ pairs, int round,
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(NT) void svd_round_kernel(const SvdJob *__restrict_
     const double g2 = gr * gr + gi * gi;
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
     if (!svd_needs_rotation(a, b, g2, tol, rho * rho * fro2[jp.x])) return;  // already orthogonal (or NaN)
+    const bool big_rot = svd_big_rotation(a, b, g2, rho * rho * fro2[jp.x]);
     const double gabs = sqrt(g2);
     const double zeta = (b - a) / (2.0 * gabs);
     const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -191,7 +200,10 @@ __global__ __launch_bounds__(NT) void svd_round_kernel(const SvdJob *__restrict_
         rot(reinterpret_cast<double2 *>(x), reinterpret_cast<double2 *>(y), L);
         rot(reinterpret_cast<double2 *>(G) + J.g_off + p * R, reinterpret_cast<double2 *>(G) + J.g_off + q * R, R);
     }
-    if (lane == 0) atomicAdd(n_rot, 1u);
+    if (lane == 0) {
+        atomicAdd(n_rot, 1u);
+        if (big_rot) atomicAdd(n_rot + 1, 1u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -425,11 +437,15 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__re
     {
         const int ei = tid >> 4, ej = tid & 15;
         const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
-        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2)) any_flag = 1;
+        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2))
+            atomicOr(&any_flag, svd_big_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], floor2) ? 3 : 1);
     }
     __syncthreads();
     if (any_flag == 0) return;
-    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
+    if (tid == 0 && E.part == 0) {
+        atomicAdd(n_rot, 1u);
+        if (any_flag & 2) atomicAdd(n_rot + 1, 1u);
+    }
 
     if (wave == 0) svd_local_solve(Sm, Qm, csA, cpA, partA, lane, local_sweeps, full_local, tol, floor2);
     __syncthreads();
@@ -615,11 +631,15 @@ __global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__re
     {
         const int ei = tid >> 4, ej = tid & 15;
         const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
-        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2)) any_flag = 1;
+        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2))
+            atomicOr(&any_flag, svd_big_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], floor2) ? 3 : 1);
     }
     __syncthreads();
     if (any_flag == 0) return;
-    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
+    if (tid == 0 && E.part == 0) {
+        atomicAdd(n_rot, 1u);
+        if (any_flag & 2) atomicAdd(n_rot + 1, 1u);
+    }
     if (wave == 0) svd_local_solve(Sm, Qm, csA, cpA, partA, lane, local_sweeps, full_local, tol, floor2);
     __syncthreads();
     // ---- apply Q to the LDS-resident chunks
@@ -776,11 +796,14 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__
         const int ei = tid >> 4, ej = tid & 15;
         const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
         if (relevant && svd_needs_rotation(Sr[ei][ei], Sr[ej][ej], Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej], tol, floor2))
-            any_flag = 1;
+            atomicOr(&any_flag, svd_big_rotation(Sr[ei][ei], Sr[ej][ej], Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej], floor2) ? 3 : 1);
     }
     __syncthreads();
     if (any_flag == 0) return;
-    if (tid == 0 && E.part == 0) atomicAdd(n_rot, 1u);
+    if (tid == 0 && E.part == 0) {
+        atomicAdd(n_rot, 1u);
+        if (any_flag & 2) atomicAdd(n_rot + 1, 1u);
+    }
 
     if (wave == 0) {
         const int ei = lane >> 2, ej0 = (lane & 3) * 4;
@@ -2143,6 +2166,7 @@ int tpa_svd_use_qrp = 1;   // real data: rank-revealing pivoted QR before the Ja
 
 int tpa_svd_fused_round = 1;   // real data: one launch per Jacobi round (sibling workgroups synchronise through a counter)
 int tpa_svd_local_sweeps = 1;
+int tpa_svd_predict_convergence = 0;   // 1: a sweep without "big" rotations ends the iteration (no verification sweep); GPU-unvalidated
 int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block pairs
                         // 32 x 32 solve dominates); kept as a tuning option, off by default
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
@@ -2311,7 +2335,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     if (use_fused) TPA_HIP_CHECK(hipMemsetAsync(pcnt, 0, lay.bentries.size() * 4 + 4, st));
     const int rounds = use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1) : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
     while (!converged && sweep < max_sweeps) {
-        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
             const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
             if (use_block && CPLX) {
@@ -2328,9 +2352,9 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 svd_round_kernel<CPLX><<<g_pairs, NT, 0, st>>>(jobs, pairs, r, W, G, cnt, fro2, rho);
         }
         TPA_LAUNCH_CHECK();
-        unsigned int h = 0;
+        unsigned int h2[2] = {0, 0};
         int herr = 0;
-        TPA_HIP_CHECK(hipMemcpyAsync(&h, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        TPA_HIP_CHECK(hipMemcpyAsync(h2, cnt, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         if (use_fused) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
         TPA_HIP_CHECK(hipStreamSynchronize(st));
         if (herr) {
@@ -2338,7 +2362,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             return TPA_E_NOCONV;
         }
         ++sweep;
-        converged = (h == 0);
+        converged = (h2[0] == 0) || (tpa_svd_predict_convergence && h2[1] == 0);
     }
     if (sweeps_done) *sweeps_done = sweep;
     svd_norms_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, W, sig);
@@ -2901,6 +2925,7 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_cross_only = (pairwise & 4) ? 0 : 1;
     tpa_svd_use_qrp = (pairwise & 512) ? 0 : 1;    // bit 9: no pivoted-QR preconditioner
     tpa_svd_fused_round = (pairwise & 2) ? 0 : 1;  // bit 1: two-kernel rounds (gram, then solve + apply)
+    tpa_svd_predict_convergence = (pairwise & 1024) ? 1 : 0;   // bit 10: skip the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
 }

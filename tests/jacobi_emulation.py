@@ -69,7 +69,10 @@ def local_solve(Sm, Q, full_local, tol, floor2, local_sweeps=1):
         if not rotated:
             break
 
-def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False):
+def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False, predict=None):
+    """Returns (sweeps, W).  ``predict``: if set (e.g. 1e-8), a sweep in which no checked pair had a scaled cosine above
+    it ends the iteration without the verification sweep (quadratic convergence: the rotations of that sweep leave
+    cosines ~ predict**2); this is the proposed `tpa_svd_set_algorithm` bit 10, see DESIGN.md section 7."""
     m, n = A.shape
     W = (A if m <= n else A.T).copy()
     R, L = W.shape
@@ -81,6 +84,7 @@ def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False):
         return 0, W
     for sweep in range(max_sweeps):
         cnt = 0
+        big = 0
         for r in range(rounds):
             full_local = 0 if (cross_only and r > 0) else 1
             for pair in range(NBp // 2):
@@ -95,14 +99,20 @@ def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False):
                     if rw >= 0: X[t] = W[rw]
                 Sm = X @ X.T
                 flag = False
+                flag_big = False
                 for ei in range(TRJ):
                     for ej in range(TRJ):
                         rel = (ei < ej) if full_local else (ei < BRJ and ej >= BRJ)
                         if rel and needs(Sm[ei, ei], Sm[ej, ej], Sm[ei, ej] ** 2, tol, floor2):
                             flag = True
+                            if predict is not None:
+                                a_, b_ = Sm[ei, ei], Sm[ej, ej]
+                                if Sm[ei, ej] ** 2 > predict * predict * min(a_, b_) * max(a_, b_, floor2):
+                                    flag_big = True
                 if not flag:
                     continue
                 cnt += 1
+                big += 1 if flag_big else 0
                 Q = np.eye(TRJ)
                 local_solve(Sm, Q, full_local, tol, floor2)
                 Xn = Q @ X
@@ -110,6 +120,6 @@ def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False):
                     if rw >= 0: W[rw] = Xn[t]
         if verbose:
             print(sweep, cnt, np.sort(np.linalg.norm(W, axis=1))[::-1][:8])
-        if cnt == 0:
+        if cnt == 0 or (predict is not None and big == 0):
             return sweep + 1, W
     return -1, W

@@ -60,3 +60,23 @@ def test_npc_svd_of_rank_deficient_blocks(backend):
         np.testing.assert_allclose(np.sort(S)[::-1], ref[:len(S)], rtol=0, atol=1e-13 * ref.max())
         rec = (U.to_ndarray() * S) @ VH.to_ndarray()
         np.testing.assert_allclose(rec, A, rtol=0, atol=1e-13 * ref.max())
+
+
+def test_predicted_convergence_saves_the_verification_sweep():
+    """`tpa_svd_set_algorithm` bit 10 (off by default): stop after a sweep without rotations of scaled cosine > 1e-7."""
+    rng = np.random.RandomState(3)
+    saved = 0
+    for m, n, r in ((48, 48, 48), (40, 90, 25), (64, 64, 30)):
+        A = rng.standard_normal((m, r)) @ np.diag(np.logspace(0, -10, r)) @ rng.standard_normal((r, n))
+        s0, W0 = je.jacobi(A)
+        s1, W1 = je.jacobi(A, predict=1e-7)
+        assert 0 < s1 <= s0
+        saved += s0 - s1
+        ref = np.linalg.svd(A, compute_uv=False)
+        for W in (W0, W1):
+            nr = np.linalg.norm(W, axis=1)
+            assert np.abs(np.sort(nr)[::-1] - ref[:len(nr)]).max() <= 1e-13 * ref[0]
+            big = nr > 1e-6 * np.linalg.norm(A)
+            Wn = W[big] / nr[big, None]
+            assert np.abs(Wn @ Wn.T - np.eye(big.sum())).max() < 1e-12
+    assert saved >= 2
