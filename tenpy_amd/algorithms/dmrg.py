@@ -22,7 +22,9 @@ __all__ = ['TwoSiteDMRGEngine', 'SingleSiteDMRGEngine', 'run']
 
 
 class TwoSiteDMRGEngine:
-    def __init__(self, psi, model_H, options, resume_data=None):
+    def __init__(self, psi, model_H, options, resume_data=None, orthogonal_to=None):
+        """``orthogonal_to``: list of MPS to orthogonalise against (excited states; reference ``Sweep.init_env`` :190,
+        ``_wrap_ortho_eff_H`` :524): the effective Hamiltonian becomes ``P H P`` with the projected states."""
         self.psi = psi
         self.H = model_H
         self.options = options = dict(options)
@@ -31,6 +33,8 @@ class TwoSiteDMRGEngine:
         self.chi_list = options.get('chi_list', None)
         self.combine = options.get('combine', True)
         self.env = MPOEnvironment(psi, model_H)
+        from ..networks.mps import MPSEnvironment
+        self.ortho_to_envs = [MPSEnvironment(psi, o) for o in (orthogonal_to or [])]
         self.sweeps = 0
         self.update_stats = {k: [] for k in ['i0', 'E_total', 'N_lanczos', 'time', 'err', 'chi', 'flops', 'bytes']}
         self.sweep_stats = {k: [] for k in ['sweep', 'E', 'S', 'time', 'max_trunc_err', 'max_chi', 'N_updates']}
@@ -181,8 +185,9 @@ class TwoSiteDMRGEngine:
             eff_H = TwoSiteH(self.env, i0, combine=True, move_right=move_right)
         theta = psi.get_theta(i0, n=2)
         theta = eff_H.combine_theta(theta)
+        op = self._wrap_ortho_eff_H(eff_H, i0, 2)
         tick('heff')
-        lanczos = LanczosGroundState(eff_H, theta, self.lanczos_params)
+        lanczos = LanczosGroundState(op, theta, self.lanczos_params)
         E0, theta, N = lanczos.run()
         theta = eff_H.prepare_svd(theta)          # fused matrix [(vL.p0), (p1.vR)] for the SVD / mixer
         tick('lanczos')
@@ -225,6 +230,7 @@ class TwoSiteDMRGEngine:
             self.env._RP[j] = None
         if not update_RP and self.env._RP[i0] is not None:
             self.env._RP[i0] = None
+        self._update_ortho_envs(i0, i1, update_LP, update_RP)
         us = self.update_stats
         us['i0'].append(i0)
         us['E_total'].append(float(E0))
@@ -237,6 +243,39 @@ class TwoSiteDMRGEngine:
         if self.log_matvec:
             self.matvec_log.append((i0, N, eff_H.flops_per_matvec, eff_H.bytes_per_matvec, theta.shape))
         return err
+
+    # ---- orthogonalisation against other states (reference mps_common.py:524-540, :569-593) -------------------------
+    def _wrap_ortho_eff_H(self, eff_H, i0, n):
+        """``eff_H`` -> ``P eff_H P`` with the local wave functions of the states in ``orthogonal_to`` projected out."""
+        if not self.ortho_to_envs:
+            return eff_H
+        from ..linalg.sparse import OrthogonalNpcLinearOperator
+        vecs = []
+        for o_env in self.ortho_to_envs:
+            th = o_env.ket.get_theta(i0, n=n)
+            th = npc.tensordot(o_env.get_LP(i0), th, axes=('vR', 'vL'))
+            th = npc.tensordot(th, o_env.get_RP(i0 + n - 1), axes=('vR', 'vL'))
+            th.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
+            th = eff_H.combine_theta(th)
+            if th.dtype != self.env.dtype:
+                th = th.astype(self.env.dtype)
+            vecs.append(th)
+        return OrthogonalNpcLinearOperator(eff_H, vecs)
+
+    def _update_ortho_envs(self, i_L, i_R, update_LP, update_RP):
+        for env in self.ortho_to_envs:
+            for j in range(i_R, self.psi.L):         # everything that contains the new tensors is stale
+                if env._LP[j] is None and j > i_R:
+                    break
+                env._LP[j] = None
+            for j in range(i_L, -1, -1):
+                if env._RP[j] is None and j < i_L:
+                    break
+                env._RP[j] = None
+            if update_LP:
+                env.get_LP(i_R, store=True)
+            if update_RP:
+                env.get_RP(i_L, store=True)
 
     def _tick(self, phase):
         """Phase timer (mirrors the reference's DEBUG_PRINT phases); synchronises only when profiling."""
@@ -336,8 +375,9 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
         tick(None)
         eff_H = OneSiteH(self.env, i0, combine=True, move_right=move_right)
         theta = eff_H.combine_theta(psi.get_theta(i0, n=1))
+        op = self._wrap_ortho_eff_H(eff_H, i0, 1)
         tick('heff')
-        E0, theta, N = LanczosGroundState(eff_H, theta, self.lanczos_params).run()
+        E0, theta, N = LanczosGroundState(op, theta, self.lanczos_params).run()
         tick('lanczos')
         U, S, VH, err, S_a = self.mixed_svd(eff_H, theta, i0, move_right)
         tick('svd')
@@ -361,6 +401,7 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
             if self.env._RP[j] is None:
                 break
             self.env._RP[j] = None
+        self._update_ortho_envs(i_L, i_R, update_LP, update_RP)
         us = self.update_stats
         us['i0'].append(i0)
         us['E_total'].append(float(E0))

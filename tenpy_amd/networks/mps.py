@@ -11,7 +11,7 @@ import numpy as np
 from ..linalg import np_conserved as npc
 from ..linalg.charges import LegCharge
 
-__all__ = ['MPS']
+__all__ = ['MPS', 'MPSEnvironment']
 
 _FORMS = {'A': (1., 0.), 'B': (0., 1.), 'C': (0.5, 0.5), 'G': (0., 0.), 'Th': (1., 1.), None: None}
 
@@ -135,3 +135,77 @@ class MPS:
             E = npc.tensordot(E, B, axes=['vR', 'vL'])
             E = npc.tensordot(B.conj(), E, axes=(['vL*', 'p*'], ['vR*', 'p']))
         return E.to_ndarray().reshape(-1)[0]
+
+
+class MPSEnvironment:
+    """Partial contractions of ``<bra|ket>`` for two finite MPS (reference mps.py:6831): ``LP[i]`` (labels 'vR*', 'vR') is
+    everything left of site i, ``RP[i]`` (labels 'vL', 'vL*') everything right of it.  Used by DMRG to orthogonalise
+    against previously found states (``orthogonal_to``)."""
+
+    def __init__(self, bra, ket):
+        if bra.L != ket.L:
+            raise ValueError("bra and ket must have the same length")
+        self.bra, self.ket = bra, ket
+        self.L = ket.L
+        self.dtype = np.result_type(bra.dtype, ket.dtype)
+        self._LP = [None] * self.L
+        self._RP = [None] * self.L
+        self._LP[0] = self._boundary(bra.get_B(0, None).get_leg('vL'), ket.get_B(0, None).get_leg('vL'), ['vR*', 'vR'])
+        self._RP[self.L - 1] = self._boundary(ket.get_B(self.L - 1, None).get_leg('vR'),
+                                              bra.get_B(self.L - 1, None).get_leg('vR'), ['vL', 'vL*'], ket_first=True)
+
+    def _boundary(self, leg_a, leg_b, labels, ket_first=False):
+        if leg_a.ind_len != 1 or leg_b.ind_len != 1:
+            raise ValueError("finite MPS with trivial boundary legs expected")
+        # LP: ('vR*' = bra's vL, 'vR' = conj of ket's vL);  RP: ('vL' = conj of ket's vR, 'vL*' = bra's vR)
+        legs = [leg_a, leg_b.conj()] if not ket_first else [leg_a.conj(), leg_b]
+        qt = legs[0].chinfo.make_valid(legs[0].get_charge(0) + legs[1].get_charge(0))
+        return npc.Array.from_ndarray(np.ones((1, 1), dtype=self.dtype), legs, dtype=self.dtype, qtotal=qt, labels=labels)
+
+    def get_LP(self, i, store=True):
+        if self._LP[i] is not None:
+            return self._LP[i]
+        j = i
+        while self._LP[j] is None:
+            j -= 1
+        LP = self._LP[j]
+        for k in range(j, i):
+            LP = self._contract_LP(k, LP)
+            if store:
+                self._LP[k + 1] = LP
+        return LP
+
+    def get_RP(self, i, store=True):
+        if self._RP[i] is not None:
+            return self._RP[i]
+        j = i
+        while self._RP[j] is None:
+            j += 1
+        RP = self._RP[j]
+        for k in range(j, i, -1):
+            RP = self._contract_RP(k, RP)
+            if store:
+                self._RP[k - 1] = RP
+        return RP
+
+    def del_LP(self, i):
+        self._LP[i] = None
+
+    def del_RP(self, i):
+        self._RP[i] = None
+
+    def _contract_LP(self, i, LP):
+        LP = npc.tensordot(LP, self.ket.get_B(i, 'A'), axes=('vR', 'vL'))
+        return npc.tensordot(self.bra.get_B(i, 'A').conj(), LP, axes=(['p*', 'vL*'], ['p', 'vR*']))     # 'vR*', 'vR'
+
+    def _contract_RP(self, i, RP):
+        RP = npc.tensordot(self.ket.get_B(i, 'B'), RP, axes=('vR', 'vL'))
+        return npc.tensordot(RP, self.bra.get_B(i, 'B').conj(), axes=(['p', 'vL*'], ['p*', 'vR*']))     # 'vL', 'vL*'
+
+    def full_contraction(self, i0):
+        """``<bra|ket>`` evaluated with the environments around bond (i0, i0+1)."""
+        LP = self.get_LP(i0 + 1, store=False)
+        RP = self.get_RP(i0, store=False)
+        S_bra, S_ket = self.bra.get_SR(i0), self.ket.get_SR(i0)
+        LP = LP.scale_axis(S_ket, 'vR').scale_axis(np.conj(S_bra), 'vR*')
+        return npc.inner(LP, RP, axes=(['vR*', 'vR'], ['vL*', 'vL']), do_conj=False)

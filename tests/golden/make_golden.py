@@ -631,7 +631,45 @@ def gen_tebd2():
     save('tebd2.pkl', out)
 
 
-GENERATORS = dict(tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_dmrg_ortho():
+    """Excited state by DMRG with ``orthogonal_to=[ground state]`` (two-site and single-site engines)."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L, chi = 10, 24
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.2, 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+        psi0 = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        e0 = dmrg.TwoSiteDMRGEngine(psi0, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}})
+        E0s = []
+        for s_ in range(5):
+            e0.sweep()
+            E0s.append(float(e0.update_stats['E_total'][-1]))
+        for engine, n_sw in (('two', 6), ('single', 6)):
+            psi1 = MPS.from_product_state(M.lat.mps_sites(), ['down', 'up'] * (L // 2), bc='finite')
+            cls = dmrg.TwoSiteDMRGEngine if engine == 'two' else dmrg.SingleSiteDMRGEngine
+            opts = {'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6 if engine == 'single' else 1.e-10}}
+            if engine == 'single':
+                opts.update(mixer=True, mixer_params={'amplitude': 1.e-3, 'decay': 2., 'disable_after': 3})
+            else:
+                opts.update(mixer=None)
+            e1 = cls(psi1, M, opts, orthogonal_to=[psi0])
+            e1.mixer_activate()
+            Es = []
+            for s_ in range(n_sw):
+                e1.sweep()
+                Es.append(float(e1.update_stats['E_total'][-1]))
+            e1.mixer_cleanup()
+            out.append(dict(engine=engine, L=L, Jxx=1., Jz=1.2, hz=0., chi=chi, E0_sweeps=E0s, E1_sweeps=Es,
+                            E1_updates=[float(e) for e in e1.update_stats['E_total']], overlap=complex(psi0.overlap(psi1)),
+                            E1_mpo=float(np.real(M.H_MPO.expectation_value(psi1))), svd_min=opts['trunc_params']['svd_min']))
+            print('dmrg_ortho', engine, E0s[-1], Es, abs(psi0.overlap(psi1)))
+    save('dmrg_ortho.pkl', out)
+
+
+GENERATORS = dict(dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
