@@ -16,7 +16,7 @@ from ..linalg import np_conserved as npc
 from ..linalg.krylov_based import LanczosGroundState
 from ..linalg.truncation import svd_theta
 from ..networks.mpo import MPOEnvironment
-from .mps_common import DensityMatrixMixer, OneSiteH, SubspaceExpansion, TwoSiteH
+from .mps_common import DensityMatrixMixer, OneSiteH, SubspaceExpansion, TwoSiteH, full_diag_effH
 
 __all__ = ['TwoSiteDMRGEngine', 'SingleSiteDMRGEngine', 'run']
 
@@ -187,8 +187,7 @@ class TwoSiteDMRGEngine:
         theta = eff_H.combine_theta(theta)
         op = self._wrap_ortho_eff_H(eff_H, i0, 2)
         tick('heff')
-        lanczos = LanczosGroundState(op, theta, self.lanczos_params)
-        E0, theta, N = lanczos.run()
+        E0, theta, N = self.diag(eff_H, op, theta)
         theta = eff_H.prepare_svd(theta)          # fused matrix [(vL.p0), (p1.vR)] for the SVD / mixer
         tick('lanczos')
         i1 = i0 + 1
@@ -243,6 +242,20 @@ class TwoSiteDMRGEngine:
         if self.log_matvec:
             self.matvec_log.append((i0, N, eff_H.flops_per_matvec, eff_H.bytes_per_matvec, theta.shape))
         return err
+
+    def diag(self, eff_H, op, theta_guess):
+        """Lowest eigenpair of the effective Hamiltonian (reference ``DMRGEngine.diag``, dmrg.py:672).  ``diag_method``:
+        'lanczos' (default HERE; the bench and the goldens of this repo fix it), 'ED_block' (exact diagonalisation in the
+        charge sector of the guess) or 'default' = the reference's default: ED below ``max_N_for_ED`` (400), Lanczos above.
+        With ``orthogonal_to`` the projected operator has no matrix form here: Lanczos is used."""
+        method = self.options.get('diag_method', 'lanczos')
+        if method not in ('lanczos', 'ED_block', 'default'):
+            raise ValueError("Unknown diagonalization method: " + repr(method))
+        use_ed = method == 'ED_block' or (method == 'default' and eff_H.N < self.options.get('max_N_for_ED', 400))
+        if use_ed and op is eff_H and hasattr(eff_H, 'to_matrix_array'):
+            E0, theta = full_diag_effH(eff_H, theta_guess)
+            return E0, theta, -1
+        return LanczosGroundState(op, theta_guess, self.lanczos_params).run()
 
     # ---- orthogonalisation against other states (reference mps_common.py:524-540, :569-593) -------------------------
     def _wrap_ortho_eff_H(self, eff_H, i0, n):
@@ -377,7 +390,7 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
         theta = eff_H.combine_theta(psi.get_theta(i0, n=1))
         op = self._wrap_ortho_eff_H(eff_H, i0, 1)
         tick('heff')
-        E0, theta, N = LanczosGroundState(op, theta, self.lanczos_params).run()
+        E0, theta, N = self.diag(eff_H, op, theta)
         tick('lanczos')
         U, S, VH, err, S_a = self.mixed_svd(eff_H, theta, i0, move_right)
         tick('svd')

@@ -22,7 +22,7 @@ import numpy as np
 from ..linalg import _device as dev
 from ..linalg import np_conserved as npc
 
-__all__ = ['TwoSiteH', 'OneSiteH', 'DensityMatrixMixer', 'SubspaceExpansion']
+__all__ = ['TwoSiteH', 'OneSiteH', 'DensityMatrixMixer', 'SubspaceExpansion', 'full_diag_effH']
 
 
 FUSED_HEFF = True     # tuning / test hook: False forces the generic tensordot + combine_legs construction
@@ -540,6 +540,12 @@ class TwoSiteH:
         env.set_RP(i, RP)
         return RP
 
+    def to_matrix_array(self):
+        """The effective Hamiltonian contracted to a device matrix with legs [(vL.p0.p1.vR)-like pipe, its conj]
+        (reference ``TwoSiteH.to_matrix`` :1392) -- for the exact diagonalisation of small bonds (``full_diag_effH``)."""
+        contr = npc.tensordot(self.LHeff, self.RHeff, axes=['wR', 'wL'])
+        return contr.combine_legs([['(vR*.p0)', '(p1.vL*)'], ['(vR.p0*)', '(p1*.vL)']], qconj=[+1, -1])
+
     def to_matrix(self):
         """Dense effective Hamiltonian on the host (tests only)."""
         L, R = self.LHeff.to_ndarray(), self.RHeff.to_ndarray()
@@ -654,6 +660,14 @@ class OneSiteH:
             env.set_RP(i, RP)
             return RP
         return env.get_RP(i, store=True)
+
+    def to_matrix_array(self):
+        """Device matrix of the one-site effective Hamiltonian (reference ``OneSiteH.to_matrix`` :1195)."""
+        if self.move_right:
+            contr = npc.tensordot(self.LHeff, self.RP, axes=['wR', 'wL'])
+            return contr.combine_legs([['(vR*.p0)', 'vL*'], ['(vR.p0*)', 'vL']], qconj=[+1, -1])
+        contr = npc.tensordot(self.LP, self.RHeff, axes=['wR', 'wL'])
+        return contr.combine_legs([['vR*', '(p0.vL*)'], ['vR', '(p0*.vL)']], qconj=[+1, -1])
 
     def to_matrix(self):
         """Dense effective Hamiltonian on the host (tests only), rows/columns in the order of ``acts_on``."""
@@ -881,3 +895,37 @@ class SubspaceExpansion:
             VH.ireplace_label('(p0.vR)', '(p1.vR)')
             return U, S, VH, err, S
         raise ValueError("Expected mix_left=True and/or mix_right=True.")
+
+
+def full_diag_effH(effH, theta_guess):
+    """Exact diagonalisation of a small effective Hamiltonian in the charge sector of ``theta_guess`` -- the
+    ``diag_method='ED_block'`` of the reference (``full_diag_effH(..., keep_sector=True)``, dmrg.py:1177), which its default
+    ``diag_method='default'`` uses below ``max_N_for_ED`` = 400.  Device version: contract H_eff to a matrix (one block GEMM
+    + one packing copy), project both legs onto the sector (gather kernel), block ``eigh`` (Jacobi), and read the lowest
+    eigenvector off with ``take_slice``.  Returns ``(E0, theta)`` with theta in the form ``effH.acts_on``."""
+    factored = bool(getattr(effH, 'factored', False))
+    if factored:                         # the factored two-site operator acts on [vL, p0, p1, vR]: fuse for the matrix form
+        theta_guess = effH.prepare_svd(theta_guess)
+    acts_on = list(theta_guess.get_leg_labels())
+    fullH = effH.to_matrix_array()
+    pipe = fullH.legs[0]
+    th = theta_guess.combine_legs([acts_on], pipes=[pipe])
+    qi = pipe.get_qindex_of_charges(th.qtotal)
+    sl = pipe.get_slice(qi)
+    mask = np.zeros(pipe.ind_len, dtype=bool)
+    mask[sl] = True
+    block = fullH.copy(deep=False)
+    block.iproject([mask, mask], axes=[0, 1])
+    if block.stored_blocks == 0:         # H vanishes in this sector: nothing to diagonalise (reference :1199)
+        return 0., theta_guess
+    E, V = npc.eigh(block)
+    i0 = int(np.argmin(E))
+    vec = V.take_slice(i0, 1)            # leg: the projected pipe (one sector)
+    theta = npc.Array([pipe], np.result_type(fullH.dtype, theta_guess.dtype), th.qtotal, list(th._labels))
+    if vec.stored_blocks:
+        src = vec if vec.dtype == theta.dtype else vec.astype(theta.dtype)
+        theta._set_blocks(np.array([[qi]], dtype=np.intp), arena=src._repack()._arena, qdata_sorted=True)
+    theta = theta.split_legs([0])
+    if list(theta.get_leg_labels()) != acts_on:
+        theta = theta.transpose(acts_on)
+    return float(E[i0]), (effH.combine_theta(theta) if factored else theta)

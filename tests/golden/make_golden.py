@@ -669,7 +669,39 @@ def gen_dmrg_ortho():
     save('dmrg_ortho.pkl', out)
 
 
-GENERATORS = dict(dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_dmrg_default_diag():
+    """Two-site DMRG with the reference's DEFAULT diagonalisation (ED below max_N_for_ED=400, Lanczos above) and with
+    'ED_block' everywhere (small chi)."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for (L, chi, method, engine) in ((14, 24, 'default', 'two'), (10, 8, 'ED_block', 'two'), (12, 12, 'ED_block', 'single')):
+            M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.8, 'hz': 0.1, 'bc_MPS': 'finite', 'sort_charge': True})
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+            opts = {'combine': True, 'diag_method': method, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10 if engine == 'two' else 1.e-6}}
+            if engine == 'two':
+                opts['mixer'] = None
+                eng = dmrg.TwoSiteDMRGEngine(psi, M, opts)
+            else:
+                opts.update(mixer=True, mixer_params={'amplitude': 1.e-3, 'decay': 2., 'disable_after': 3})
+                eng = dmrg.SingleSiteDMRGEngine(psi, M, opts)
+            eng.mixer_activate()
+            Es = []
+            for s_ in range(5):
+                eng.sweep()
+                Es.append(float(eng.update_stats['E_total'][-1]))
+            eng.mixer_cleanup()
+            out.append(dict(L=L, Jxx=1., Jz=0.8, hz=0.1, chi=chi, diag_method=method, engine=engine, E_sweeps=Es,
+                            E_updates=[float(e) for e in eng.update_stats['E_total']], N_lanczos=[int(n) for n in eng.update_stats['N_lanczos']],
+                            svd_min=opts['trunc_params']['svd_min'], S=[np.array(psi.get_SL(i)) for i in range(1, L)]))
+            print('dmrg_default_diag', L, chi, method, engine, Es[-1], sorted(set(out[-1]['N_lanczos']))[:5])
+    save('dmrg_default_diag.pkl', out)
+
+
+GENERATORS = dict(dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
