@@ -39,6 +39,11 @@ class TwoSiteDMRGEngine:
         self.update_stats = {k: [] for k in ['i0', 'E_total', 'N_lanczos', 'time', 'err', 'chi', 'flops', 'bytes']}
         self.sweep_stats = {k: [] for k in ['sweep', 'E', 'S', 'time', 'max_trunc_err', 'max_chi', 'N_updates']}
         self.E_trunc_list = []
+        self._entropy_approx = [None] * psi.L     # entropy of the approximate Schmidt values, left of a given site
+        self._meas_E_trunc = False
+        self._in_iteration = False
+        self.n_optimize = 2
+        self.N_sweeps_check = options.get('N_sweeps_check', 1)
         self.time0 = time.time()
         self.log_matvec = options.get('log_matvec', False)
         self.matvec_log = []
@@ -146,8 +151,11 @@ class TwoSiteDMRGEngine:
         update_LP_RP = [[True, False]] * (L - 2) + [[False, True]] * (L - 2)
         return list(zip(i0s, move_right, update_LP_RP))
 
-    def sweep(self, optimize=True):
-        """One sweep = 2(L-2) two-site updates.  Returns the maximal truncation error."""
+    def sweep(self, optimize=True, meas_E_trunc=False):
+        """One sweep = 2(L-2) two-site updates.  Returns the maximal truncation error.  ``meas_E_trunc``: also evaluate
+        ``<psi|H|psi>`` after every truncation (one full contraction per update, reference dmrg.py:520/:589)."""
+        self._meas_E_trunc = meas_E_trunc
+        self.E_trunc_list = []
         if self.chi_list is not None:
             keys = [k for k in self.chi_list if k <= self.sweeps]
             if keys:
@@ -163,6 +171,8 @@ class TwoSiteDMRGEngine:
         self.sweeps += 1
         if self.mixer is not None and self.mixer.update_amplitude(self.sweeps) is None:
             self.mixer_deactivate()
+        if self._in_iteration:          # run(): the statistics of an iteration are collected by run_iteration
+            return max_err
         st = self.sweep_stats
         st['sweep'].append(self.sweeps)
         st['E'].append(self.update_stats['E_total'][-1])
@@ -239,6 +249,7 @@ class TwoSiteDMRGEngine:
         us['chi'].append(len(S_a))
         us['flops'].append(eff_H.flops_per_matvec)
         us['bytes'].append(eff_H.bytes_per_matvec)
+        self._post_update(i0, 2, move_right, float(E0), S_a)
         if self.log_matvec:
             self.matvec_log.append((i0, N, eff_H.flops_per_matvec, eff_H.bytes_per_matvec, theta.shape))
         return err
@@ -301,27 +312,106 @@ class TwoSiteDMRGEngine:
             self.phase_time[phase] += now - self._t_phase
         self._t_phase = now
 
-    def run(self):
-        """Sweep until converged (``max_E_err``) or ``max_sweeps``; returns ``(E, psi)``."""
+    def _post_update(self, i0, n_opt, move_right, E0, S_approx):
+        """Entropy of the (approximate) Schmidt values of the updated bond and, if requested, the truncation energy
+        (reference dmrg.py:570, :587-594)."""
+        S_approx = np.asarray(S_approx)
+        p = S_approx**2
+        p = p[p > 1.e-30]
+        self._entropy_approx[(i0 + n_opt - 1) % self.psi.L] = float(-np.inner(np.log(p), p))
+        E_trunc = None
+        if self._meas_E_trunc:
+            i = i0 if (n_opt == 2 or move_right) else i0 - 1
+            E_trunc = float(np.real(self.env.full_contraction(i))) - E0
+        self.update_stats.setdefault('E_trunc', []).append(E_trunc)
+        self.E_trunc_list.append(E_trunc)
+
+    # ---- the reference's main loop (IterativeSweeps.run, mps_common.py:796; DMRGEngine.run_iteration, dmrg.py:219) --------
+    def run_iteration(self):
+        """``N_sweeps_check`` sweeps, then the Lanczos tolerances follow the truncation error (``P_tol_to_trunc`` = 0.05,
+        ``P_tol_min`` / ``P_tol_max``; ``E_tol_to_trunc`` = None, ``E_tol_min`` / ``E_tol_max``) and the statistics of the
+        iteration are appended to ``sweep_stats`` (same keys as the reference)."""
         opt = self.options
-        max_sweeps = opt.get('max_sweeps', 1000)
-        min_sweeps = opt.get('min_sweeps', 1)
-        max_E_err = opt.get('max_E_err', 1.e-8)
-        n_check = opt.get('N_sweeps_check', 1)
-        E_old = None
+        st = self.sweep_stats
+        for k in ('Delta_E', 'Delta_S', 'max_S', 'max_E_trunc', 'norm_err'):
+            st.setdefault(k, [])
+        p_tol_to_trunc = opt.get('P_tol_to_trunc', 0.05)
+        if p_tol_to_trunc is not None:
+            svd_min = self.trunc_params.get('svd_min', 0.) or 0.
+            trunc_cut = self.trunc_params.get('trunc_cut', 0.) or 0.
+            p_tol_min = opt.get('P_tol_min', max(1.e-30, svd_min**2 * p_tol_to_trunc, trunc_cut**2 * p_tol_to_trunc))
+            p_tol_max = opt.get('P_tol_max', 1.e-4)
+        e_tol_to_trunc = opt.get('E_tol_to_trunc', None)
+        if e_tol_to_trunc is not None:
+            e_tol_min, e_tol_max = opt.get('E_tol_min', 5.e-16), opt.get('E_tol_max', 1.e-4)
+        if len(st['E']) < 1:
+            E_old, S_old = np.nan, float(np.mean(self.psi.entanglement_entropy()))
+        else:
+            E_old, S_old = st['E'][-1], st['S'][-1]
+        self._in_iteration = True
+        try:
+            for _ in range(self.N_sweeps_check - 1):
+                self.sweep(meas_E_trunc=False)
+            max_trunc_err = self.sweep(meas_E_trunc=True)
+        finally:
+            self._in_iteration = False
+        max_E_trunc = float(np.max(self.E_trunc_list))
+        if p_tol_to_trunc is not None and max_trunc_err > p_tol_min:
+            self.lanczos_params['P_tol'] = max(p_tol_min, min(p_tol_max, max_trunc_err * p_tol_to_trunc))
+        if e_tol_to_trunc is not None and max_E_trunc > e_tol_min:
+            self.lanczos_params['E_tol'] = max(e_tol_min, min(e_tol_max, max_E_trunc * e_tol_to_trunc))
+        entropy_bonds = self._entropy_approx[1:]
+        E = self.update_stats['E_total'][-1]
+        S = float(np.mean(entropy_bonds))
+        st['sweep'].append(self.sweeps)
+        st['N_updates'].append(len(self.update_stats['i0']))
+        st['E'].append(E)
+        st['Delta_E'].append((E - E_old) / self.N_sweeps_check)
+        st['S'].append(S)
+        st['Delta_S'].append((S - S_old) / self.N_sweeps_check)
+        st['max_S'].append(float(max(entropy_bonds)))
+        st['time'].append(time.time() - self.time0)
+        st['max_trunc_err'].append(max_trunc_err)
+        st['max_E_trunc'].append(max_E_trunc)
+        st['max_chi'].append(int(np.max(self.psi.chi)))
+        st['norm_err'].append(abs(abs(self.psi.norm_test()) - 1.) if not any(isinstance(x, npc.Array) for x in self.psi._S) else np.nan)
+        return E, self.psi
+
+    def is_converged(self):
+        """``|Delta E / max(E, 1)| < max_E_err`` (1e-8) and ``|Delta S| < max_S_err`` (1e-5)  (reference dmrg.py:376)."""
+        max_E_err = self.options.get('max_E_err', 1.e-8)
+        max_S_err = self.options.get('max_S_err', 1.e-5)
+        st = self.sweep_stats
+        if not st.get('Delta_E'):           # no iteration of run() yet (e.g. right after resuming from a checkpoint)
+            return False
+        E, Delta_E, Delta_S = st['E'][-1], st['Delta_E'][-1], st['Delta_S'][-1]
+        return abs(Delta_E / max(E, 1.)) < max_E_err and abs(Delta_S) < max_S_err
+
+    def stopping_criterion(self):
+        """Reference mps_common.py:869: ``max_sweeps`` (1000), ``min_sweeps`` (1), convergence with the mixer still on
+        switches the mixer off and goes on; ``max_hours``."""
+        opt = self.options
+        if self.sweeps > opt.get('max_sweeps', 1000):
+            return True
+        if self.sweeps > opt.get('min_sweeps', 1) and self.is_converged():
+            if self.mixer is None:
+                return True
+            self.mixer_deactivate()
+            return False
+        if time.time() - self.time0 > 3600. * opt.get('max_hours', 24 * 365):
+            self.shelve = True
+            return True
+        return False
+
+    def run(self):
+        """The reference's ``DMRGEngine.run()``: iterate ``run_iteration`` until ``stopping_criterion``; returns ``(E, psi)``."""
+        self.shelve = False
         self.mixer_activate()
-        while self.sweeps < max_sweeps:
-            for _ in range(n_check):
-                self.sweep()
-            E = self.sweep_stats['E'][-1]
-            if E_old is not None and self.sweeps >= min_sweeps:
-                if abs((E - E_old) / max(abs(E), 1.)) < max_E_err:
-                    if self.mixer is None:
-                        break
-                    self.mixer_deactivate()      # converged with the mixer still on: switch it off and go on (:905-914)
-            E_old = E
+        result = (np.nan, self.psi)
+        while not self.stopping_criterion():
+            result = self.run_iteration()
         self.mixer_cleanup()
-        return self.sweep_stats['E'][-1], self.psi
+        return result
 
 
 class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
@@ -331,6 +421,10 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
     and the tensors of sites i0 and i0+1 are updated, moving left the bond (i0-1, i0) and sites i0-1, i0
     (``_update_env_inds``, mps_common.py:595).  Shares sweep / run / checkpoint / mixer-cleanup logic with the two-site
     engine."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.n_optimize = 1
 
     def mixer_activate(self):
         which = self.options.get('mixer', True)
@@ -424,10 +518,13 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
         us['chi'].append(len(S_a))
         us['flops'].append(eff_H.flops_per_matvec)
         us['bytes'].append(eff_H.bytes_per_matvec)
+        self._post_update(i0, 1, move_right, float(E0), S_a)
         return err
 
 
-def run(psi, model_H, options):
-    eng = TwoSiteDMRGEngine(psi, model_H, options)
+def run(psi, model_H, options, **kwargs):
+    """Two-site DMRG like the reference's ``dmrg.run`` (dmrg.py:63); returns the same dict keys."""
+    eng = TwoSiteDMRGEngine(psi, model_H, options, **kwargs)
     E, psi = eng.run()
-    return {'E': E, 'sweep_statistics': eng.sweep_stats, 'update_statistics': eng.update_stats}
+    return {'E': E, 'shelve': eng.shelve, 'bond_statistics': eng.update_stats, 'sweep_statistics': eng.sweep_stats,
+            'update_statistics': eng.update_stats}

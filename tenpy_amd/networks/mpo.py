@@ -203,5 +203,9 @@ class MPOEnvironment:
             raise ValueError
         S = self.psi.get_SR(i0)
         RP = self.get_RP(i0, store=False)
-        LP = LP.scale_axis(S, 'vR').scale_axis(S, 'vR*')
+        if isinstance(S, npc.Array):     # general bond matrix of a sweep with mixer (reference mps.py:6715-6724)
+            LP = npc.tensordot(S.conj(), LP, axes=['vL*', 'vR*'])
+            LP = npc.tensordot(LP, S, axes=['vR', 'vL'])
+        else:
+            LP = LP.scale_axis(S, 'vR').scale_axis(np.conj(S), 'vR*')
         return npc.inner(LP, RP, axes=(['vR*', 'wR', 'vR'], ['vL*', 'wL', 'vL']), do_conj=False)

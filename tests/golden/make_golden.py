@@ -701,7 +701,49 @@ def gen_dmrg_default_diag():
     save('dmrg_default_diag.pkl', out)
 
 
-GENERATORS = dict(dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_dmrg_run():
+    """The reference's ``DMRGEngine.run()`` main loop with its default options (examples/d_dmrg.py parameters: TFI chain,
+    chi_max=30, svd_min=1e-10, max_E_err=1e-10, no mixer, combine, DEFAULT diag_method and Lanczos tolerances that follow
+    the truncation error), and an XXZ run with the mixer on by default parameters."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for case in ('tfi_d_dmrg', 'xxz_mixer'):
+            if case == 'tfi_d_dmrg':
+                L = 16
+                M = TFIChain({'L': L, 'J': 1., 'g': 1., 'bc_MPS': 'finite', 'conserve': None})
+                psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+                opts = {'mixer': None, 'max_E_err': 1.e-10, 'trunc_params': {'chi_max': 30, 'svd_min': 1.e-10}, 'combine': True}
+                extra = dict(L=L, J=1., g=1., conserve=None)
+            else:
+                L = 12
+                M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+                psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+                opts = {'mixer': True, 'mixer_params': {'amplitude': 1.e-4, 'decay': 2., 'disable_after': 4}, 'max_E_err': 1.e-9,
+                        'trunc_params': {'chi_max': 20, 'svd_min': 1.e-6}, 'combine': True, 'max_N_for_ED': 0}
+                extra = dict(L=L, Jxx=1., Jz=1., hz=0., conserve='Sz')
+            import copy
+            opts_plain = copy.deepcopy(opts)
+            eng = dmrg.TwoSiteDMRGEngine(psi, M, opts)
+            E, _ = eng.run()
+            st = eng.sweep_stats
+            rec = dict(case=case, E=float(E), sweeps=int(eng.sweeps), P_tol_final=float(eng.lanczos_params['P_tol']),
+                       N_lanczos=[int(n) for n in eng.update_stats['N_lanczos']], E_updates=[float(e) for e in eng.update_stats['E_total']],
+                       E_trunc=[None if e is None else float(e) for e in eng.update_stats['E_trunc']],
+                       sweep_stats={k: [float(x) for x in st[k]] for k in ('sweep', 'N_updates', 'E', 'Delta_E', 'S', 'Delta_S', 'max_S',
+                                                                              'max_trunc_err', 'max_E_trunc', 'max_chi')},
+                       options=opts_plain)
+            rec.update(extra)
+            out.append(rec)
+            print('dmrg_run', case, E, eng.sweeps, eng.lanczos_params['P_tol'])
+    save('dmrg_run.pkl', out)
+
+
+GENERATORS = dict(dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

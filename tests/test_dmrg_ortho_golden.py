@@ -61,3 +61,46 @@ def test_dmrg_with_exact_diagonalisation_of_small_bonds(backend):
         eng.mixer_cleanup()
         for i in range(1, L):
             np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i - 1])[::-1], rtol=0, atol=1e-9)
+
+
+def test_dmrg_run_main_loop(backend):
+    """``TwoSiteDMRGEngine.run()`` = the reference's main loop (run_iteration / is_converged / stopping_criterion): same
+    number of sweeps, same statistics per iteration, same Lanczos iteration counts (P_tol follows the truncation error),
+    for the parameters of examples/d_dmrg.py (on L=16: E = -20.01638790048513, examples/userguide/f_dmrg_finite.py) and
+    for a run that converges with the mixer still on."""
+    from tenpy_amd.models.spin_chains import tfi_chain_mpo
+    for rec in golden('dmrg_run.pkl'):
+        L = rec['L']
+        if rec['case'] == 'tfi_d_dmrg':
+            H = tfi_chain_mpo(L, rec['J'], rec['g'], conserve=None)
+            _, p = spin_half_leg(None)
+            psi = MPS.from_product_state([p] * L, [1] * L)          # all 'up' (index 1 in this package's leg order)
+            opts = dict(rec['options'], diag_method='default')      # the reference's default diag_method
+        else:
+            H = xxz_chain_mpo(L, rec['Jxx'], rec['Jz'], rec['hz'])
+            _, p = spin_half_leg('Sz')
+            psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
+            opts = dict(rec['options'])
+        eng = TwoSiteDMRGEngine(psi, H, opts)
+        E, _ = eng.run()
+        assert eng.sweeps == rec['sweeps']
+        assert abs(E - rec['E']) <= 1e-10 * abs(rec['E'])
+        if rec['case'] == 'tfi_d_dmrg':
+            assert abs(E - (-20.01638790048513)) < 1e-9
+        Nm, Nr = np.array(eng.update_stats['N_lanczos']), np.array(rec['N_lanczos'])
+        assert np.array_equal(Nm == -1, Nr == -1)                       # same choice ED / Lanczos on every bond
+        # (once P_tol has followed the truncation error down to ~1e-21, the Krylov iteration stops on rounding noise:
+        #  the count may differ by a step or two on a few bonds)
+        assert np.all(np.abs(Nm - Nr) <= 2) and np.mean(Nm == Nr) > 0.85
+        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-10)
+        # P_tol = 0.05 * (largest truncation error of the last sweep); that error is ~1e-20 here, i.e. rounding noise
+        np.testing.assert_allclose(eng.lanczos_params['P_tol'], rec['P_tol_final'], rtol=0.2, atol=1e-21)
+        for k, tol in (('sweep', 0), ('N_updates', 0), ('E', 1e-10), ('Delta_E', 1e-9), ('S', 1e-8), ('Delta_S', 1e-8), ('max_S', 1e-8),
+                       ('max_trunc_err', 1e-11), ('max_E_trunc', 1e-9), ('max_chi', 0.04)):     # (chi: +-1, a Schmidt value at svd_min)
+            a, b = np.array(eng.sweep_stats[k], dtype=float), np.array(rec['sweep_stats'][k], dtype=float)
+            assert a.shape == b.shape, k
+            ok = np.isnan(b) | (np.abs(a - b) <= tol * np.maximum(1., np.abs(b)))
+            assert np.all(ok), (k, a, b)
+        et = [e for e in rec['E_trunc'] if e is not None]
+        mine = [e for e in eng.update_stats['E_trunc'] if e is not None]
+        np.testing.assert_allclose(mine, et, rtol=0, atol=1e-9)
