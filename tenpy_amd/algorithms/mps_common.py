@@ -22,7 +22,7 @@ import numpy as np
 from ..linalg import _device as dev
 from ..linalg import np_conserved as npc
 
-__all__ = ['TwoSiteH', 'OneSiteH', 'DensityMatrixMixer', 'SubspaceExpansion', 'full_diag_effH']
+__all__ = ['TwoSiteH', 'OneSiteH', 'ZeroSiteH', 'DensityMatrixMixer', 'SubspaceExpansion', 'full_diag_effH']
 
 
 FUSED_HEFF = True     # tuning / test hook: False forces the generic tensordot + combine_legs construction
@@ -563,8 +563,6 @@ class OneSiteH:
     length = 1
 
     def __init__(self, env, i0, combine=True, move_right=True, tensors=None):
-        if not combine:
-            raise NotImplementedError("tenpy_amd.OneSiteH: only combine=True")
         self.i0 = i0
         self.combine = combine
         self.move_right = move_right
@@ -582,7 +580,10 @@ class OneSiteH:
         self.N = self.LP.get_leg('vR').ind_len * self.W0.get_leg('p0').ind_len * self.RP.get_leg('vL').ind_len
         self.flops_per_matvec = None
         self.bytes_per_matvec = None
-        self.combine_Heff(self._env)
+        if combine:
+            self.combine_Heff(self._env)
+        else:
+            self.acts_on = ['vL', 'p0', 'vR']
 
     def combine_Heff(self, env=None):
         cache = getattr(env, '_heff_cache', None) if env is not None else None
@@ -623,6 +624,8 @@ class OneSiteH:
             self.acts_on = ['vL', '(p0.vR)']
 
     def combine_theta(self, theta):
+        if not self.combine:
+            return theta if list(theta.get_leg_labels()) == self.acts_on else theta.transpose(self.acts_on)
         if self.move_right:
             theta = theta.combine_legs(['vL', 'p0'], pipes=self.pipeL)
         else:
@@ -630,7 +633,13 @@ class OneSiteH:
         return theta if list(theta.get_leg_labels()) == self.acts_on else theta.transpose(self.acts_on)
 
     def matvec(self, theta):
-        """Reference :1118-1151 (combine branch)."""
+        """Reference :1118-1151."""
+        if not self.combine:             # LP - W0 - RP applied to [vL, p0, vR] (three contractions)
+            res = npc.tensordot(self.LP, theta, axes=['vR', 'vL'])
+            res = npc.tensordot(self.W0, res, axes=[['wL', 'p0*'], ['wR', 'p0']])
+            res = npc.tensordot(res, self.RP, axes=[['wR', 'vR'], ['wL', 'vL']])
+            res.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
+            return res if list(res.get_leg_labels()) == self.acts_on else res.transpose(self.acts_on)
         if self.move_right:
             tmp = npc.tensordot(self.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])            # (vR*.p0), wR, vR
             res = npc.tensordot(tmp, self.RP, axes=[['wR', 'vR'], ['wL', 'vL']])            # (vR*.p0), vL*
@@ -643,7 +652,7 @@ class OneSiteH:
 
     def update_LP(self, env, i, U=None):
         """Reference :1226.  Moving right: LP(i0+1) = U^dagger LHeff U; otherwise the generic contraction."""
-        if self.move_right:
+        if self.combine and self.move_right:
             assert i == self.i0 + 1
             LP = npc.tensordot(self.LHeff, U, axes=['(vR.p0*)', '(vL.p)'])
             LP = npc.tensordot(U.conj(), LP, axes=['(vL*.p*)', '(vR*.p0)'])                 # vR*, wR, vR
@@ -653,7 +662,7 @@ class OneSiteH:
 
     def update_RP(self, env, i, VH=None):
         """Reference :1235.  Moving left: RP(i0-1) = RHeff VH VH^dagger."""
-        if self.move_right is False:
+        if self.combine and self.move_right is False:
             assert i == self.i0 - 1
             RP = npc.tensordot(VH, self.RHeff, axes=['(p.vR)', '(p0*.vL)'])                 # vL, wL, (p0.vL*)
             RP = npc.tensordot(RP, VH.conj(), axes=['(p0.vL*)', '(p*.vR*)'])                # vL, wL, vL*
@@ -679,6 +688,26 @@ class OneSiteH:
         full = full.transpose(0, 2, 1, 3)        # out_L, out_R, in_L, in_R
         n = full.shape[0] * full.shape[1]
         return full.reshape(n, n)
+
+
+class ZeroSiteH:
+    """Zero-site effective Hamiltonian ``LP - RP`` on the bond left of site ``i0`` (reference mps_common.py:1440-1530):
+    acts on a bond matrix [vL, vR]; used by the backward time step of single-site TDVP."""
+    length = 0
+    acts_on = ['vL', 'vR']
+
+    def __init__(self, env, i0):
+        self.i0 = i0
+        self.LP = env.get_LP(i0)
+        self.RP = env.get_RP(i0 - 1)
+        self.dtype = env.H.dtype
+        self.N = self.LP.get_leg('vR').ind_len * self.RP.get_leg('vL').ind_len
+
+    def matvec(self, theta):
+        res = npc.tensordot(self.LP, theta, axes=['vR', 'vL'])
+        res = npc.tensordot(res, self.RP, axes=[['wR', 'vR'], ['wL', 'vL']])
+        res.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
+        return res if list(res.get_leg_labels()) == self.acts_on else res.transpose(self.acts_on)
 
 
 class DensityMatrixMixer:

@@ -27,6 +27,7 @@ class MPS:
         self.dtype = Bs[0].dtype
         self.finite = True
         self.bc = 'finite'
+        self.norm = 1.                       # tracked by the time-evolution engines (reference MPS.norm)
 
     @classmethod
     def from_product_state(cls, p_legs, p_state, dtype=np.float64):

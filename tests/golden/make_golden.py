@@ -743,7 +743,39 @@ def gen_dmrg_run():
     save('dmrg_run.pkl', out)
 
 
-GENERATORS = dict(dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_tdvp():
+    """Real-time TDVP after a quench from the Neel state (XXZ, Sz conserved): two-site engine growing the bond dimension,
+    then the single-site engine continuing on the same state."""
+    from tenpy.algorithms import tdvp
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 8
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.7, 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        opts = {'dt': 0.05, 'N_steps': 2, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 2, 'N_max': 20}}
+        eng = tdvp.TwoSiteTDVPEngine(psi, M, dict(opts))
+        recs = []
+        for rep in range(4):
+            eng.run()
+            recs.append(dict(engine='two', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
+                             Sz=np.array(psi.expectation_value('Sz')), norm=float(psi.norm), t=float(eng.evolved_time),
+                             trunc_err=float(eng.trunc_err.eps)))
+        eng1 = tdvp.SingleSiteTDVPEngine(psi, M, dict(opts))
+        for rep in range(4):
+            eng1.run()
+            recs.append(dict(engine='single', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
+                             Sz=np.array(psi.expectation_value('Sz')), norm=float(psi.norm), t=float(eng1.evolved_time),
+                             trunc_err=float(eng1.trunc_err.eps)))
+        out.append(dict(L=L, Jxx=1., Jz=0.7, hz=0., options=opts, steps=recs,
+                        E=float(np.real(M.H_MPO.expectation_value(psi)))))
+        print('tdvp', [r['chi'] for r in recs][-1], recs[-1]['S'], recs[-1]['norm'])
+    save('tdvp.pkl', out)
+
+
+GENERATORS = dict(tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
