@@ -40,6 +40,21 @@ FACTORED_MIN_SECTOR = 200
 # blocks -- as a GEMM it has inner dimension 1 per link (64072 almost empty 64 x 64 tiles for a chi = 2048 Heisenberg
 # bond, 1.4 ms) and is followed by a 131 MB repacking copy (combine_legs, 0.2 ms).  ``tpa_lincomb_batch`` writes every
 # (w', p, p*) slab of the fused tensor directly at its place inside the pipe blocks.
+def _env_set_LP(env, i, LP):
+    """``env.set_LP`` with the age (number of physical sites in the part) of the reference (mps_common.py:1427)."""
+    if hasattr(env, 'get_LP_age'):
+        env.set_LP(i, LP, age=(env.get_LP_age(i - 1) or 0) + 1)
+    else:
+        env.set_LP(i, LP)
+
+
+def _env_set_RP(env, i, RP):
+    if hasattr(env, 'get_RP_age'):
+        env.set_RP(i, RP, age=(env.get_RP_age(i + 1) or 0) + 1)
+    else:
+        env.set_RP(i, RP)
+
+
 def _mpo_entries(W):
     """(qdata, values) of an MPO tensor whose stored blocks are all 1 x 1 x 1 x 1, else ``None`` (cached on W)."""
     ent = getattr(W, '_tpa_entries', False)
@@ -517,11 +532,11 @@ class TwoSiteH:
             X = MpoApplyPlan.get(X, self.W0, 'wR', 'p0', 'wL', 'wR', 'p0', 'p0*', ('vR*', 'p0', 'wR', 'vR')).apply(X)
             LP = npc.tensordot(A.conj(), X, axes=(['vL*', 'p0*'], ['vR*', 'p0']))   # vR*, wR, vR
             LP = _relabel_view(LP, list(self.LP.get_leg_labels()))
-            env.set_LP(i, LP)
+            _env_set_LP(env, i, LP)
             return LP
         LP = npc.tensordot(self.LHeff, U, axes=['(vR.p0*)', '(vL.p0)'])
         LP = npc.tensordot(U.conj(), LP, axes=['(vL*.p0*)', '(vR*.p0)'])      # vR*, wR, vR
-        env.set_LP(i, LP)
+        _env_set_LP(env, i, LP)
         return LP
 
     def update_RP(self, env, i, VH=None):
@@ -533,11 +548,11 @@ class TwoSiteH:
             X = MpoApplyPlan.get(X, self.W1, 'wL', 'p1', 'wR', 'wL', 'p1', 'p1*', ('vL', 'wL', 'p1', 'vL*')).apply(X)
             RP = npc.tensordot(X, B.conj(), axes=(['p1', 'vL*'], ['p1*', 'vR*']))   # vL, wL, vL*
             RP = _relabel_view(RP, list(self.RP.get_leg_labels()))
-            env.set_RP(i, RP)
+            _env_set_RP(env, i, RP)
             return RP
         RP = npc.tensordot(VH, self.RHeff, axes=['(p1.vR)', '(p1*.vL)'])      # vL, wL, (p1.vL*)
         RP = npc.tensordot(RP, VH.conj(), axes=['(p1.vL*)', '(p1*.vR*)'])     # vL, wL, vL*
-        env.set_RP(i, RP)
+        _env_set_RP(env, i, RP)
         return RP
 
     def to_matrix_array(self):
@@ -656,7 +671,7 @@ class OneSiteH:
             assert i == self.i0 + 1
             LP = npc.tensordot(self.LHeff, U, axes=['(vR.p0*)', '(vL.p)'])
             LP = npc.tensordot(U.conj(), LP, axes=['(vL*.p*)', '(vR*.p0)'])                 # vR*, wR, vR
-            env.set_LP(i, LP)
+            _env_set_LP(env, i, LP)
             return LP
         return env.get_LP(i, store=True)
 
@@ -666,7 +681,7 @@ class OneSiteH:
             assert i == self.i0 - 1
             RP = npc.tensordot(VH, self.RHeff, axes=['(p.vR)', '(p0*.vL)'])                 # vL, wL, (p0.vL*)
             RP = npc.tensordot(RP, VH.conj(), axes=['(p0.vL*)', '(p*.vR*)'])                # vL, wL, vL*
-            env.set_RP(i, RP)
+            _env_set_RP(env, i, RP)
             return RP
         return env.get_RP(i, store=True)
 

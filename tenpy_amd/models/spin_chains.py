@@ -29,7 +29,7 @@ def spin_half_leg(conserve='Sz'):
     return chinfo, leg
 
 
-def xxz_chain_mpo(L, Jxx=1., Jz=1., hz=0., conserve='Sz'):
+def xxz_chain_mpo(L, Jxx=1., Jz=1., hz=0., conserve='Sz', bc='finite'):
     chinfo, p = spin_half_leg(conserve)
     Sp = np.array([[0., 0.], [1., 0.]])    # |up><down| in (down, up) basis: Sp[1,0] = 1
     Sm = Sp.T.copy()
@@ -46,13 +46,15 @@ def xxz_chain_mpo(L, Jxx=1., Jz=1., hz=0., conserve='Sz'):
     W[2, 4] = 0.5 * Jxx * Sp
     W[3, 4] = Jz * Sz
     W[4, 4] = Id
+    if bc == 'infinite':
+        return mpo_from_dense([W] * L, [p] * L, chinfo, IdL=0, IdR=-1, bc='infinite')
     Ws = [W[0:1] if i == 0 else (W[:, 4:5] if i == L - 1 else W) for i in range(L)]
     H = mpo_from_dense(Ws, [p] * L, chinfo)
     H.IdL, H.IdR = 0, -1
     return H
 
 
-def tfi_chain_mpo(L, J=1., g=1., conserve=None):
+def tfi_chain_mpo(L, J=1., g=1., conserve=None, bc='finite'):
     chinfo, p = spin_half_leg('parity' if conserve == 'parity' else None)
     sx = np.array([[0., 1.], [1., 0.]])
     sz = np.diag([-1., 1.])      # (down, up)
@@ -64,6 +66,8 @@ def tfi_chain_mpo(L, J=1., g=1., conserve=None):
     W[0, 2] = -g * sz
     W[1, 2] = -J * sx
     W[2, 2] = Id
+    if bc == 'infinite':
+        return mpo_from_dense([W] * L, [p] * L, chinfo, IdL=0, IdR=-1, bc='infinite')
     Ws = [W[0:1] if i == 0 else (W[:, 2:3] if i == L - 1 else W) for i in range(L)]
     H = mpo_from_dense(Ws, [p] * L, chinfo)
     H.IdL, H.IdR = 0, -1

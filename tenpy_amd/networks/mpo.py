@@ -15,7 +15,7 @@ __all__ = ['MPO', 'MPOEnvironment', 'mpo_from_dense']
 
 
 class MPO:
-    def __init__(self, p_legs, Ws, IdL=0, IdR=-1):
+    def __init__(self, p_legs, Ws, IdL=0, IdR=-1, bc='finite'):
         self.p_legs = list(p_legs)
         self._W = list(Ws)
         self.L = len(Ws)
@@ -23,16 +23,19 @@ class MPO:
         self.IdR = IdR
         self.chinfo = Ws[0].chinfo
         self.dtype = Ws[0].dtype
+        self.bc = bc
+        self.finite = (bc == 'finite')
+        self.explicit_plus_hc = False
 
     def get_W(self, i):
-        return self._W[i]
+        return self._W[i if self.finite else i % self.L]
 
     @property
     def chi(self):
         return [W.get_leg('wR').ind_len for W in self._W[:-1]]
 
 
-def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64, IdL=0, IdR=-1):
+def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64, IdL=0, IdR=-1, bc='finite'):
     """Build a finite MPO from dense ``W[i]`` of shape (D_l, D_r, d, d).  The charges of the virtual MPO legs are deduced
     from the non-zero entries (every entry must conserve charge) in two passes: forward from the left boundary (index
     ``IdL`` of the first leg = charge 0) and backward from the right boundary (index ``IdR`` of the last leg = charge 0).
@@ -87,6 +90,32 @@ def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64, IdL=0, IdR=-1
                 raise ValueError("MPO entry (%d,%d) on site %d violates charge conservation" % (a, b, i))
             q[a], k[a] = qa, True
         bq[i], bk[i] = q, k
+    if bc == 'infinite':
+        # the bond right of the last site IS the bond left of the first one: let both passes go around until nothing changes
+        for _ in range(2 * Ws_d[0].shape[0] + 2):
+            changed = False
+            new_k = fk[0] | fk[L]
+            if np.any(new_k != fk[0]) or np.any(new_k != fk[L]):
+                q = np.where(fk[0][:, None], fq[0], fq[L])
+                fq[0], fk[0] = q, new_k
+                changed = True
+                for i in range(L):
+                    for (a, b), (s_, t_) in sorted(ents[i].items()):
+                        if fk[i][a] and not fk[i + 1][b]:
+                            fq[i + 1][b] = chinfo.make_valid(fq[i][a] + pqs[i][s_] - pqs[i][t_])
+                            fk[i + 1][b] = True
+            new_k = bk[0] | bk[L]
+            if np.any(new_k != bk[0]) or np.any(new_k != bk[L]):
+                q = np.where(bk[L][:, None], bq[L], bq[0])
+                bq[L], bk[L] = q, new_k
+                changed = True
+                for i in range(L - 1, -1, -1):
+                    for (a, b), (s_, t_) in sorted(ents[i].items()):
+                        if bk[i + 1][b] and not bk[i][a]:
+                            bq[i][a] = chinfo.make_valid(bq[i + 1][b] - pqs[i][s_] + pqs[i][t_])
+                            bk[i][a] = True
+            if not changed:
+                break
     bond_q, bond_k = [], []
     for j in range(L + 1):
         both = fk[j] & bk[j]
@@ -104,22 +133,37 @@ def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64, IdL=0, IdR=-1
         W = npc.Array.from_ndarray(Wd, [wL, wR, p, p.conj()], dtype=dtype, qtotal=None if nq == 0 else chinfo.make_valid(),
                                    labels=['wL', 'wR', 'p', 'p*'])
         Ws.append(W)
-    return MPO(p_legs, Ws, IdL, IdR)
+    if bc == 'infinite':
+        Ws[0].get_leg('wL').test_contractible(Ws[-1].get_leg('wR'))
+    return MPO(p_legs, Ws, IdL, IdR, bc=bc)
 
 
 class MPOEnvironment:
-    """``<bra| H |ket>`` environments with bra = ket = psi; LP[i] is everything left of site i."""
+    """``<bra| H |ket>`` environments with bra = ket = psi; LP[i] is everything left of site i.  For an infinite MPS the
+    indices are taken modulo L: the stored LP[i] is the one most recently computed for ANY of the equivalent sites
+    i + n L (reference ``BaseEnvironment.get_LP``, mps.py:6429), and every part carries an ``age`` = number of physical
+    sites it contains (used for the energy per site of iDMRG)."""
 
     def __init__(self, psi, H):
         self.psi = self.ket = self.bra = psi
         self.H = H
         self.L = psi.L
+        self.finite = psi.finite
         self.dtype = np.result_type(psi.dtype, H.dtype)
         self._LP = [None] * self.L
         self._heff_cache = {}        # (side, site) -> (env tensor, fused Heff, pipe); see TwoSiteH.combine_Heff
         self._RP = [None] * self.L
-        self._LP[0] = self.init_LP(0)
-        self._RP[self.L - 1] = self.init_RP(self.L - 1)
+        self._LP_age = [None] * self.L
+        self._RP_age = [None] * self.L
+        self.set_LP(0, self.init_LP(0), age=0)
+        self.set_RP(self.L - 1, self.init_RP(self.L - 1), age=0)
+
+    def _idx(self, i):
+        if self.finite:
+            if not 0 <= i < self.L:
+                raise IndexError("environment index %d out of range" % i)
+            return i
+        return i % self.L
 
     def init_LP(self, i):
         leg_ket = self.psi.get_B(i, None).get_leg('vL')
@@ -128,8 +172,7 @@ class MPOEnvironment:
         IdL = self.H.IdL % leg_mpo.ind_len
         for j in range(leg_ket.ind_len):
             dense[j, IdL, j] = 1.
-        return npc.Array.from_ndarray(dense, [leg_ket.conj() if False else leg_ket, leg_mpo, leg_ket.conj()],
-                                      dtype=self.dtype, labels=['vR*', 'wR', 'vR'])
+        return npc.Array.from_ndarray(dense, [leg_ket, leg_mpo, leg_ket.conj()], dtype=self.dtype, labels=['vR*', 'wR', 'vR'])
 
     def init_RP(self, i):
         leg_ket = self.psi.get_B(i, None).get_leg('vR')
@@ -143,42 +186,61 @@ class MPOEnvironment:
 
     # The environment legs: LP has ('vR*', 'wR', 'vR') where 'vR' contracts with the ket's 'vL'.
     def get_LP(self, i, store=True):
-        if self._LP[i] is not None:
-            return self._LP[i]
-        j = i
-        while self._LP[j] is None:
-            j -= 1
-        LP = self._LP[j]
-        for k in range(j, i):
+        """LP left of site i from the nearest stored one (at most L sites to the left)."""
+        for i0 in range(i, i - self.L, -1):
+            if not self.finite or i0 >= 0:
+                LP = self._LP[self._idx(i0)]
+                if LP is not None:
+                    break
+        else:
+            raise ValueError("No left part in the system???")
+        age = self._LP_age[self._idx(i0)] or 0
+        for k in range(i0, i):
             LP = self._contract_LP(k, LP)
+            age = age + 1
             if store:
-                self._LP[k + 1] = LP
+                self.set_LP(k + 1, LP, age=age)
         return LP
 
     def get_RP(self, i, store=True):
-        if self._RP[i] is not None:
-            return self._RP[i]
-        j = i
-        while self._RP[j] is None:
-            j += 1
-        RP = self._RP[j]
-        for k in range(j, i, -1):
+        for i0 in range(i, i + self.L):
+            if not self.finite or i0 < self.L:
+                RP = self._RP[self._idx(i0)]
+                if RP is not None:
+                    break
+        else:
+            raise ValueError("No right part in the system???")
+        age = self._RP_age[self._idx(i0)] or 0
+        for k in range(i0, i, -1):
             RP = self._contract_RP(k, RP)
+            age = age + 1
             if store:
-                self._RP[k - 1] = RP
+                self.set_RP(k - 1, RP, age=age)
         return RP
 
-    def set_LP(self, i, LP):
-        self._LP[i] = LP
+    def get_LP_age(self, i):
+        return self._LP_age[self._idx(i)]
 
-    def set_RP(self, i, RP):
+    def get_RP_age(self, i):
+        return self._RP_age[self._idx(i)]
+
+    def set_LP(self, i, LP, age=None):
+        i = self._idx(i)
+        self._LP[i] = LP
+        if age is not None:
+            self._LP_age[i] = age
+
+    def set_RP(self, i, RP, age=None):
+        i = self._idx(i)
         self._RP[i] = RP
+        if age is not None:
+            self._RP_age[i] = age
 
     def del_LP(self, i):
-        self._LP[i] = None
+        self._LP[self._idx(i)] = None
 
     def del_RP(self, i):
-        self._RP[i] = None
+        self._RP[self._idx(i)] = None
 
     def _contract_LP(self, i, LP):
         """LP(i+1) from LP(i): contract with A[i], W[i], A*[i]  (reference mpo.py:3087)."""

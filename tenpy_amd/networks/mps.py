@@ -17,7 +17,11 @@ _FORMS = {'A': (1., 0.), 'B': (0., 1.), 'C': (0.5, 0.5), 'G': (0., 0.), 'Th': (1
 
 
 class MPS:
-    def __init__(self, p_legs, Bs, SVs, form='B'):
+    def __init__(self, p_legs, Bs, SVs, form='B', bc='finite'):
+        """``bc='infinite'``: the L tensors are the unit cell of an infinite MPS; site and bond indices are taken modulo L
+        (``_S[L]`` is kept identical to ``_S[0]``), as in the reference (mps.py ``_to_valid_site_index``)."""
+        if bc not in ('finite', 'infinite'):
+            raise ValueError("bc must be 'finite' or 'infinite'")
         self.p_legs = list(p_legs)          # physical leg of each site
         self.L = len(Bs)
         self._B = list(Bs)
@@ -25,13 +29,14 @@ class MPS:
         self.form = [_FORMS[form]] * self.L
         self.chinfo = Bs[0].chinfo
         self.dtype = Bs[0].dtype
-        self.finite = True
-        self.bc = 'finite'
+        self.bc = bc
+        self.finite = (bc == 'finite')
         self.norm = 1.                       # tracked by the time-evolution engines (reference MPS.norm)
 
     @classmethod
-    def from_product_state(cls, p_legs, p_state, dtype=np.float64):
-        """Product state; ``p_state[i]`` is the flat physical index occupied on site i."""
+    def from_product_state(cls, p_legs, p_state, dtype=np.float64, bc='finite'):
+        """Product state; ``p_state[i]`` is the flat physical index occupied on site i.  For ``bc='infinite'`` the unit
+        cell must be charge neutral (no charge shift between unit cells is implemented)."""
         chinfo = p_legs[0].chinfo
         L = len(p_legs)
         Bs = []
@@ -46,28 +51,53 @@ class MPS:
             dense[0, int(p_state[i]), 0] = 1.
             Bs.append(npc.Array.from_ndarray(dense, [vL, leg_p, vR], dtype=dtype, labels=['vL', 'p', 'vR']))
             q_left = q_right
-        return cls(p_legs, Bs, [np.ones(1)] * (L + 1), form='B')
+        if bc == 'infinite' and np.any(q_left != chinfo.make_valid()):
+            raise ValueError("infinite MPS: the unit cell of the product state must have total charge 0")
+        return cls(p_legs, Bs, [np.ones(1)] * (L + 1), form='B', bc=bc)
 
     @property
     def chi(self):
-        """Bond dimensions; a 2-D bond matrix (DMRG with mixer) counts with its smaller dimension (reference mps.py)."""
-        return [int(min(s.shape)) if isinstance(s, npc.Array) else len(s) for s in self._S[1:-1]]
+        """Bond dimensions (finite: the L-1 inner bonds; infinite: the bond right of every site); a 2-D bond matrix (DMRG
+        with mixer) counts with its smaller dimension (reference mps.py)."""
+        Ss = self._S[1:-1] if self.finite else self._S[1:]
+        return [int(min(s.shape)) if isinstance(s, npc.Array) else len(s) for s in Ss]
+
+    def _site(self, i):
+        if self.finite:
+            if not 0 <= i < self.L:
+                raise IndexError("site index %d out of range for a finite MPS of length %d" % (i, self.L))
+            return i
+        return i % self.L
+
+    def _bond(self, i):
+        """Index into ``_S`` of the bond LEFT of site i."""
+        if self.finite:
+            return i
+        return i % self.L
 
     def get_SL(self, i):
-        return self._S[i]
+        return self._S[self._bond(i)]
 
     def get_SR(self, i):
-        return self._S[i + 1]
+        return self._S[self._bond(i + 1)] if not self.finite else self._S[i + 1]
 
     def set_SL(self, i, S):
         """Schmidt values (1-D host array) or, during DMRG with a mixer, a general bond MATRIX (2-D device Array with
         labels 'vL', 'vR') left of site i  (reference ``MPS.set_SL``; 2-D case: mps.py:5970)."""
-        self._S[i] = S if isinstance(S, npc.Array) else np.asarray(S)
+        S = S if isinstance(S, npc.Array) else np.asarray(S)
+        b = self._bond(i)
+        self._S[b] = S
+        if not self.finite and b == 0:
+            self._S[self.L] = S
 
     def set_SR(self, i, S):
-        self._S[i + 1] = S if isinstance(S, npc.Array) else np.asarray(S)
+        if self.finite:
+            self._S[i + 1] = S if isinstance(S, npc.Array) else np.asarray(S)
+        else:
+            self.set_SL(i + 1, S)
 
     def set_B(self, i, B, form='B'):
+        i = self._site(i)
         self._B[i] = B.transpose(['vL', 'p', 'vR']) if B._labels != ['vL', 'p', 'vR'] else B
         self.form[i] = _FORMS[form] if not isinstance(form, tuple) else form
 
@@ -93,6 +123,7 @@ class MPS:
     def get_B(self, i, form='B', copy=False):
         """Site tensor converted to ``form``; ``form=None`` returns the stored tensor."""
         want = _FORMS[form] if not isinstance(form, tuple) else form
+        i = self._site(i)
         B = self._B[i]
         if want is not None and want != self.form[i]:
             have = self.form[i]
@@ -108,18 +139,19 @@ class MPS:
         if n == 1:
             return self.get_B(i, (formL, formR)).replace_label('p', 'p0')
         assert n == 2
+        i, i1 = self._site(i), self._site(i + 1)
         B0 = self._B[i]
         B0 = self._scale_axis_B(B0, self._S[i], formL - self.form[i][0], 'vL')
-        B0 = self._scale_axis_B(B0, self._S[i + 1], 1. - self.form[i][1] - self.form[i + 1][0], 'vR')
-        B1 = self._B[i + 1]
-        B1 = self._scale_axis_B(B1, self._S[i + 2], formR - self.form[i + 1][1], 'vR')
+        B0 = self._scale_axis_B(B0, self._S[i + 1], 1. - self.form[i][1] - self.form[i1][0], 'vR')
+        B1 = self._B[i1]
+        B1 = self._scale_axis_B(B1, self._S[i1 + 1], formR - self.form[i1][1], 'vR')
         B0 = B0.replace_label('p', 'p0')
         B1 = B1.replace_label('p', 'p1')
         return npc.tensordot(B0, B1, axes=['vR', 'vL'])
 
     def entanglement_entropy(self):
         res = []
-        for s in self._S[1:-1]:
+        for s in (self._S[1:-1] if self.finite else self._S[1:]):
             if isinstance(s, npc.Array):      # bond matrix: its singular values are the Schmidt values
                 _, s, _ = npc.svd(s, inner_labels=['vR', 'vL'])
                 s = s / np.linalg.norm(s)
