@@ -43,7 +43,8 @@ class TwoSiteDMRGEngine:
         self._meas_E_trunc = False
         self._in_iteration = False
         self.n_optimize = 2
-        self.N_sweeps_check = options.get('N_sweeps_check', 1)
+        self.finite = psi.finite
+        self.N_sweeps_check = options.get('N_sweeps_check', 1 if psi.finite else 10)
         self.time0 = time.time()
         self.log_matvec = options.get('log_matvec', False)
         self.matvec_log = []
@@ -56,6 +57,7 @@ class TwoSiteDMRGEngine:
         self.profile = options.get('profile', False)
         self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
         self.mixer = None            # activated by run() / mixer_activate() (reference: pre_run_initialize :829)
+        self._optimize = True
         if resume_data is not None:  # reference: Algorithm.__init__(..., resume_data=...) / get_resume_data (algorithm.py)
             self.sweeps = int(resume_data['sweeps'])
             for k, v in resume_data.get('sweep_stats', {}).items():
@@ -64,6 +66,10 @@ class TwoSiteDMRGEngine:
                 self.update_stats[k] = list(v)
             if resume_data.get('chi_max') is not None:
                 self.trunc_params['chi_max'] = resume_data['chi_max']
+        if not self.finite:          # iDMRG: initial sweeps of the environment without optimisation (reference :254-256)
+            if self.ortho_to_envs:
+                raise ValueError("Can't orthogonalize for infinite MPS: overlap not well defined.")
+            self.environment_sweeps(options.get('start_env', 1))
 
     # ---- checkpoint / resume (reference: Algorithm.get_resume_data, simulations/simulation.py:1189) ----
     def get_resume_data(self):
@@ -146,10 +152,20 @@ class TwoSiteDMRGEngine:
 
     def get_sweep_schedule(self):
         L = self.psi.L
+        if not self.finite:          # reference mps_common.py:444-450: the bonds of the unit cell, across its boundary too
+            i0s = list(range(0, L)) + list(range(L, 0, -1))
+            move_right = [True] * L + [False] * L
+            update_LP_RP = [[True, True]] * 2 + [[True, False]] * (L - 2) + [[True, True]] * 2 + [[False, True]] * (L - 2)
+            return list(zip(i0s, move_right, update_LP_RP))
         i0s = list(range(0, L - 2)) + list(range(L - 2, 0, -1))
         move_right = [True] * (L - 2) + [False] * (L - 2)
         update_LP_RP = [[True, False]] * (L - 2) + [[False, True]] * (L - 2)
         return list(zip(i0s, move_right, update_LP_RP))
+
+    def environment_sweeps(self, N_sweeps):
+        """Sweeps without optimisation, to converge the environments of an infinite MPS (reference :330)."""
+        for _ in range(max(int(N_sweeps), 0)):
+            self.sweep(optimize=False)
 
     def sweep(self, optimize=True, meas_E_trunc=False):
         """One sweep = 2(L-2) two-site updates.  Returns the maximal truncation error.  ``meas_E_trunc``: also evaluate
@@ -164,10 +180,16 @@ class TwoSiteDMRGEngine:
                 self.mixer_activate()                       # reference mps_common.py:376-382
         t0 = time.time()
         max_err, n_upd = 0., 0
-        for i0, move_right, (upd_LP, upd_RP) in self.get_sweep_schedule():
-            err = self.update_bond(i0, move_right, upd_LP, upd_RP)
-            max_err = max(max_err, err.eps)
-            n_upd += 1
+        self._optimize = bool(optimize)
+        try:
+            for i0, move_right, (upd_LP, upd_RP) in self.get_sweep_schedule():
+                err = self.update_bond(i0, move_right, upd_LP, upd_RP)
+                max_err = max(max_err, err.eps)
+                n_upd += 1
+        finally:
+            self._optimize = True
+        if not optimize:                # environment sweep: not counted, mixer untouched (reference :405-413)
+            return max_err
         self.sweeps += 1
         if self.mixer is not None and self.mixer.update_amplitude(self.sweeps) is None:
             self.mixer_deactivate()
@@ -196,8 +218,12 @@ class TwoSiteDMRGEngine:
         theta = psi.get_theta(i0, n=2)
         theta = eff_H.combine_theta(theta)
         op = self._wrap_ortho_eff_H(eff_H, i0, 2)
+        age = (self.env.get_LP_age(i0) or 0) + 2 + (self.env.get_RP_age(i0 + 1) or 0)
         tick('heff')
-        E0, theta, N = self.diag(eff_H, op, theta)
+        if self._optimize:
+            E0, theta, N = self.diag(eff_H, op, theta)
+        else:                                     # environment sweep: only re-decompose and update the environments
+            E0, N = None, 0
         theta = eff_H.prepare_svd(theta)          # fused matrix [(vL.p0), (p1.vR)] for the SVD / mixer
         tick('lanczos')
         i1 = i0 + 1
@@ -215,6 +241,9 @@ class TwoSiteDMRGEngine:
                                                                         qtotal_LR)
                 # (like the reference, the factor on the non-mixed side is stored as it comes: not an isometry)
         tick('svd')
+        if not self.finite:          # the parts next to the updated bond are recomputed or dropped (reference :580-593)
+            self.env.del_LP(i1)
+            self.env.del_RP(i0)
         if update_LP:
             eff_H.update_LP(self.env, i1, U)
         if update_RP:
@@ -226,21 +255,24 @@ class TwoSiteDMRGEngine:
         psi.set_B(i1, B, form='B')
         psi.set_SR(i0, S)
         tick('setB')
-        # environments that depended on the old tensors are stale now
-        for j in range(i1 + 1, psi.L):
-            if self.env._LP[j] is None:
-                break
-            self.env._LP[j] = None
-        if not update_LP and self.env._LP[i1] is not None:
-            self.env._LP[i1] = None
-        for j in range(i0 - 1, -1, -1):
-            if self.env._RP[j] is None:
-                break
-            self.env._RP[j] = None
-        if not update_RP and self.env._RP[i0] is not None:
-            self.env._RP[i0] = None
-        self._update_ortho_envs(i0, i1, update_LP, update_RP)
+        if self.finite:              # environments that depended on the old tensors are stale now
+            for j in range(i1 + 1, psi.L):
+                if self.env._LP[j] is None:
+                    break
+                self.env._LP[j] = None
+            if not update_LP and self.env._LP[i1] is not None:
+                self.env._LP[i1] = None
+            for j in range(i0 - 1, -1, -1):
+                if self.env._RP[j] is None:
+                    break
+                self.env._RP[j] = None
+            if not update_RP and self.env._RP[i0] is not None:
+                self.env._RP[i0] = None
+            self._update_ortho_envs(i0, i1, update_LP, update_RP)
+        if E0 is None:               # no optimisation: the energy after truncation (reference :587-592)
+            E0 = float(np.real(self.env.full_contraction(i0)))
         us = self.update_stats
+        us.setdefault('age', []).append(age)
         us['i0'].append(i0)
         us['E_total'].append(float(E0))
         us['N_lanczos'].append(N)
@@ -360,8 +392,15 @@ class TwoSiteDMRGEngine:
             self.lanczos_params['P_tol'] = max(p_tol_min, min(p_tol_max, max_trunc_err * p_tol_to_trunc))
         if e_tol_to_trunc is not None and max_E_trunc > e_tol_min:
             self.lanczos_params['E_tol'] = max(e_tol_min, min(e_tol_max, max_E_trunc * e_tol_to_trunc))
-        entropy_bonds = self._entropy_approx[1:]
-        E = self.update_stats['E_total'][-1]
+        if not self.finite:          # iDMRG: update the environments, energy per site from the growth of the system
+            self.environment_sweeps(opt.get('update_env', self.N_sweeps_check // 2))
+            entropy_bonds = list(self._entropy_approx)
+            Es, ages = self.update_stats['E_total'], self.update_stats['age']
+            delta = min(1 + 2 * self.env.L, len(ages))
+            E = (Es[-1] - Es[-delta]) / (ages[-1] - ages[-delta])
+        else:
+            entropy_bonds = self._entropy_approx[1:]
+            E = self.update_stats['E_total'][-1]
         S = float(np.mean(entropy_bonds))
         st['sweep'].append(self.sweeps)
         st['N_updates'].append(len(self.update_stats['i0']))
@@ -374,7 +413,7 @@ class TwoSiteDMRGEngine:
         st['max_trunc_err'].append(max_trunc_err)
         st['max_E_trunc'].append(max_E_trunc)
         st['max_chi'].append(int(np.max(self.psi.chi)))
-        st['norm_err'].append(abs(abs(self.psi.norm_test()) - 1.) if not any(isinstance(x, npc.Array) for x in self.psi._S) else np.nan)
+        st['norm_err'].append(abs(abs(self.psi.norm_test()) - 1.) if self.finite and not any(isinstance(x, npc.Array) for x in self.psi._S) else np.nan)
         return E, self.psi
 
     def is_converged(self):

@@ -260,9 +260,7 @@ class MPOEnvironment:
 
     def full_contraction(self, i0):
         """<psi|H|psi> evaluated at bond (i0, i0+1)."""
-        LP = self.get_LP(i0 + 1, store=False) if i0 + 1 < self.L else None
-        if LP is None:
-            raise ValueError
+        LP = self.get_LP(i0 + 1, store=False)
         S = self.psi.get_SR(i0)
         RP = self.get_RP(i0, store=False)
         if isinstance(S, npc.Array):     # general bond matrix of a sweep with mixer (reference mps.py:6715-6724)

@@ -775,7 +775,47 @@ def gen_tdvp():
     save('tdvp.pkl', out)
 
 
-GENERATORS = dict(tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_idmrg():
+    """Infinite DMRG (two-site, Lanczos always): XXZ chain with a 2-site unit cell and TFI with parity, through the
+    reference's run() loop (N_sweeps_check, environment sweeps, energy per site from the growth of the system)."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    import copy
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for case in ('xxz', 'tfi'):
+            if case == 'xxz':
+                L = 2
+                M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.5, 'hz': 0., 'bc_MPS': 'infinite', 'sort_charge': True})
+                psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
+                extra = dict(L=L, Jxx=1., Jz=1.5, hz=0., conserve='Sz')
+            else:
+                L = 2
+                M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'infinite', 'conserve': 'parity', 'sort_charge': True})
+                psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'up'], bc='infinite')
+                extra = dict(L=L, J=1., g=1.5, conserve='parity')
+            opts = {'mixer': None, 'combine': True, 'max_N_for_ED': 0, 'max_E_err': 1.e-10, 'max_sweeps': 40, 'N_sweeps_check': 5,
+                    'trunc_params': {'chi_max': 16, 'svd_min': 1.e-10}}
+            opts_plain = copy.deepcopy(opts)
+            eng = dmrg.TwoSiteDMRGEngine(psi, M, opts)
+            E, _ = eng.run()
+            st = eng.sweep_stats
+            rec = dict(case=case, E=float(E), sweeps=int(eng.sweeps), options=opts_plain,
+                       E_updates=[float(e) for e in eng.update_stats['E_total']], age=[int(a) for a in eng.update_stats['age']],
+                       i0=[int(i) for i in eng.update_stats['i0']],
+                       sweep_stats={k: [float(x) for x in st[k]] for k in ('sweep', 'N_updates', 'E', 'Delta_E', 'S', 'Delta_S', 'max_S',
+                                                                              'max_trunc_err', 'max_E_trunc', 'max_chi')},
+                       S=[np.array(psi.get_SL(i)) for i in range(L)], chi=[int(c) for c in psi.chi])
+            rec.update(extra)
+            out.append(rec)
+            print('idmrg', case, E, eng.sweeps, psi.chi)
+    save('idmrg.pkl', out)
+
+
+GENERATORS = dict(idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

@@ -1,0 +1,47 @@
+"""Infinite DMRG (two-site unit cell, environments growing across the unit-cell boundary, energy per site from the
+ages of the environment parts) vs the reference's run (tests/golden/make_golden.py:gen_idmrg).  The TFI value is the
+golden number of the reference's own test (tests/test_dmrg.py:121: -1.67192622)."""
+import numpy as np
+
+from helpers import golden
+from tenpy_amd.algorithms.dmrg import TwoSiteDMRGEngine
+from tenpy_amd.models.spin_chains import spin_half_leg, tfi_chain_mpo, xxz_chain_mpo
+from tenpy_amd.networks.mps import MPS
+
+
+def test_idmrg(backend):
+    for rec in golden('idmrg.pkl'):
+        L = rec['L']
+        if rec['case'] == 'xxz':
+            H = xxz_chain_mpo(L, rec['Jxx'], rec['Jz'], rec['hz'], bc='infinite')
+            _, p = spin_half_leg('Sz')
+            psi = MPS.from_product_state([p] * L, [1, 0], bc='infinite')
+        else:
+            H = tfi_chain_mpo(L, rec['J'], rec['g'], conserve='parity', bc='infinite')
+            _, p = spin_half_leg('parity')
+            psi = MPS.from_product_state([p] * L, [1, 1], bc='infinite')
+        opts = {k: v for k, v in rec['options'].items() if k not in ('combine', 'max_N_for_ED')}
+        eng = TwoSiteDMRGEngine(psi, H, opts)
+        E, _ = eng.run()
+        assert eng.sweeps == rec['sweeps']
+        assert abs(E - rec['E']) < 1e-10
+        if rec['case'] == 'tfi':
+            assert abs(E - (-1.67192622)) < 1e-6
+        assert eng.update_stats['i0'] == rec['i0']
+        assert eng.update_stats['age'] == rec['age']
+        # E_total is the energy of the whole grown system.  The reference starts from the dominant eigenvectors of the MPO
+        # transfer matrix of the initial state (MPOTransferMatrix.find_init_LP_RP), i.e. its first environment already
+        # contains the coupling to the (mean-field) neighbours; this package starts from the bare boundary vectors.  The
+        # frozen boundary contributes a CONSTANT to every E_total; energies per site, ages and the state are unaffected.
+        d = np.array(eng.update_stats['E_total']) - np.array(rec['E_updates'])
+        assert np.max(np.abs(d - d[0])) < 1e-9
+        for k, tol in (('sweep', 0), ('N_updates', 0), ('E', 1e-10), ('Delta_E', 1e-10), ('S', 1e-8), ('Delta_S', 1e-8), ('max_S', 1e-8),
+                       ('max_trunc_err', 1e-11), ('max_E_trunc', 1e-9), ('max_chi', 0)):
+            a, b = np.array(eng.sweep_stats[k], dtype=float), np.array(rec['sweep_stats'][k], dtype=float)
+            assert a.shape == b.shape, k
+            assert np.all(np.isnan(b) | (np.abs(a - b) <= tol * np.maximum(1., np.abs(b)))), (k, a, b)
+        assert list(psi.chi) == rec['chi']
+        for i in range(L):
+            # (the reference finishes run() with psi.canonical_form() when the norm error exceeds norm_tol_final = 1e-10;
+            #  that transfer-matrix based re-gauging of the infinite MPS is not part of this package: 1e-4 here)
+            np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i])[::-1], rtol=0, atol=1e-4)
