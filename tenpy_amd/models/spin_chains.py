@@ -72,3 +72,51 @@ def tfi_chain_mpo(L, J=1., g=1., conserve=None, bc='finite'):
     H = mpo_from_dense(Ws, [p] * L, chinfo)
     H.IdL, H.IdR = 0, -1
     return H
+
+
+def spin_S_leg(S, conserve='Sz'):
+    """Physical leg of a spin-S site, states ordered m = -S ... S (charge 2 m for ``conserve='Sz'``)."""
+    d = int(round(2 * S + 1))
+    if conserve == 'Sz':
+        chinfo = ChargeInfo([1], ['2*Sz'])
+        leg = LegCharge.from_qflat(chinfo, [[int(round(2 * (-S + k)))] for k in range(d)])
+    elif conserve == 'parity':
+        chinfo = ChargeInfo([2], ['parity_Sz'])
+        leg = LegCharge.from_qflat(chinfo, [[k % 2] for k in range(d)])
+    else:
+        chinfo = ChargeInfo()
+        leg = LegCharge.from_trivial(d, chinfo)
+    return chinfo, leg
+
+
+def spin_chain_mpo(L, S=0.5, Jx=1., Jy=1., Jz=1., D=0., hz=0., conserve='Sz', bc='finite'):
+    """Spin-S chain ``sum_i Jx SxSx + Jy SySy + Jz SzSz + D (Sz)^2 - hz Sz`` -- the model of the reference's iDMRG
+    benchmark (``tests/benchmark/dmrg_infinite.py:22``: ``SpinChain(S=2, D=0.3, bc_MPS='infinite')``, models/spins.py).
+    ``conserve='Sz'`` needs Jx = Jy."""
+    chinfo, p = spin_S_leg(S, conserve)
+    d = p.ind_len
+    m = -S + np.arange(d)
+    Sz = np.diag(m)
+    Sp = np.zeros((d, d))
+    for k in range(d - 1):
+        Sp[k + 1, k] = np.sqrt(S * (S + 1) - m[k] * (m[k] + 1))
+    Sm = Sp.T.copy()
+    Id = np.eye(d)
+    if conserve == 'Sz' and Jx != Jy:
+        raise ValueError("Sz conservation needs Jx == Jy")
+    Jpm, Jpp = 0.25 * (Jx + Jy), 0.25 * (Jx - Jy)          # Jx SxSx + Jy SySy = Jpm (S+S- + S-S+) + Jpp (S+S+ + S-S-)
+    Dm = 5
+    W = np.zeros((Dm, Dm, d, d))
+    W[0, 0] = Id
+    W[0, 1] = Sp
+    W[0, 2] = Sm
+    W[0, 3] = Sz
+    W[0, 4] = D * (Sz @ Sz) - hz * Sz
+    W[1, 4] = Jpm * Sm + Jpp * Sp
+    W[2, 4] = Jpm * Sp + Jpp * Sm
+    W[3, 4] = Jz * Sz
+    W[4, 4] = Id
+    if bc == 'infinite':
+        return mpo_from_dense([W] * L, [p] * L, chinfo, IdL=0, IdR=-1, bc='infinite')
+    Ws = [W[0:1] if i == 0 else (W[:, 4:5] if i == L - 1 else W) for i in range(L)]
+    return mpo_from_dense(Ws, [p] * L, chinfo, IdL=0, IdR=-1)

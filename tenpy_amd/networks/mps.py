@@ -57,9 +57,9 @@ class MPS:
 
     @property
     def chi(self):
-        """Bond dimensions (finite: the L-1 inner bonds; infinite: the bond right of every site); a 2-D bond matrix (DMRG
+        """Bond dimensions (finite: the L-1 inner bonds; infinite: the bond left of every site); a 2-D bond matrix (DMRG
         with mixer) counts with its smaller dimension (reference mps.py)."""
-        Ss = self._S[1:-1] if self.finite else self._S[1:]
+        Ss = self._S[1:-1] if self.finite else self._S[:self.L]      # (reference: MPS.nontrivial_bonds)
         return [int(min(s.shape)) if isinstance(s, npc.Array) else len(s) for s in Ss]
 
     def _site(self, i):
@@ -151,7 +151,7 @@ class MPS:
 
     def entanglement_entropy(self):
         res = []
-        for s in (self._S[1:-1] if self.finite else self._S[1:]):
+        for s in (self._S[1:-1] if self.finite else self._S[:self.L]):      # infinite: the bond LEFT of every site
             if isinstance(s, npc.Array):      # bond matrix: its singular values are the Schmidt values
                 _, s, _ = npc.svd(s, inner_labels=['vR', 'vL'])
                 s = s / np.linalg.norm(s)

@@ -815,7 +815,33 @@ def gen_idmrg():
     save('idmrg.pkl', out)
 
 
-GENERATORS = dict(idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_idmrg_bench():
+    """The reference's iDMRG benchmark (tests/benchmark/dmrg_infinite.py) in small: spin-2 chain with D=0.3, Sz conserved,
+    Lanczos N_min=N_max=10, optimisation sweeps alternating with environment sweeps."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.spins import SpinChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L, chi = 4, 14
+        M = SpinChain(dict(L=L, S=2., D=0.3, bc_MPS='infinite', conserve='Sz', sort_charge=True))
+        psi = MPS.from_product_state(M.lat.mps_sites(), (['up', 'down'] * L)[:L], bc='infinite')
+        eng = dmrg.TwoSiteDMRGEngine(psi, M, {'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 10, 'N_max': 10},
+                                              'max_N_for_ED': 0, 'combine': True})
+        eng.diag_method = 'lanczos'
+        for i in range(6):
+            eng.sweep(meas_E_trunc=False)
+            eng.sweep(optimize=False, meas_E_trunc=False)
+        Es, ages = eng.update_stats['E_total'], eng.update_stats['age']
+        out.append(dict(L=L, chi=chi, S=2., D=0.3, E_updates=[float(e) for e in Es], age=[int(a) for a in ages],
+                        i0=[int(i) for i in eng.update_stats['i0']], chi_final=[int(c) for c in psi.chi],
+                        S_ent=np.array(psi.entanglement_entropy()), state_labels=list(M.lat.mps_sites()[0].state_labels.items())))
+        print('idmrg_bench', psi.chi, (Es[-1] - Es[-9]) / (ages[-1] - ages[-9]))
+    save('idmrg_bench.pkl', out)
+
+
+GENERATORS = dict(idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

@@ -45,3 +45,30 @@ def test_idmrg(backend):
             # (the reference finishes run() with psi.canonical_form() when the norm error exceeds norm_tol_final = 1e-10;
             #  that transfer-matrix based re-gauging of the infinite MPS is not part of this package: 1e-4 here)
             np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i])[::-1], rtol=0, atol=1e-4)
+
+
+def test_idmrg_benchmark_model(backend):
+    """The reference's iDMRG benchmark in small (tests/benchmark/dmrg_infinite.py: spin-2 chain, D = 0.3, Sz conserved,
+    Lanczos N_min = N_max = 10, optimisation sweeps alternating with environment sweeps)."""
+    from tenpy_amd.models.spin_chains import spin_S_leg, spin_chain_mpo
+    rec = golden('idmrg_bench.pkl')[0]
+    L = rec['L']
+    H = spin_chain_mpo(L, S=rec['S'], D=rec['D'], bc='infinite')
+    _, p = spin_S_leg(rec['S'])
+    labels = dict(rec['state_labels'])
+    d = p.ind_len
+    # this package orders the states m = -S ... S; 'up' = m = +S, 'down' = m = -S
+    idx = {'up': d - 1, 'down': 0}
+    psi = MPS.from_product_state([p] * L, [idx[s] for s in (['up', 'down'] * L)[:L]], bc='infinite')
+    eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 10, 'N_max': 10}})
+    n0 = len(eng.update_stats['E_total'])        # (the engine starts with one environment sweep, like the reference)
+    for i in range(6):
+        eng.sweep()
+        eng.sweep(optimize=False)
+    assert eng.update_stats['i0'] == rec['i0']
+    assert eng.update_stats['age'] == rec['age']
+    d_E = np.array(eng.update_stats['E_total']) - np.array(rec['E_updates'])
+    assert np.max(np.abs(d_E - d_E[0])) < 1e-8            # constant boundary offset, see test_idmrg
+    assert list(psi.chi) == rec['chi_final']
+    np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-7)
+    assert labels['up'] in (0, d - 1) and n0 > 0
