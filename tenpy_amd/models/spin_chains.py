@@ -120,3 +120,32 @@ def spin_chain_mpo(L, S=0.5, Jx=1., Jy=1., Jz=1., D=0., hz=0., conserve='Sz', bc
         return mpo_from_dense([W] * L, [p] * L, chinfo, IdL=0, IdR=-1, bc='infinite')
     Ws = [W[0:1] if i == 0 else (W[:, 4:5] if i == L - 1 else W) for i in range(L)]
     return mpo_from_dense(Ws, [p] * L, chinfo, IdL=0, IdR=-1)
+
+
+def spin_chain_h_bonds(L, S=0.5, Jx=1., Jy=1., Jz=1., D=0., hz=0., bc='finite'):
+    """Two-site terms ``h[i]`` coupling sites (i-1, i) of :func:`spin_chain_mpo` as dense (d, d, d, d) arrays
+    [p0, p1, p0*, p1*] for TEBD; ``h[0]`` is ``None`` for a finite chain.  On-site terms are shared half / half between
+    the two bonds of a site, a boundary site of a finite chain gives all of it to its only bond (reference
+    ``NearestNeighborModel.calc_H_bond``, models/model.py)."""
+    d = int(round(2 * S + 1))
+    m = -S + np.arange(d)
+    Sz = np.diag(m)
+    Sp = np.zeros((d, d))
+    for k in range(d - 1):
+        Sp[k + 1, k] = np.sqrt(S * (S + 1) - m[k] * (m[k] + 1))
+    Sm = Sp.T.copy()
+    Id = np.eye(d)
+    Sx, Sy = 0.5 * (Sp + Sm), -0.5j * (Sp - Sm)
+    onsite = D * (Sz @ Sz) - hz * Sz
+    two = Jx * np.kron(Sx, Sx) + np.real(Jy * np.kron(Sy, Sy)) + Jz * np.kron(Sz, Sz)
+    res = []
+    for i in range(L):
+        if i == 0 and bc == 'finite':
+            res.append(None)
+            continue
+        j = (i - 1) % L
+        wl = 1. if (bc == 'finite' and j == 0) else 0.5
+        wr = 1. if (bc == 'finite' and i == L - 1) else 0.5
+        h = two + wl * np.kron(onsite, Id) + wr * np.kron(Id, onsite)
+        res.append(np.real_if_close(h).reshape(d, d, d, d))
+    return res

@@ -841,7 +841,31 @@ def gen_idmrg_bench():
     save('idmrg_bench.pkl', out)
 
 
-GENERATORS = dict(idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_tebd_infinite():
+    """The reference's TEBD benchmark (tests/benchmark/tebd_infinite.py) in small: infinite spin-2 chain, order 2."""
+    from tenpy.algorithms import tebd
+    from tenpy.models.spins import SpinChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L, chi = 2, 12
+        M = SpinChain(dict(L=L, S=2., D=0.3, bc_MPS='infinite', conserve='Sz', sort_charge=True))
+        psi = MPS.from_product_state(M.lat.mps_sites(), (['up', 'down'] * L)[:L], bc='infinite')
+        eng = tebd.TEBDEngine(psi, M, {'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}, 'order': 2, 'N_steps': 2, 'dt': 0.05})
+        S_t, chi_t = [], []
+        for rep in range(5):
+            eng.run()
+            S_t.append(np.array(psi.entanglement_entropy()))
+            chi_t.append([int(c) for c in psi.chi])
+        out.append(dict(L=L, chi=chi, S_t=np.array(S_t), chi_t=chi_t, trunc_err=float(eng.trunc_err.eps), t=float(eng.evolved_time),
+                        h_bond=[h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond],
+                        S0=np.array(psi.get_SL(0)), S1=np.array(psi.get_SL(1))))
+        print('tebd_infinite', chi_t[-1], S_t[-1])
+    save('tebd_infinite.pkl', out)
+
+
+GENERATORS = dict(tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

@@ -72,3 +72,22 @@ def test_tebd_orders_and_imaginary_time(backend):
             assert abs(err.eps - rec['err_t'][rep]) < 1e-11
         assert abs(complex(eng.evolved_time) - rec['evolved_time']) < 1e-14
         np.testing.assert_allclose(np.sort(psi.get_SL(L // 2))[::-1], np.sort(rec['S_mid'])[::-1], rtol=0, atol=1e-10)
+
+
+def test_tebd_infinite_benchmark_model(backend):
+    """Infinite TEBD of the spin-2 chain (the reference's benchmark tests/benchmark/tebd_infinite.py in small):
+    the bond across the unit-cell boundary is updated like any other."""
+    from tenpy_amd.models.spin_chains import spin_S_leg
+    rec = golden('tebd_infinite.pkl')[0]
+    L = rec['L']
+    _, p = spin_S_leg(2.)
+    d = p.ind_len
+    psi = MPS.from_product_state([p] * L, ([d - 1, 0] * L)[:L], dtype=np.complex128, bc='infinite')
+    eng = TEBDEngine(psi, rec['h_bond'], {'dt': 0.05, 'order': 2, 'N_steps': 2, 'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}})
+    for rep in range(len(rec['chi_t'])):
+        eng.run_evolution()
+        assert list(psi.chi) == rec['chi_t'][rep]
+        np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_t'][rep], rtol=0, atol=1e-10)
+    assert abs(eng.evolved_time - rec['t']) < 1e-14
+    np.testing.assert_allclose(np.sort(psi.get_SL(0))[::-1], np.sort(rec['S0'])[::-1], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.sort(psi.get_SL(1))[::-1], np.sort(rec['S1'])[::-1], rtol=0, atol=1e-10)
