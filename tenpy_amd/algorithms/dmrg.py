@@ -1,12 +1,14 @@
-"""Two-site finite DMRG sweep driver -- the measurement harness around the hot path.
+"""DMRG engines -- the callers around the hot path, mirroring ``tenpy/algorithms/dmrg.py``.
 
-Follows the call sequence of the reference: ``Sweep.sweep`` (mps_common.py:345) ->
-``prepare_update_local`` (:498) -> ``update_local`` (dmrg.py:529: ``diag`` :672 = Lanczos,
-``mixed_svd`` :876 = ``svd_theta``, ``set_B`` :934) -> ``update_env`` (:569).  Options keep the
-reference's names (``trunc_params``, ``lanczos_params``, ``chi_list``, ``max_sweeps``, ``min_sweeps``,
-``max_E_err``, ``N_sweeps_check``, ``combine``, ``mixer``, ``mixer_params``, ``chi_list_reactivates_mixer``).  Only what a
-finite two-site sweep needs is here (optionally with the density-matrix mixer); the rest of ``algorithms/dmrg.py``
-(infinite MPS, one-site engine, subspace expansion) is out of scope.
+Call sequence of the reference: ``Sweep.sweep`` (mps_common.py:345) -> ``prepare_update_local`` (:498) ->
+``update_local`` (dmrg.py:529: ``diag`` :672 = Lanczos or exact diagonalisation, ``mixed_svd`` :876 / :996, ``set_B``) ->
+``update_env`` (:569); main loop ``run`` / ``run_iteration`` / ``is_converged`` / ``stopping_criterion``.  Options keep the
+reference's names (``trunc_params``, ``lanczos_params``, ``chi_list``, ``max_sweeps``, ``min_sweeps``, ``max_E_err``,
+``max_S_err``, ``N_sweeps_check``, ``P_tol_to_trunc``, ``E_tol_to_trunc``, ``diag_method``, ``max_N_for_ED``, ``mixer``,
+``mixer_params``, ``chi_list_reactivates_mixer``, ``start_env``, ``update_env``, ``orthogonal_to``).  ``TwoSiteDMRGEngine``: finite and
+infinite MPS, density-matrix mixer or subspace expansion, checkpoint / resume, multi-GPU sharding of the matvec and the SVD.
+``SingleSiteDMRGEngine``: finite MPS, subspace expansion.  Not here: ``explicit_plus_hc`` MPOs, segment boundary conditions,
+``canonical_form`` of infinite MPS at the end of ``run``.
 """
 import time
 
