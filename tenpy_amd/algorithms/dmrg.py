@@ -217,7 +217,7 @@ class TwoSiteDMRGEngine:
             eff_H = ShardedTwoSiteH(self.env, i0, combine=True, move_right=move_right)
         else:
             eff_H = TwoSiteH(self.env, i0, combine=True, move_right=move_right)
-        theta = psi.get_theta(i0, n=2)
+        theta = psi.get_theta(i0, n=2, cutoff=self.S_inv_cutoff)
         theta = eff_H.combine_theta(theta)
         op = self._wrap_ortho_eff_H(eff_H, i0, 2)
         age = (self.env.get_LP_age(i0) or 0) + 2 + (self.env.get_RP_age(i0 + 1) or 0)
@@ -287,6 +287,12 @@ class TwoSiteDMRGEngine:
         if self.log_matvec:
             self.matvec_log.append((i0, N, eff_H.flops_per_matvec, eff_H.bytes_per_matvec, theta.shape))
         return err
+
+    @property
+    def S_inv_cutoff(self):
+        """Cutoff of the (pseudo-)inverse of bond matrices: 1e-8 while a mixer left 2-D matrices in the MPS (reference
+        mps_common.py:161)."""
+        return 1.e-8 if any(isinstance(S, npc.Array) for S in self.psi._S) else 1.e-15
 
     def diag(self, eff_H, op, theta_guess):
         """Lowest eigenpair of the effective Hamiltonian (reference ``DMRGEngine.diag``, dmrg.py:672).  ``diag_method``:
@@ -522,7 +528,7 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
         tick = self._tick
         tick(None)
         eff_H = OneSiteH(self.env, i0, combine=True, move_right=move_right)
-        theta = eff_H.combine_theta(psi.get_theta(i0, n=1))
+        theta = eff_H.combine_theta(psi.get_theta(i0, n=1, cutoff=self.S_inv_cutoff))
         op = self._wrap_ortho_eff_H(eff_H, i0, 1)
         tick('heff')
         E0, theta, N = self.diag(eff_H, op, theta)

@@ -102,13 +102,15 @@ class MPS:
         self.form[i] = _FORMS[form] if not isinstance(form, tuple) else form
 
     @staticmethod
-    def _scale_axis_B(B, S, power, axis):
-        """``B.scale_axis(S**power)``; a 2-D bond matrix is contracted instead (reference mps.py:5964-6002; the
-        pseudo-inverse needed for power -1 is never requested inside a sweep and is not provided)."""
+    def _scale_axis_B(B, S, power, axis, cutoff=1.e-16):
+        """``B.scale_axis(S**power)``; a 2-D bond matrix (DMRG with a mixer) is contracted instead, its Moore-Penrose
+        pseudo-inverse (``npc.pinv`` with ``cutoff``) for power -1  (reference mps.py:5964-6002)."""
         if power == 0.:
             return B
         if isinstance(S, npc.Array):
-            if power != 1.:
+            if power == -1.:
+                S = npc.pinv(S, cutoff).iset_leg_labels(['vL', 'vR'])
+            elif power != 1.:
                 raise ValueError("Can't scale/tensordot a 2D `S` with power %r" % (power,))
             labels = B.get_leg_labels()
             if axis == 'vL':
@@ -120,31 +122,31 @@ class MPS:
             return B.scale_axis(S, axis)
         return B.scale_axis(S**power, axis)
 
-    def get_B(self, i, form='B', copy=False):
+    def get_B(self, i, form='B', copy=False, cutoff=1.e-16):
         """Site tensor converted to ``form``; ``form=None`` returns the stored tensor."""
         want = _FORMS[form] if not isinstance(form, tuple) else form
         i = self._site(i)
         B = self._B[i]
         if want is not None and want != self.form[i]:
             have = self.form[i]
-            B = self._scale_axis_B(B, self._S[i], want[0] - have[0], 'vL')
-            B = self._scale_axis_B(B, self._S[i + 1], want[1] - have[1], 'vR')
+            B = self._scale_axis_B(B, self._S[i], want[0] - have[0], 'vL', cutoff)
+            B = self._scale_axis_B(B, self._S[i + 1], want[1] - have[1], 'vR', cutoff)
         elif copy:
             B = B.copy(deep=True)
         return B
 
-    def get_theta(self, i, n=2, formL=1., formR=1.):
+    def get_theta(self, i, n=2, formL=1., formR=1., cutoff=1.e-16):
         """Two-site wave function with labels ``'vL', 'p0', 'p1', 'vR'``, or the one-site one ``'vL', 'p0', 'vR'``
         (reference mps.py:3041; n=1: ``get_B(i, (1., 1.))`` :3075)."""
         if n == 1:
-            return self.get_B(i, (formL, formR)).replace_label('p', 'p0')
+            return self.get_B(i, (formL, formR), cutoff=cutoff).replace_label('p', 'p0')
         assert n == 2
         i, i1 = self._site(i), self._site(i + 1)
         B0 = self._B[i]
-        B0 = self._scale_axis_B(B0, self._S[i], formL - self.form[i][0], 'vL')
-        B0 = self._scale_axis_B(B0, self._S[i + 1], 1. - self.form[i][1] - self.form[i1][0], 'vR')
+        B0 = self._scale_axis_B(B0, self._S[i], formL - self.form[i][0], 'vL', cutoff)
+        B0 = self._scale_axis_B(B0, self._S[i + 1], 1. - self.form[i][1] - self.form[i1][0], 'vR', cutoff)
         B1 = self._B[i1]
-        B1 = self._scale_axis_B(B1, self._S[i1 + 1], formR - self.form[i1][1], 'vR')
+        B1 = self._scale_axis_B(B1, self._S[i1 + 1], formR - self.form[i1][1], 'vR', cutoff)
         B0 = B0.replace_label('p', 'p0')
         B1 = B1.replace_label('p', 'p1')
         return npc.tensordot(B0, B1, axes=['vR', 'vL'])

@@ -786,8 +786,8 @@ def gen_idmrg():
     out = []
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        for case in ('xxz', 'tfi'):
-            if case == 'xxz':
+        for case in ('xxz', 'tfi', 'xxz_mixer'):
+            if case.startswith('xxz'):
                 L = 2
                 M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.5, 'hz': 0., 'bc_MPS': 'infinite', 'sort_charge': True})
                 psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
@@ -799,6 +799,9 @@ def gen_idmrg():
                 extra = dict(L=L, J=1., g=1.5, conserve='parity')
             opts = {'mixer': None, 'combine': True, 'max_N_for_ED': 0, 'max_E_err': 1.e-10, 'max_sweeps': 40, 'N_sweeps_check': 5,
                     'trunc_params': {'chi_max': 16, 'svd_min': 1.e-10}}
+            if case == 'xxz_mixer':
+                opts.update(mixer=True, mixer_params={'amplitude': 1.e-4, 'decay': 1.5, 'disable_after': 6})
+                opts['trunc_params']['svd_min'] = 1.e-6
             opts_plain = copy.deepcopy(opts)
             eng = dmrg.TwoSiteDMRGEngine(psi, M, opts)
             E, _ = eng.run()
