@@ -151,6 +151,54 @@ class MPS:
         B1 = B1.replace_label('p', 'p1')
         return npc.tensordot(B0, B1, axes=['vR', 'vL'])
 
+    def canonical_form(self, renormalize=True, cutoff=0.):
+        """Bring a finite MPS into canonical (B) form with correct Schmidt values (reference ``canonical_form_finite``,
+        mps.py:4505-4603): a left-to-right sweep of block QR decompositions, then a right-to-left sweep of block SVDs.
+        With ``renormalize=False`` the norm of the state is multiplied into ``self.norm``."""
+        if not self.finite:
+            raise NotImplementedError("tenpy_amd: canonical_form of infinite MPS (transfer-matrix method) is not implemented")
+        L = self.L
+        self.set_SL(0, np.array([1.]))
+        self.set_SR(L - 1, np.array([1.]))
+
+        def normalise(M):
+            nrm = float(npc.norm(M))
+            if not renormalize:
+                self.norm = self.norm * nrm
+            M.iscale_prefactor(1. / nrm)
+            return M
+        if any(f is None for f in self.form):
+            M, form = self.get_B(0, None), None           # no canonical form before: ignore the stored S
+        else:
+            M, form = self.get_B(0, 'Th'), 'B'
+        M = normalise(M.copy(deep=True))
+        Q, R = npc.qr(M.combine_legs(['vL', 'p']), inner_labels=['vR', 'vL'])
+        self.set_B(0, Q.split_legs(0), form='A')
+        for i in range(1, L):
+            M = npc.tensordot(R, self.get_B(i, form), axes=['vR', 'vL'])
+            M = normalise(M)
+            if i == L - 1:
+                break
+            Q, R = npc.qr(M.combine_legs(['vL', 'p']), inner_labels=['vR', 'vL'])
+            self.set_B(i, Q.split_legs(0), form='A')
+        kw = dict(inner_labels=['vR', 'vL'])
+        if cutoff:
+            kw['cutoff'] = cutoff
+        U, S, V = npc.svd(M.combine_legs(['p', 'vR'], qconj=-1), **kw)
+        if not renormalize:
+            self.norm = self.norm * float(np.linalg.norm(S))
+        S = S / np.linalg.norm(S)
+        self.set_SL(L - 1, S)
+        self.set_B(L - 1, V.split_legs(1), form='B')
+        for i in range(L - 2, -1, -1):
+            M = npc.tensordot(self.get_B(i, 'A'), U.scale_axis(S, 'vR'), axes=['vR', 'vL'])
+            U, S, V = npc.svd(M.combine_legs(['p', 'vR'], qconj=-1), qtotal_LR=[None, M.qtotal], **kw)
+            S = S / np.linalg.norm(S)
+            self.set_SL(i, S)
+            self.set_B(i, V.split_legs(1), form='B')
+        assert len(S) == 1
+        self._B[0] = self._B[0] * U.to_ndarray()[0, 0]       # a trivial phase factor, but better keep it
+
     def entanglement_entropy(self):
         res = []
         for s in (self._S[1:-1] if self.finite else self._S[:self.L]):      # infinite: the bond LEFT of every site

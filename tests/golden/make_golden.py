@@ -868,7 +868,43 @@ def gen_tebd_infinite():
     save('tebd_infinite.pkl', out)
 
 
-GENERATORS = dict(tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_canonical_form():
+    """MPS.canonical_form of a finite MPS made of random (non-canonical) tensors and of a slightly perturbed canonical one."""
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    r4 = np.random.RandomState(99)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 6
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+        for cplx in (False, True):
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite', dtype=np.complex128 if cplx else np.float64)
+            from tenpy.algorithms import tebd
+            eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.1, 'N_steps': 4, 'trunc_params': {'chi_max': 8, 'svd_min': 1.e-10}})
+            eng.run()
+            # perturb every tensor: the form labels stay 'B' but the state is no longer canonical
+            Bs_in = []
+            for i in range(L):
+                B = psi.get_B(i, 'B')
+                noise = npc.Array.from_func(lambda size: 0.05 * (r4.standard_normal(size) + (1.j * r4.standard_normal(size) if cplx else 0.)),
+                                            B.legs, dtype=B.dtype, qtotal=B.qtotal, shape_kw='size')
+                noise.iset_leg_labels(B.get_leg_labels())
+                Bn = B + noise
+                psi.set_B(i, Bn, form='B')
+                Bs_in.append(dump_array(Bn.transpose(['vL', 'p', 'vR'])))
+            S_in = [np.array(psi.get_SL(i)) for i in range(L)] + [np.array(psi.get_SR(L - 1))]
+            for renorm in (True, False):
+                p2 = psi.copy()
+                p2.canonical_form(renormalize=renorm)
+                out.append(dict(L=L, cplx=cplx, renormalize=renorm, B_in=Bs_in, S_in=S_in, norm=float(p2.norm),
+                                S_out=[np.array(p2.get_SL(i)) for i in range(L)] + [np.array(p2.get_SR(L - 1))], S_ent=np.array(p2.entanglement_entropy()),
+                                overlap=complex(p2.overlap(psi)), chi=[int(c) for c in p2.chi]))
+            print('canonical_form', cplx, out[-1]['norm'], out[-1]['chi'])
+    save('canonical_form.pkl', out)
+
+
+GENERATORS = dict(canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

@@ -1,0 +1,26 @@
+"""``MPS.canonical_form`` (QR sweep + SVD sweep) of finite MPS whose tensors were perturbed out of canonical form, vs the
+reference (tests/golden/make_golden.py:gen_canonical_form): Schmidt spectra, entropies, norm bookkeeping, isometry."""
+import numpy as np
+
+from helpers import golden, load_array
+from tenpy_amd.linalg import np_conserved as npc
+from tenpy_amd.networks.mps import MPS
+
+
+def test_canonical_form(backend):
+    for rec in golden('canonical_form.pkl'):
+        L = rec['L']
+        Bs = [load_array(b) for b in rec['B_in']]
+        psi = MPS([B.get_leg('p') for B in Bs], Bs, rec['S_in'], form='B')
+        psi.canonical_form(renormalize=rec['renormalize'])
+        assert list(psi.chi) == rec['chi']
+        assert abs(psi.norm - rec['norm']) < 1e-10 * max(1., rec['norm'])
+        for i in range(L + 1):
+            S = psi.get_SL(i) if i < L else psi.get_SR(L - 1)
+            np.testing.assert_allclose(np.sort(S)[::-1], np.sort(rec['S_out'][i])[::-1], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-10)
+        for i in range(L):                       # right-canonical: B B^dagger = 1
+            B = psi.get_B(i, 'B')
+            G = npc.tensordot(B, B.conj(), axes=(['p', 'vR'], ['p*', 'vR*'])).to_ndarray()
+            np.testing.assert_allclose(G, np.eye(G.shape[0]), rtol=0, atol=1e-12)
+        assert abs(psi.norm_test() - 1.) < 1e-10
