@@ -199,6 +199,38 @@ class MPS:
         assert len(S) == 1
         self._B[0] = self._B[0] * U.to_ndarray()[0, 0]       # a trivial phase factor, but better keep it
 
+    def expectation_value(self, op, sites=None):
+        """``<psi| op_i |psi>`` for every site in ``sites`` (default: all): ``op`` is a dense (d, d) host matrix [p, p*] (must
+        conserve the charges) or a device Array with labels 'p', 'p*' (reference ``MPS.expectation_value`` for one-site
+        operators, mps.py).  One tensordot and one inner product per site on the device."""
+        sites = range(self.L) if sites is None else sites
+        res = []
+        for i in sites:
+            th = self.get_B(i, 'Th')
+            if isinstance(op, npc.Array):
+                O = op
+            else:
+                leg = th.get_leg('p')
+                O = npc.Array.from_ndarray(np.asarray(op), [leg, leg.conj()], labels=['p', 'p*'])
+            C = npc.tensordot(O, th, axes=['p*', 'p'])
+            res.append(npc.inner(th, C, axes='labels', do_conj=True))
+        res = np.array(res)
+        return np.real_if_close(res)
+
+    def overlap(self, other):
+        """``<self|other>`` including the norms of both states (reference ``MPS.overlap`` for finite MPS)."""
+        if not (self.finite and other.finite):
+            raise NotImplementedError("tenpy_amd: overlap of infinite MPS (transfer-matrix eigenvalue) is not implemented")
+        ov = MPSEnvironment(self, other).full_contraction(max(self.L // 2 - 1, 0))
+        return ov * self.norm * other.norm
+
+    def copy(self):
+        """Copy sharing the (immutable) tensors: the engines replace tensors, they never modify them in place."""
+        res = MPS(self.p_legs, list(self._B), list(self._S), form='B', bc=self.bc)
+        res.form = list(self.form)
+        res.norm = self.norm
+        return res
+
     def entanglement_entropy(self):
         res = []
         for s in (self._S[1:-1] if self.finite else self._S[:self.L]):      # infinite: the bond LEFT of every site

@@ -34,6 +34,7 @@ def test_excited_state_dmrg(backend):
         e1.mixer_cleanup()
         ov = MPSEnvironment(psi0, psi1).full_contraction(L // 2 - 1)
         assert abs(ov) < 1e-9
+        assert abs(psi0.overlap(psi1)) < 1e-9 and abs(psi1.overlap(psi1) - 1.) < 1e-10
         assert abs(MPSEnvironment(psi1, psi1).full_contraction(L // 2 - 1) - 1.) < 1e-10
         assert e1.sweep_stats['E'][-1] > e0.sweep_stats['E'][-1] + 0.1
 

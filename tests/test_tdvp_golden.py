@@ -37,6 +37,7 @@ def test_tdvp_quench(backend):
         assert list(psi.chi) == step['chi']
         np.testing.assert_allclose(psi.entanglement_entropy(), step['S'], rtol=0, atol=1e-10)
         np.testing.assert_allclose(_sz(psi), step['Sz'], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(psi.expectation_value(np.diag([-0.5, 0.5])), step['Sz'], rtol=0, atol=1e-10)
         assert abs(psi.norm - step['norm']) < 1e-10
         assert abs(eng.evolved_time - step['t']) < 1e-14
         assert abs(eng.trunc_err.eps - step['trunc_err']) < 1e-11
