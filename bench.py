@@ -105,10 +105,14 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    backend = os.environ.get('TPA_BENCH_BACKEND', 'nccl')     # 'gloo': CPU dry run of the N>1 control flow (tests/test_bench_contract.py)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -160,7 +164,7 @@ def main():
     npc.gemm_timer.enabled = False
     gemm_ms = npc.gemm_timer.collect()
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     s_per_sweep = elapsed / max(args.steps, 1)

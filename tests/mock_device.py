@@ -329,6 +329,30 @@ def install(monkeypatch):
         def empty(n, dtype=None, device=None):
             return REG.add(torch.empty(int(n), dtype=dtype))
 
+        class cuda:
+            """Just enough of torch.cuda for the event timer and the phase timers (host clock)."""
+            class Event:
+                def __init__(self, enable_timing=True):
+                    self.t = None
+
+                def record(self):
+                    import time
+                    self.t = time.perf_counter()
+
+                def synchronize(self):
+                    pass
+
+                def elapsed_time(self, other):
+                    return 1e3 * (other.t - self.t)
+
+            @staticmethod
+            def synchronize(*a, **k):
+                pass
+
+            @staticmethod
+            def current_device():
+                return 0
+
     monkeypatch.setattr(dev, "empty", empty)
     monkeypatch.setattr(dev, "zeros", zeros)
     monkeypatch.setattr(dev, "to_device", to_device)
