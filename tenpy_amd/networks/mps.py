@@ -1,10 +1,11 @@
-"""Minimal finite MPS holding device-resident site tensors -- the *caller side* of the hot path.
+"""MPS holding device-resident site tensors -- the *caller side* of the hot path.
 
-This is NOT a re-implementation of ``tenpy/networks/mps.py`` (7.6k lines, out of scope); it
-holds exactly what a two-site sweep touches (reference ``MPS.get_theta`` :3041, ``get_B`` / ``set_B`` /
-``set_SR``, ``from_product_state``) with the same leg labels ``('vL', 'p', 'vR')`` and the same
-canonical-form convention ``B = S**nuL  Gamma  S**nuR`` ('A' = (1,0), 'B' = (0,1), 'Th' = (1,1)), so that the
-bench/parity harness exercises the npc calls of a real sweep in the reference's order.
+Not a re-implementation of ``tenpy/networks/mps.py`` (7.6k lines): it holds what the DMRG / TEBD / TDVP engines
+of this package touch -- ``from_product_state``, ``get_B`` / ``set_B`` / ``get_theta`` / ``set_SL`` / ``set_SR`` with the reference's leg
+labels ``('vL', 'p', 'vR')`` and canonical-form convention ``B = S**nuL  Gamma  S**nuR`` ('A' = (1,0), 'B' = (0,1), 'Th' = (1,1)),
+finite and infinite boundary conditions (indices modulo the unit cell), 2-D bond matrices of a mixer sweep (incl. their
+pseudo-inverse), ``canonical_form`` (finite), ``expectation_value``, ``overlap``, ``entanglement_entropy`` -- and
+``MPSEnvironment`` for overlaps with other states.
 """
 import numpy as np
 
