@@ -227,13 +227,39 @@ class ShardedTwoSiteH(TwoSiteH):
         res.iset_leg_labels(['vL', 'p0', 'p1', 'vR'])
         return res
 
+    def _gather_jobs(self, s):
+        """Pack / unpack tables of the all-gather as batched-copy jobs (built once per plan, kept on the device): packing
+        this rank's segments and scattering the other ranks' segments are ONE `tpa_copy_batch` launch each instead of
+        one small copy per (block, rank)."""
+        if 'pack_dev' not in s:
+            segs, maxlen = s['segs'], s['maxlen']
+            mine = segs[self.rank]
+            n_mine = np.array([n for _, n in mine], dtype=np.int64)
+            at = np.concatenate([[0], np.cumsum(n_mine)[:-1]]) if len(mine) else np.zeros(0, np.int64)
+            pack = npc._copy_jobs_contiguous(at, np.array([o for o, _ in mine], dtype=np.int64), n_mine)
+            dst, src, nn = [], [], []
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                a = r * maxlen
+                for off, n in segs[r]:
+                    dst.append(off)
+                    src.append(a)
+                    nn.append(n)
+                    a += n
+            unpack = npc._copy_jobs_contiguous(np.array(dst, dtype=np.int64), np.array(src, dtype=np.int64), np.array(nn, dtype=np.int64))
+            s['pack_dev'] = (dev.to_device(pack) if len(pack) else None, len(pack), int(n_mine.max()) if len(mine) else 0)
+            s['unpack_dev'] = (dev.to_device(unpack) if len(unpack) else None, len(unpack), int(max(nn)) if nn else 0)
+        return s['pack_dev'], s['unpack_dev']
+
     def _gather_rows(self, s, out_arena):
         """The one collective of a matvec: all-gather of the row panels (padded to the largest share)."""
+        (pk, n_pk, mx_pk), (up, n_up, mx_up) = self._gather_jobs(s)
+        L = dev.lib()
+        code = dev.code(s['p2'].dtype)
         send = dev.empty(s['maxlen'], s['p2'].dtype)
-        at = 0
-        for off, n in s['segs'][self.rank]:
-            send[at:at + n].copy_(out_arena[off:off + n])
-            at += n
+        if n_pk:
+            dev.check(L.tpa_copy_batch(code, pk.data_ptr(), n_pk, mx_pk, out_arena.data_ptr(), send.data_ptr(), dev.stream()), "pack")
         recv = dev.empty(s['maxlen'] * self.world, s['p2'].dtype)
         if np.dtype(s['p2'].dtype).kind == 'c':       # RCCL has no complex type: ship interleaved (re, im) doubles
             import torch
@@ -241,13 +267,8 @@ class ShardedTwoSiteH(TwoSiteH):
             _dist().all_gather_into_tensor(recv.view(f64), send.view(f64), group=self.group)
         else:
             _dist().all_gather_into_tensor(recv, send, group=self.group)
-        for r in range(self.world):
-            if r == self.rank:
-                continue
-            at = r * s['maxlen']
-            for off, n in s['segs'][r]:
-                out_arena[off:off + n].copy_(recv[at:at + n])
-                at += n
+        if n_up:
+            dev.check(L.tpa_copy_batch(code, up.data_ptr(), n_up, mx_up, recv.data_ptr(), out_arena.data_ptr(), dev.stream()), "unpack")
 
     def matvec(self, theta):
         if self.world == 1:
