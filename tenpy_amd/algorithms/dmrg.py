@@ -458,7 +458,30 @@ class TwoSiteDMRGEngine:
         while not self.stopping_criterion():
             result = self.run_iteration()
         self.mixer_cleanup()
+        self._canonicalize()
         return result
+
+    def _canonicalize(self):
+        """Reference ``DMRGEngine._canonicalize`` (dmrg.py:455): for an infinite MPS converge the environments (at most
+        ``norm_tol_iter`` x ``update_env`` environment sweeps) until the norm error is below ``norm_tol`` (1e-5); if it is
+        still above ``norm_tol_final`` (1e-10) bring the state into canonical form."""
+        if self.mixer is not None:
+            return
+        opt = self.options
+        norm_tol, norm_tol_final = opt.get('norm_tol', 1.e-5), opt.get('norm_tol_final', 1.e-10)
+        norm_err = float(np.linalg.norm(self.psi.norm_error()))
+        if norm_tol is None or (norm_err < norm_tol and norm_err < norm_tol_final):
+            return
+        if norm_err > norm_tol and not self.finite:
+            update_env = opt.get('update_env', self.N_sweeps_check // 2)
+            for _ in range(opt.get('norm_tol_iter', 5)):
+                self.environment_sweeps(update_env)
+                norm_err = float(np.linalg.norm(self.psi.norm_error()))
+                if norm_err <= norm_tol:
+                    break
+        if norm_err > norm_tol_final:
+            self.psi.canonical_form()
+            self.env._heff_cache.clear()
 
 
 class SingleSiteDMRGEngine(TwoSiteDMRGEngine):

@@ -19,7 +19,7 @@ from . import np_conserved as npc
 
 logger = logging.getLogger(__name__)
 
-__all__ = ['LanczosGroundState', 'LanczosEvolution', 'lanczos', 'gram_schmidt', 'iscale_prefactor', 'iadd_prefactor_other']
+__all__ = ['LanczosGroundState', 'LanczosEvolution', 'Arnoldi', 'lanczos', 'gram_schmidt', 'iscale_prefactor', 'iadd_prefactor_other']
 
 
 class LanczosGroundState:
@@ -213,6 +213,87 @@ class LanczosEvolution(LanczosGroundState):
 
     def _converged(self, k):
         return np.abs(self._result_krylov[k]) < self.P_tol
+
+
+class Arnoldi:
+    """Arnoldi iteration for the dominant eigenvector(s) of a general (non-Hermitian) operator given through
+    ``H.matvec`` -- e.g. the transfer matrix of an infinite MPS (reference ``krylov_based.Arnoldi`` :322).
+
+    Options: ``N_min`` (2), ``N_max`` (20), ``P_tol`` (1e-14), ``E_tol`` (inf), ``min_gap`` (1e-12), ``cutoff``, ``which`` ('LM':
+    largest magnitude, 'LR' / 'SR': largest / smallest real part), ``num_ev`` (1).  The Krylov basis stays on the device
+    (full Gram-Schmidt: k inner products + k axpy in step k); the Hessenberg matrix is diagonalised on the host."""
+
+    def __init__(self, H, psi0, options):
+        self.H = H
+        self.psi0 = psi0.copy(deep=True)
+        opt = dict(options) if options is not None else {}
+        self.N_min = int(opt.get('N_min', 2))
+        self.N_max = int(opt.get('N_max', 20))
+        self.P_tol = opt.get('P_tol', 1.e-14)
+        self.E_tol = opt.get('E_tol', np.inf)
+        self.min_gap = opt.get('min_gap', 1.e-12)
+        self.which = opt.get('which', 'LM')
+        self.num_ev = int(opt.get('num_ev', 1))
+        self._cutoff = opt.get('cutoff', np.finfo(np.float64).eps * 100)
+        self._basis = []
+        self._hess = np.zeros((self.N_max + 1, self.N_max), dtype=np.complex128)
+        self.Es = np.zeros((self.N_max, self.N_max), dtype=np.complex128)
+        self._ritz = None
+
+    def _order(self, ev):
+        key = {'LM': -np.abs(ev), 'LR': -np.real(ev), 'SR': np.real(ev), 'SM': np.abs(ev)}[self.which]
+        return np.argsort(key, kind='stable')
+
+    def run(self):
+        """Returns ``(eigenvalues[num_ev], eigenvectors[<= num_ev], N)``."""
+        hs = self._hess
+        w = self.psi0
+        nrm = npc.norm(w)
+        N = 0
+        for k in range(self.N_max):
+            w.iscale_prefactor(1. / nrm)
+            self._basis.append(w)
+            w = self.H.matvec(w)
+            for i, v in enumerate(self._basis):
+                ov = npc.inner(v, w, axes='range', do_conj=True)
+                hs[i, k] = ov
+                w.iadd_prefactor_other(-ov, v)
+            hs[k + 1, k] = nrm = npc.norm(w)
+            N = k + 1
+            if k == 0:
+                self.Es[0, 0] = hs[0, 0]
+                self._ritz = np.ones((1, 1), dtype=np.complex128)
+            else:
+                ev, vec = np.linalg.eig(hs[:k + 1, :k + 1])
+                order = self._order(ev)
+                self.Es[k, :k + 1] = ev[order]
+                self._ritz = vec[:, order]
+            if nrm < self._cutoff or (N >= self.N_min and self._converged(k)):
+                break
+        E = self.Es[N - 1, :self.num_ev].copy()
+        if N == 1:
+            return np.real_if_close(E), [self.psi0.copy(deep=True)], N
+        out = []
+        for j in range(min(N, self.num_ev)):
+            c = np.real_if_close(self._ritz[:, j])
+            psi = self._basis[0] * c[0]
+            for k in range(1, N):
+                psi.iadd_prefactor_other(c[k], self._basis[k])
+            psi.iscale_prefactor(1. / npc.norm(psi))
+            out.append(psi)
+        return np.real_if_close(E), out, N
+
+    def _converged(self, k):
+        if k == 0:
+            return False
+        v0 = self._ritz[:, 0]
+        E = self.Es[k, :k + 1]
+        ritz_res = abs(v0[k]) * abs(self._hess[k + 1, k])
+        gaps = [np.min(np.abs(E[i + 1:] - E[i])) for i in range(min(self.num_ev, k))]
+        gap = max(min(gaps) if gaps else self.min_gap, self.min_gap)
+        p_err = (ritz_res / gap)**2
+        delta_E = abs(self.Es[k - 1, 0] - E[0])
+        return p_err < self.P_tol and delta_E < self.E_tol
 
 
 def gram_schmidt(vecs, rcond=1.e-14):

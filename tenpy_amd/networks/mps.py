@@ -12,7 +12,7 @@ import numpy as np
 from ..linalg import np_conserved as npc
 from ..linalg.charges import LegCharge
 
-__all__ = ['MPS', 'MPSEnvironment']
+__all__ = ['MPS', 'MPSEnvironment', 'TransferMatrix']
 
 _FORMS = {'A': (1., 0.), 'B': (0., 1.), 'C': (0.5, 0.5), 'G': (0., 0.), 'Th': (1., 1.), None: None}
 
@@ -157,7 +157,7 @@ class MPS:
         mps.py:4505-4603): a left-to-right sweep of block QR decompositions, then a right-to-left sweep of block SVDs.
         With ``renormalize=False`` the norm of the state is multiplied into ``self.norm``."""
         if not self.finite:
-            raise NotImplementedError("tenpy_amd: canonical_form of infinite MPS (transfer-matrix method) is not implemented")
+            return self._canonical_form_infinite(renormalize=renormalize, cutoff=cutoff if cutoff else 1.e-15)
         L = self.L
         self.set_SL(0, np.array([1.]))
         self.set_SR(L - 1, np.array([1.]))
@@ -199,6 +199,92 @@ class MPS:
             self.set_B(i, V.split_legs(1), form='B')
         assert len(S) == 1
         self._B[0] = self._B[0] * U.to_ndarray()[0, 0]       # a trivial phase factor, but better keep it
+
+    # ---- infinite MPS: Algorithms 1, 2 of Vanderstraeten, Haegeman, Verstraete 2019 (reference canonical_form_infinite2, :4721) ----
+    def _canonical_form_infinite(self, renormalize=True, tol=1.e-15, arnoldi_params=None, cutoff=1.e-15):
+        from ..linalg.krylov_based import Arnoldi
+        assert cutoff <= tol or True
+        L = self.L
+        ap = dict(arnoldi_params or {})
+        if any(f is None for f in self.form):
+            self.form = [_FORMS['B']] * L
+            self._S[0] = self._S[L] = np.ones(self._B[0].get_leg('vL').ind_len)
+        else:
+            for i in range(L):
+                self._B[i] = self.get_B(i, 'B')
+            self.form = [_FORMS['B']] * L
+
+        def qr_R2L(R):         # B[0] ... B[L-1] R  ->  R Q[0] ... Q[L-1]
+            Qs = [None] * L
+            for i in reversed(range(L)):
+                BR = npc.tensordot(self._B[i], R, axes=['vR', 'vL']).combine_legs(['p', 'vR'], new_axes=0, qconj=-1)
+                Q, R = npc.qr(BR, inner_labels=['vL', 'vR'], pos_diag_R=True, qtotal_Q=BR.qtotal, inner_qconj=-1)
+                Qs[i] = Q.split_legs()
+            return Qs, R
+
+        def qr_L2R(Lm):        # L B[0] ... B[L-1]  ->  Q[0] ... Q[L-1] L
+            Qs = [None] * L
+            for i in range(L):
+                LB = npc.tensordot(Lm, self._B[i], axes=['vR', 'vL']).combine_legs(['vL', 'p'], new_axes=0, qconj=+1)
+                Q, Lm = npc.qr(LB, inner_labels=['vR', 'vL'], pos_diag_R=True, qtotal_Q=LB.qtotal, inner_qconj=+1)
+                Qs[i] = Q.split_legs()
+            return Qs, Lm
+
+        def fixed_point(M, sweep, right):
+            for _ in range(10000):
+                M = M / npc.norm(M)
+                old = M
+                new_Bs, M = sweep(M)
+                nrm = npc.norm(M)
+                M = M / nrm
+                M = M.transpose(old.get_leg_labels())
+                err = npc.norm(M - old)
+                if err <= tol:
+                    return new_Bs, M, nrm
+                ap['E_tol'] = err / 10.
+                TM = TransferMatrix(new_Bs, self._B, transpose=not right)
+                vec = M.replace_label('vR', 'vL*') if right else M.replace_label('vL', 'vR*')
+                _, vecs, _ = Arnoldi(TM, vec, ap).run()
+                M = vecs[0].replace_label('vL*', 'vR') if right else vecs[0].replace_label('vR*', 'vL')
+                if right:
+                    _, M = npc.qr(M.transpose(['vR', 'vL']), inner_labels=['vL', 'vR'], pos_diag_R=True, inner_qconj=-1)
+                else:
+                    _, M = npc.qr(M.transpose(['vL', 'vR']), inner_labels=['vR', 'vL'], pos_diag_R=True, inner_qconj=+1)
+            raise RuntimeError("canonical_form did not converge up to tol=%g (last error %g)" % (tol, err))
+        R_guess = npc.diag(1., self._B[0].get_leg('vL'), labels=['vL', 'vR'])
+        new_Bs, _, nrm = fixed_point(R_guess, qr_R2L, True)
+        if not renormalize:
+            self.norm *= nrm
+        self._B = new_Bs
+        C_guess = npc.diag(self.get_SL(0), self._B[0].get_leg('vL'), labels=['vL', 'vR'])
+        new_As, C, _ = fixed_point(C_guess, qr_L2R, False)
+        C = C.transpose(['vL', 'vR'])
+        U, S, V = npc.svd(C, cutoff=cutoff, inner_labels=['vR', 'vL'])
+        new_As[0] = npc.tensordot(U.conj().ireplace_label('vR*', 'vL'), new_As[0], axes=['vL*', 'vL'])
+        for i in reversed(range(L)):
+            th = npc.tensordot(new_As[i], U.scale_axis(S, 'vR'), axes=['vR', 'vL'])
+            th = th.combine_legs(['p', 'vR'], new_axes=1)
+            U, S, V = npc.svd(th, cutoff=cutoff, inner_labels=['vR', 'vL'])
+            self._B[i] = V.split_legs().transpose(['vL', 'p', 'vR'])
+            self.set_SL(i, S)
+        self._B[L - 1] = npc.tensordot(self._B[L - 1], U, axes=['vR', 'vL'])
+
+    def norm_error(self):
+        """What the reference calls ``MPS.norm_test()`` (mps.py:4432): for every site the deviations
+        ``| theta theta^dagger - S_L^2 |`` and ``| theta^dagger theta - S_R^2 |`` of the reduced density matrices from the
+        stored Schmidt values, shape (L, 2); zero in canonical form."""
+        err = np.empty((self.L, 2))
+        for i in range(self.L):
+            th = self.get_B(i, 'Th')
+            for k, (ax, ax_c, lab, S) in enumerate(((['p', 'vR'], ['p*', 'vR*'], 'vL', self.get_SL(i)),
+                                                    (['vL', 'p'], ['vL*', 'p*'], 'vR', self.get_SR(i)))):
+                rho = npc.tensordot(th, th.conj(), axes=[ax, ax_c])
+                if isinstance(S, npc.Array):
+                    rho2 = npc.tensordot(S, S.conj(), axes=(['vR', 'vR*'] if k == 0 else ['vL', 'vL*']))
+                else:
+                    rho2 = npc.diag(S**2, rho.legs[0], dtype=rho.dtype)
+                err[i, k] = npc.norm(rho - rho2.iset_leg_labels(rho.get_leg_labels()))
+        return err
 
     def expectation_value(self, op, sites=None):
         """``<psi| op_i |psi>`` for every site in ``sites`` (default: all): ``op`` is a dense (d, d) host matrix [p, p*] (must
@@ -325,3 +411,26 @@ class MPSEnvironment:
         S_bra, S_ket = self.bra.get_SR(i0), self.ket.get_SR(i0)
         LP = LP.scale_axis(S_ket, 'vR').scale_axis(np.conj(S_bra), 'vR*')
         return npc.inner(LP, RP, axes=(['vR*', 'vR'], ['vL*', 'vL']), do_conj=False)
+
+
+class TransferMatrix:
+    """Transfer matrix of the unit cell of two infinite MPS given by their tensor lists ``bra_N`` (conjugated inside) and
+    ``ket_M`` (reference mps.py:6914).  ``transpose=False``: acts to the left on a right vector with labels 'vL', 'vL*';
+    ``transpose=True``: acts to the right on a left vector with labels 'vR*', 'vR'.  A linear operator for ``Arnoldi``."""
+
+    def __init__(self, bra_N, ket_M, transpose=False):
+        self.transpose = transpose
+        Ns = [N.conj() for N in bra_N]
+        self._bra_N, self._ket_M = (list(reversed(Ns)), list(reversed(ket_M))) if not transpose else (Ns, list(ket_M))
+
+    def matvec(self, vec):
+        labels = vec.get_leg_labels()
+        if not self.transpose:
+            for N, M in zip(self._bra_N, self._ket_M):
+                vec = npc.tensordot(M, vec, axes=['vR', 'vL'])
+                vec = npc.tensordot(vec, N, axes=[['p', 'vL*'], ['p*', 'vR*']])
+        else:
+            for N, M in zip(self._bra_N, self._ket_M):
+                vec = npc.tensordot(vec, M, axes=['vR', 'vL'])
+                vec = npc.tensordot(N, vec, axes=[['vL*', 'p*'], ['vR*', 'p']])
+        return vec if list(vec.get_leg_labels()) == labels else vec.transpose(labels)

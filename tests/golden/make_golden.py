@@ -904,7 +904,46 @@ def gen_canonical_form():
     save('canonical_form.pkl', out)
 
 
-GENERATORS = dict(canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_canonical_form_infinite():
+    """canonical_form of an infinite MPS that is slightly out of canonical form (after real-time iTEBD with truncation
+    and an extra perturbation of the tensors)."""
+    from tenpy.algorithms import tebd
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    r5 = np.random.RandomState(123)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 2
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.5, 'hz': 0., 'bc_MPS': 'infinite', 'sort_charge': True})
+        for cplx in (False, True):
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
+            eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.1, 'N_steps': 6, 'trunc_params': {'chi_max': 8, 'svd_min': 1.e-10}})
+            if cplx:
+                eng.run()
+            else:
+                eng.calc_U(2, 0.1, type_evo='imag')
+                eng.evolve(6, 0.1)
+            Bs_in = []
+            for i in range(L):
+                B = psi.get_B(i, 'B')
+                noise = npc.Array.from_func(lambda size: 0.03 * (r5.standard_normal(size) + (1.j * r5.standard_normal(size) if cplx else 0.)),
+                                            B.legs, dtype=B.dtype, qtotal=B.qtotal, shape_kw='size')
+                noise.iset_leg_labels(B.get_leg_labels())
+                Bn = B + noise
+                psi.set_B(i, Bn, form='B')
+                Bs_in.append(dump_array(Bn.transpose(['vL', 'p', 'vR'])))
+            S_in = [np.array(psi.get_SL(i)) for i in range(L)]
+            err_in = np.array(psi.norm_test())
+            psi.canonical_form()
+            out.append(dict(L=L, cplx=cplx, B_in=Bs_in, S_in=S_in, err_in=err_in, err_out=np.array(psi.norm_test()),
+                            S_out=[np.array(psi.get_SL(i)) for i in range(L)], S_ent=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
+                            Sz=np.array(psi.expectation_value('Sz'))))
+            print('canonical_form_infinite', cplx, np.linalg.norm(err_in), np.linalg.norm(out[-1]['err_out']), out[-1]['chi'], out[-1]['S_ent'])
+    save('canonical_form_infinite.pkl', out)
+
+
+GENERATORS = dict(canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

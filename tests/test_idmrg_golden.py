@@ -42,9 +42,8 @@ def test_idmrg(backend):
             assert np.all(np.isnan(b) | (np.abs(a - b) <= tol * np.maximum(1., np.abs(b)))), (k, a, b)
         assert list(psi.chi) == rec['chi']
         for i in range(L):
-            # (the reference finishes run() with psi.canonical_form() when the norm error exceeds norm_tol_final = 1e-10;
-            #  that transfer-matrix based re-gauging of the infinite MPS is not part of this package: 1e-4 here)
-            np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i])[::-1], rtol=0, atol=1e-4)
+            # (run() ends like the reference's: environment sweeps / psi.canonical_form() until the norm error is < 1e-10)
+            np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i])[::-1], rtol=0, atol=1e-8)
 
 
 def test_idmrg_benchmark_model(backend):

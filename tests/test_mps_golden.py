@@ -24,3 +24,21 @@ def test_canonical_form(backend):
             G = npc.tensordot(B, B.conj(), axes=(['p', 'vR'], ['p*', 'vR*'])).to_ndarray()
             np.testing.assert_allclose(G, np.eye(G.shape[0]), rtol=0, atol=1e-12)
         assert abs(psi.norm_test() - 1.) < 1e-10
+
+
+def test_canonical_form_infinite(backend):
+    """Infinite MPS out of canonical form (iTEBD with truncation + noise on the tensors) -> ``canonical_form`` (fixed points of
+    the QR sweeps accelerated by Arnoldi on the transfer matrix, then an SVD sweep) vs the reference: Schmidt spectra,
+    entropies, <Sz>, and the norm error (the reference's ``norm_test``) before / after."""
+    for rec in golden('canonical_form_infinite.pkl'):
+        L = rec['L']
+        Bs = [load_array(b) for b in rec['B_in']]
+        psi = MPS([B.get_leg('p') for B in Bs], Bs, list(rec['S_in']) + [rec['S_in'][0]], form='B', bc='infinite')
+        np.testing.assert_allclose(psi.norm_error(), rec['err_in'], rtol=0, atol=1e-10)
+        psi.canonical_form()
+        assert np.linalg.norm(psi.norm_error()) < 1e-12
+        assert list(psi.chi) == rec['chi']
+        for i in range(L):
+            np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S_out'][i])[::-1], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(psi.expectation_value(np.diag([-0.5, 0.5])), rec['Sz'], rtol=0, atol=1e-10)
