@@ -1268,6 +1268,44 @@ class Array:
         res._skey = None
         return res
 
+    def add_leg(self, leg, i, axis=0, label=None):
+        """Insert ``leg`` at ``axis`` with the data of ``self`` at its flat index ``i`` and zeros elsewhere -- the inverse of
+        ``take_slice`` (reference :1123).  Bookkeeping only when the charge sector of ``i`` has one entry (MPO legs); a wider
+        sector gets its blocks embedded by one strided copy launch."""
+        if axis < 0:
+            axis += self.rank
+        if label is not None and label in self._labels:
+            raise ValueError("label already exists")
+        qi, pos = leg.get_qindex(int(i) % leg.ind_len if -leg.ind_len <= i < leg.ind_len else int(i))
+        width = int(leg.get_block_sizes()[qi])
+        legs = list(self.legs)
+        legs.insert(axis, leg)
+        labels = list(self._labels)
+        labels.insert(axis, label)
+        res = Array(legs, self.dtype, self.chinfo.make_valid(self.qtotal + leg.get_charge(qi)), labels)
+        qdata = np.ascontiguousarray(np.insert(self._qdata, axis, qi, axis=1)).astype(np.intp)
+        if self.stored_blocks == 0:
+            return res
+        if width == 1:
+            src = self.copy(deep=True)
+            src._repack()
+            res._set_blocks(qdata, arena=src._arena, qdata_sorted=False)
+            return res
+        res._set_blocks(qdata, zero=True, qdata_sorted=False)
+        shapes = self._block_shapes()
+        outer = np.prod(shapes[:, :axis], axis=1)
+        inner = np.prod(shapes[:, axis:], axis=1)
+        # block [outer, width, inner] <- self block [outer, inner] at position pos of the new axis: `outer` contiguous runs
+        dst_off, src_off, sizes = [], [], []
+        for b in range(self.stored_blocks):
+            o = np.arange(outer[b], dtype=np.int64)
+            dst_off.append(res._offsets[b] + (o * width + pos) * inner[b])
+            src_off.append(self._offsets[b] + o * inner[b])
+            sizes.append(np.full(outer[b], inner[b], dtype=np.int64))
+        dst_off, src_off, sizes = np.concatenate(dst_off), np.concatenate(src_off), np.concatenate(sizes)
+        _run_copy(self.dtype, _copy_jobs_contiguous(dst_off, src_off, sizes), int(np.max(sizes)), self._arena, res._arena)
+        return res
+
     def squeeze(self, axes=None):
         """Remove length-1 legs (only the trivial case with zero charge on the removed leg's single block is
         handled without charge compensation, like the reference does via qtotal adjustment)."""
