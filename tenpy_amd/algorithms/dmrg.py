@@ -7,8 +7,7 @@ reference's names (``trunc_params``, ``lanczos_params``, ``chi_list``, ``max_swe
 ``max_S_err``, ``N_sweeps_check``, ``P_tol_to_trunc``, ``E_tol_to_trunc``, ``diag_method``, ``max_N_for_ED``, ``mixer``,
 ``mixer_params``, ``chi_list_reactivates_mixer``, ``start_env``, ``update_env``, ``orthogonal_to``).  ``TwoSiteDMRGEngine``: finite and
 infinite MPS, density-matrix mixer or subspace expansion, checkpoint / resume, multi-GPU sharding of the matvec and the SVD.
-``SingleSiteDMRGEngine``: finite MPS, subspace expansion.  Not here: ``explicit_plus_hc`` MPOs, segment boundary conditions,
-``canonical_form`` of infinite MPS at the end of ``run``.
+``SingleSiteDMRGEngine``: finite MPS, subspace expansion.  Not here: ``explicit_plus_hc`` MPOs, segment boundary conditions.
 """
 import time
 
