@@ -141,6 +141,78 @@ class TEBDEngine:
             trunc_err = trunc_err + self.update_bond(i_bond, Us[i_bond])
         return trunc_err
 
+    # ---- imaginary time evolution towards the ground state (reference :113-180, :485-583) -------------------------------
+    def update_bond_imag(self, i, U_bond):
+        """Bond update that keeps the A - S - B form (no old Schmidt values are used), for sweeping left and right with
+        non-unitary gates (reference :545)."""
+        i0, i1 = i - 1, i
+        psi = self.psi
+        theta = psi.get_theta(i0, n=2)
+        theta = npc.tensordot(U_bond, theta, axes=(['p0*', 'p1*'], ['p0', 'p1']))
+        theta.itranspose(['vL', 'p0', 'p1', 'vR'])
+        theta = theta.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])
+        U, S, V, err, renorm = svd_theta(theta, self.trunc_params, inner_labels=['vR', 'vL'])
+        self.norm *= renorm
+        psi.set_SR(i0, S)
+        psi.set_B(i0, U.split_legs(0).ireplace_label('p0', 'p'), form='A')
+        psi.set_B(i1, V.split_legs(1).ireplace_label('p1', 'p'), form='B')
+        self.trunc_err = self.trunc_err + err
+        return err
+
+    def update_imag(self, N_steps, call_canonical_form=True):
+        """``N_steps`` second-order imaginary time steps of a finite chain as sweeps right and left with the half-step gates
+        (reference :485)."""
+        if self._U_param['order'] != 2 or not self.psi.finite:
+            raise NotImplementedError("Use DMRG instead...")
+        Us = self._U_list[0]            # gates for dt / 2
+        trunc_err = TruncationError()
+        for _ in range(N_steps):
+            for i_bond in list(range(self.psi.L)) + list(range(self.psi.L - 1, -1, -1)):
+                if Us[i_bond] is not None:
+                    trunc_err = trunc_err + self.update_bond_imag(i_bond, Us[i_bond])
+        self.evolved_time = self.evolved_time + N_steps * self._U_param['tau']
+        if call_canonical_form:
+            self.psi.canonical_form()
+        return trunc_err
+
+    def bond_energies(self):
+        """``<h_bond>`` of every bond term; entry i is the bond (i, i+1) (reference ``NearestNeighborModel.bond_energies``)."""
+        psi = self.psi
+        res = []
+        order = list(range(1, psi.L)) + ([0] if not psi.finite else [])
+        for i in order:
+            h = self.h_bonds[i]
+            if h is None:
+                continue
+            p0, p1 = psi.p_legs[(i - 1) % psi.L], psi.p_legs[i % psi.L]
+            H2 = npc.Array.from_ndarray(np.asarray(h), [p0, p1, p0.conj(), p1.conj()], labels=['p0', 'p1', 'p0*', 'p1*'], cutoff=1e-14)
+            theta = psi.get_theta(i - 1, n=2)
+            C = npc.tensordot(H2, theta, axes=(['p0*', 'p1*'], ['p0', 'p1']))
+            res.append(np.real(npc.inner(theta, C, axes='labels', do_conj=True)))
+        return np.array(res)
+
+    def run_GS(self):
+        """Imaginary time evolution with decreasing time steps until the mean bond energy stops changing (reference :113).
+        Options: ``delta_tau_list``, ``max_error_E`` (1e-13), ``N_steps`` (10), ``order`` (2)."""
+        opt = self.options
+        delta_tau_list = opt.get('delta_tau_list', [0.1, 0.01, 0.001, 1.e-4, 1.e-5, 1.e-6, 1.e-7, 1.e-8, 1.e-9, 1.e-10, 1.e-11, 0.])
+        max_error_E = opt.get('max_error_E', 1.e-13)
+        N_steps = opt.get('N_steps', 10)
+        order = opt.get('order', 2)
+        Eold = float(np.mean(self.bond_energies()))
+        for delta_tau in delta_tau_list:
+            self.calc_U(order, delta_tau, type_evo='imag')
+            DeltaE = 2 * max_error_E
+            while DeltaE > max_error_E:
+                if self.psi.finite and order == 2:
+                    self.update_imag(N_steps, call_canonical_form=False)
+                else:
+                    self.evolve(N_steps, delta_tau)
+                E = float(np.mean(self.bond_energies()))
+                DeltaE = abs(Eold - E)
+                Eold = E
+        return Eold
+
     def run_evolution(self):
         """What the reference's ``TEBDEngine.run()`` does: ``options['N_steps']`` (1) steps of ``options['dt']`` at
         ``options['order']`` (2), real time."""

@@ -943,7 +943,29 @@ def gen_canonical_form_infinite():
     save('canonical_form_infinite.pkl', out)
 
 
-GENERATORS = dict(canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_tebd_gs():
+    """TEBDEngine.run_GS (imaginary time, decreasing steps) for a finite chain (update_imag sweeps) and an infinite one."""
+    from tenpy.algorithms import tebd
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for bc in ('finite', 'infinite'):
+            L = 8 if bc == 'finite' else 2
+            M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': bc, 'conserve': 'parity', 'sort_charge': True})
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc=bc)
+            opts = {'order': 2, 'delta_tau_list': [0.1, 0.01, 0.001], 'N_steps': 10, 'max_error_E': 1.e-9, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}}
+            eng = tebd.TEBDEngine(psi, M, dict(opts))
+            eng.run_GS()
+            out.append(dict(bc=bc, L=L, options=opts, E_bonds=np.array(M.bond_energies(psi)), S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
+                            beta=float(-np.imag(eng.evolved_time)), h_bond=[None if h is None else h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond],
+                            state_labels=list(M.lat.mps_sites()[0].state_labels.items())))
+            print('tebd_gs', bc, np.mean(out[-1]['E_bonds']), out[-1]['beta'], out[-1]['chi'])
+    save('tebd_gs.pkl', out)
+
+
+GENERATORS = dict(tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

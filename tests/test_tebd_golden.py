@@ -91,3 +91,22 @@ def test_tebd_infinite_benchmark_model(backend):
     assert abs(eng.evolved_time - rec['t']) < 1e-14
     np.testing.assert_allclose(np.sort(psi.get_SL(0))[::-1], np.sort(rec['S0'])[::-1], rtol=0, atol=1e-10)
     np.testing.assert_allclose(np.sort(psi.get_SL(1))[::-1], np.sort(rec['S1'])[::-1], rtol=0, atol=1e-10)
+
+
+def test_tebd_run_GS(backend):
+    """``TEBDEngine.run_GS``: imaginary time evolution with decreasing steps until the bond energy stops changing -- finite
+    chain (``update_imag`` sweeps keeping the A - S - B form) and infinite chain -- vs the reference
+    (tests/golden/make_golden.py:gen_tebd_gs): same total imaginary time (= same number of loop iterations), bond energies,
+    entropies."""
+    for rec in golden('tebd_gs.pkl'):
+        L = rec['L']
+        _, p = spin_half_leg('parity')
+        up = dict(rec['state_labels'])['up']
+        psi = MPS.from_product_state([p] * L, [up] * L, bc=rec['bc'])
+        eng = TEBDEngine(psi, rec['h_bond'], dict(rec['options']))
+        E = eng.run_GS()
+        assert abs(-np.imag(eng.evolved_time) - rec['beta']) < 1e-9
+        assert list(psi.chi) == rec['chi']
+        np.testing.assert_allclose(eng.bond_energies(), rec['E_bonds'], rtol=0, atol=1e-9)
+        assert abs(E - np.mean(rec['E_bonds'])) < 1e-9
+        np.testing.assert_allclose(psi.entanglement_entropy(), rec['S'], rtol=0, atol=1e-8)
