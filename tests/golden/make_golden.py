@@ -965,7 +965,60 @@ def gen_tebd_gs():
     save('tebd_gs.pkl', out)
 
 
-GENERATORS = dict(tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_nocharge():
+    """The newer engines WITHOUT charge conservation (TFI chain, conserve=None: one block per tensor) and with Z2 parity:
+    single-site DMRG with subspace expansion, TDVP (two-site then single-site), iDMRG with the default run loop."""
+    from tenpy.algorithms import dmrg, tdvp
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.networks.mps import MPS
+    import copy
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for conserve in (None, 'parity'):
+            L = 8
+            M = TFIChain({'L': L, 'J': 1., 'g': 1.3, 'bc_MPS': 'finite', 'conserve': conserve, 'sort_charge': True})
+            labels = list(M.lat.mps_sites()[0].state_labels.items())
+            # single-site DMRG
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+            eng = dmrg.SingleSiteDMRGEngine(psi, M, {'combine': True, 'max_N_for_ED': 0, 'mixer': True,
+                                                     'mixer_params': {'amplitude': 1.e-3, 'decay': 2., 'disable_after': 3},
+                                                     'trunc_params': {'chi_max': 10, 'svd_min': 1.e-6}})
+            eng.mixer_activate()
+            Es = []
+            for s_ in range(5):
+                eng.sweep()
+                Es.append(float(eng.update_stats['E_total'][-1]))
+            eng.mixer_cleanup()
+            rec = dict(conserve=conserve, L=L, J=1., g=1.3, state_labels=labels, single_E_sweeps=Es,
+                       single_E_updates=[float(e) for e in eng.update_stats['E_total']], single_S=np.array(psi.entanglement_entropy()))
+            # TDVP from the all-up product state
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+            topts = {'dt': 0.05, 'N_steps': 2, 'trunc_params': {'chi_max': 10, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 2, 'N_max': 20}}
+            e2 = tdvp.TwoSiteTDVPEngine(psi, M, copy.deepcopy(topts))
+            steps = []
+            for rep in range(3):
+                e2.run()
+                steps.append(dict(engine='two', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], sz=np.array(psi.expectation_value('Sigmaz'))))
+            e1 = tdvp.SingleSiteTDVPEngine(psi, M, copy.deepcopy(topts))
+            for rep in range(2):
+                e1.run()
+                steps.append(dict(engine='single', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], sz=np.array(psi.expectation_value('Sigmaz'))))
+            rec.update(tdvp_options=topts, tdvp_steps=steps)
+            # iDMRG
+            Mi = TFIChain({'L': 2, 'J': 1., 'g': 1.3, 'bc_MPS': 'infinite', 'conserve': conserve, 'sort_charge': True})
+            psi = MPS.from_product_state(Mi.lat.mps_sites(), ['up'] * 2, bc='infinite')
+            iopts = {'mixer': None, 'max_E_err': 1.e-10, 'max_sweeps': 30, 'N_sweeps_check': 5, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}}
+            ei = dmrg.TwoSiteDMRGEngine(psi, Mi, dict(copy.deepcopy(iopts), combine=True, max_N_for_ED=0))
+            E, _ = ei.run()
+            rec.update(idmrg_options=iopts, idmrg_E=float(E), idmrg_sweeps=int(ei.sweeps), idmrg_E_updates=[float(e) for e in ei.update_stats['E_total']],
+                       idmrg_S=[np.array(psi.get_SL(i)) for i in range(2)])
+            out.append(rec)
+            print('nocharge', conserve, Es[-1], steps[-1]['chi'], E, ei.sweeps)
+    save('nocharge.pkl', out)
+
+
+GENERATORS = dict(nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

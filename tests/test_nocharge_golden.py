@@ -1,0 +1,54 @@
+"""The engines added late in round 1 on tensors WITHOUT charges (one block per tensor, ``ChargeInfo()``) and with Z2 parity
+(tests/golden/make_golden.py:gen_nocharge): single-site DMRG with subspace expansion, TDVP, iDMRG run loop."""
+import numpy as np
+import pytest
+
+from helpers import golden
+from tenpy_amd.algorithms.dmrg import SingleSiteDMRGEngine, TwoSiteDMRGEngine
+from tenpy_amd.algorithms.tdvp import SingleSiteTDVPEngine, TwoSiteTDVPEngine
+from tenpy_amd.models.spin_chains import spin_half_leg, tfi_chain_mpo
+from tenpy_amd.networks.mps import MPS
+
+
+@pytest.mark.parametrize("conserve", [None, 'parity'])
+def test_engines_without_charges(backend, conserve):
+    rec = [r for r in golden('nocharge.pkl') if r['conserve'] == conserve][0]
+    L = rec['L']
+    _, p = spin_half_leg(conserve)
+    up = 1                                       # index of 'up' in this package's leg order (down, up)
+    sz = np.diag([-1., 1.])
+    H = tfi_chain_mpo(L, rec['J'], rec['g'], conserve=conserve)
+    # single-site DMRG
+    psi = MPS.from_product_state([p] * L, [up] * L)
+    eng = SingleSiteDMRGEngine(psi, H, {'mixer': True, 'mixer_params': {'amplitude': 1.e-3, 'decay': 2., 'disable_after': 3},
+                                        'trunc_params': {'chi_max': 10, 'svd_min': 1.e-6}, 'lanczos_params': {}})
+    eng.mixer_activate()
+    for s, E in enumerate(rec['single_E_sweeps']):
+        eng.sweep()
+        assert abs(eng.sweep_stats['E'][-1] - E) <= 1e-10 * abs(E)
+    np.testing.assert_allclose(eng.update_stats['E_total'], rec['single_E_updates'], rtol=1e-10, atol=1e-10)
+    eng.mixer_cleanup()
+    np.testing.assert_allclose(psi.entanglement_entropy(), rec['single_S'], rtol=0, atol=1e-8)
+    # TDVP
+    psi = MPS.from_product_state([p] * L, [up] * L)
+    e2 = TwoSiteTDVPEngine(psi, H, dict(rec['tdvp_options']))
+    e1 = None
+    for step in rec['tdvp_steps']:
+        if step['engine'] == 'two':
+            e2.run()
+        else:
+            e1 = e1 or SingleSiteTDVPEngine(psi, H, dict(rec['tdvp_options']))
+            e1.run()
+        assert list(psi.chi) == step['chi']
+        np.testing.assert_allclose(psi.entanglement_entropy(), step['S'], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(psi.expectation_value(sz), step['sz'], rtol=0, atol=1e-10)
+    # iDMRG
+    Hi = tfi_chain_mpo(2, rec['J'], rec['g'], conserve=conserve, bc='infinite')
+    psi = MPS.from_product_state([p] * 2, [up] * 2, bc='infinite')
+    ei = TwoSiteDMRGEngine(psi, Hi, dict(rec['idmrg_options']))
+    E, _ = ei.run()
+    assert ei.sweeps == rec['idmrg_sweeps'] and abs(E - rec['idmrg_E']) < 1e-10
+    assert abs(E - (-1.50082324)) < 1e-6        # the golden number of the reference's own iDMRG test (tests/test_dmrg.py:130)
+    np.testing.assert_allclose(ei.update_stats['E_total'], rec['idmrg_E_updates'], rtol=1e-10, atol=1e-9)
+    for i in range(2):
+        np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['idmrg_S'][i])[::-1], rtol=0, atol=1e-8)
