@@ -304,6 +304,50 @@ class MPS:
         res = np.array(res)
         return np.real_if_close(res)
 
+    def correlation_function(self, op1, op2, sites1=None, sites2=None, opstr=None):
+        """``C[i, j] = <psi| op1_i op2_j |psi>`` for one-site operators given as dense (d, d) host matrices [p, p*] or device
+        Arrays with labels 'p', 'p*' (reference ``MPS.correlation_function`` for ``str_on_first=True`` semantics: the operator
+        string ``opstr`` -- e.g. the Jordan-Wigner sign -- acts on the sites strictly between i and j and, multiplied onto
+        ``op1``, on site min(i, j) when given).  Finite MPS; every entry is a chain of device tensordots."""
+        if not self.finite:
+            raise NotImplementedError("tenpy_amd: correlation_function of infinite MPS")
+        L = self.L
+        sites1 = list(range(L)) if sites1 is None else list(sites1)
+        sites2 = list(range(L)) if sites2 is None else list(sites2)
+
+        def as_op(op, i):
+            if isinstance(op, npc.Array):
+                return op
+            leg = self._B[i].get_leg('p')
+            return npc.Array.from_ndarray(np.asarray(op), [leg, leg.conj()], labels=['p', 'p*'], cutoff=0.)
+        res = np.zeros((len(sites1), len(sites2)), dtype=np.complex128)
+        for a, i in enumerate(sites1):
+            for b, j in enumerate(sites2):
+                if i == j:
+                    O = npc.tensordot(as_op(op1, i), as_op(op2, i), axes=['p*', 'p'])
+                    th = self.get_B(i, 'Th')
+                    res[a, b] = npc.inner(th, npc.tensordot(O, th, axes=['p*', 'p']), axes='labels', do_conj=True)
+                    continue
+                lo, hi = (i, j) if i < j else (j, i)
+                O_lo, O_hi = (as_op(op1, i), as_op(op2, j)) if i < j else (as_op(op2, j), as_op(op1, i))
+                if opstr is not None:
+                    S_lo = as_op(opstr, lo)
+                    O_lo = npc.tensordot(O_lo, S_lo, axes=['p*', 'p']) if i < j else npc.tensordot(S_lo, O_lo, axes=['p*', 'p'])
+                th = self.get_B(lo, 'Th')            # orthogonality centre on the left site: everything to its left drops out
+                C = npc.tensordot(O_lo, th, axes=['p*', 'p'])
+                C = npc.tensordot(th.conj(), C, axes=[['vL*', 'p*'], ['vL', 'p']])           # vR*, vR
+                for k in range(lo + 1, hi):
+                    B = self.get_B(k, 'B')
+                    C = npc.tensordot(C, B, axes=['vR', 'vL'])
+                    if opstr is not None:
+                        C = npc.tensordot(as_op(opstr, k), C, axes=['p*', 'p'])
+                    C = npc.tensordot(B.conj(), C, axes=[['vL*', 'p*'], ['vR*', 'p']])
+                B = self.get_B(hi, 'B')
+                C = npc.tensordot(C, B, axes=['vR', 'vL'])
+                C = npc.tensordot(O_hi, C, axes=['p*', 'p'])
+                res[a, b] = npc.inner(B.conj(), C, axes=[['vL*', 'p*', 'vR*'], ['vR*', 'p', 'vR']], do_conj=False)
+        return np.real_if_close(res)
+
     def overlap(self, other):
         """``<self|other>`` including the norms of both states (reference ``MPS.overlap`` for finite MPS)."""
         if not (self.finite and other.finite):

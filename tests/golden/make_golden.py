@@ -1018,7 +1018,30 @@ def gen_nocharge():
     save('nocharge.pkl', out)
 
 
-GENERATORS = dict(nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_correlations():
+    """Correlation functions of a DMRG ground state (XXZ chain): Sz-Sz, S+ S-, and the state itself (B tensors) so that the
+    device code is checked on identical input."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 8
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.6, 'hz': 0.05, 'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        dmrg.run(psi, M, {'mixer': None, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}, 'max_sweeps': 6})
+        site = M.lat.mps_sites()[0]
+        out.append(dict(L=L, B=[dump_array(psi.get_B(i, 'B').transpose(['vL', 'p', 'vR'])) for i in range(L)],
+                        S=[np.array(psi.get_SL(i)) for i in range(L)] + [np.array(psi.get_SR(L - 1))],
+                        SzSz=np.array(psi.correlation_function('Sz', 'Sz')), SpSm=np.array(psi.correlation_function('Sp', 'Sm')),
+                        SzSz_sub=np.array(psi.correlation_function('Sz', 'Sz', sites1=[1, 4], sites2=[0, 4, 7])),
+                        Sz=site.Sz.to_ndarray(), Sp=site.Sp.to_ndarray(), Sm=site.Sm.to_ndarray(), exp_Sz=np.array(psi.expectation_value('Sz'))))
+        print('correlations', out[-1]['SzSz'][0, :3])
+    save('correlations.pkl', out)
+
+
+GENERATORS = dict(correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

@@ -42,3 +42,15 @@ def test_canonical_form_infinite(backend):
             np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S_out'][i])[::-1], rtol=0, atol=1e-10)
         np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-10)
         np.testing.assert_allclose(psi.expectation_value(np.diag([-0.5, 0.5])), rec['Sz'], rtol=0, atol=1e-10)
+
+
+def test_correlation_function(backend):
+    """``MPS.correlation_function`` / ``expectation_value`` on a DMRG ground state dumped from the reference."""
+    rec = golden('correlations.pkl')[0]
+    L = rec['L']
+    Bs = [load_array(b) for b in rec['B']]
+    psi = MPS([B.get_leg('p') for B in Bs], Bs, rec['S'], form='B')
+    np.testing.assert_allclose(psi.expectation_value(rec['Sz']), rec['exp_Sz'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(psi.correlation_function(rec['Sz'], rec['Sz']), rec['SzSz'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(psi.correlation_function(rec['Sp'], rec['Sm']), rec['SpSm'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(psi.correlation_function(rec['Sz'], rec['Sz'], sites1=[1, 4], sites2=[0, 4, 7]), rec['SzSz_sub'], rtol=0, atol=1e-12)
