@@ -67,7 +67,10 @@ class TDVPEngine:
 
     def run(self):
         """``options['N_steps']`` steps of ``options['dt']`` (reference ``TimeEvolutionAlgorithm.run``)."""
+        old_norm = self.psi.norm
         self.evolve(self.options.get('N_steps', 1), self.options.get('dt', 0.1))
+        if self.options.get('preserve_norm', True):      # real time: keep the norm (reference ``run_evolution``)
+            self.psi.norm = old_norm
         return self.psi
 
 

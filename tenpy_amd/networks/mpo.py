@@ -30,9 +30,135 @@ class MPO:
     def get_W(self, i):
         return self._W[i if self.finite else i % self.L]
 
+    # ---- time evolution operators (Zaletel et al. 2015; reference mpo.py:959-1112, make_W_II :2144) ------------------------
+    def make_U(self, dt, approximation='II'):
+        if approximation != 'II':
+            raise NotImplementedError("tenpy_amd: only the W_II approximation is implemented")
+        return self.make_U_II(dt)
+
+    def make_U_II(self, dt):
+        """``U_II ~= exp(dt H)`` as an MPO (``dt`` imaginary for real time).  The small dense exponentials of the W_II
+        construction are host work done once per time step size, like the bond gates of TEBD; the result is an MPO of
+        device tensors with IdL = IdR = 0."""
+        import scipy.linalg
+        if not self.finite:
+            raise NotImplementedError("tenpy_amd: make_U_II for infinite MPO")
+        Ws = []
+        for i in range(self.L):
+            W = self.get_W(i)
+            Wd = W.transpose(['wL', 'wR', 'p', 'p*']).to_ndarray()
+            DL, DR = Wd.shape[:2]
+            IdL_l, IdR_l = self.IdL % DL if DL > 1 else 0, self.IdR % DL if DL > 1 else 0
+            IdL_r, IdR_r = self.IdL % DR if DR > 1 else 0, self.IdR % DR if DR > 1 else 0
+            if i == 0:
+                IdL_l = IdR_l = 0                       # the boundary leg of a finite chain has one entry (= IdL)
+            if i == self.L - 1:
+                IdL_r = IdR_r = 0                       # ... (= IdR)
+            proj_L = np.ones(DL, dtype=bool)
+            proj_R = np.ones(DR, dtype=bool)
+            if i > 0:
+                proj_L[[IdL_l, IdR_l]] = False
+            else:
+                proj_L[:] = False
+            if i < self.L - 1:
+                proj_R[[IdL_r, IdR_r]] = False
+            else:
+                proj_R[:] = False
+            D = Wd[IdL_l, IdR_r]
+            C = Wd[IdL_l][proj_R]
+            B = Wd[proj_L][:, IdR_r]
+            A = Wd[proj_L][:, proj_R]
+            Ws.append(_make_W_II(dt, A, B, C, D, scipy.linalg.expm))
+        return mpo_from_dense(Ws, self.p_legs, self.chinfo, dtype=np.result_type(dt, self.dtype), IdL=0, IdR=0)
+
+    def apply_naively(self, psi):
+        """``psi <- self psi`` without compression: bond dimension chi_MPO * chi (reference :1611).  The Schmidt values
+        are only placeholders afterwards; compress or canonicalise."""
+        if not (self.finite and psi.finite) or psi.L != self.L:
+            raise NotImplementedError("tenpy_amd: apply_naively for finite MPS / MPO of equal length")
+        from ..linalg.charges import LegCharge
+        L = psi.L
+
+        def plain(leg):        # LegPipe -> LegCharge with the same charge data (reference ``to_LegCharge``)
+            return LegCharge.from_qind(leg.chinfo, leg.slices, leg.charges, leg.qconj)
+        for i in range(L):
+            B = npc.tensordot(psi.get_B(i, 'B'), self.get_W(i), axes=('p', 'p*'))
+            if i == 0:
+                B = B.take_slice(self.IdL % self.get_W(i).get_leg('wL').ind_len, 'wL')
+            if i == L - 1:
+                B = B.take_slice(self.IdR % self.get_W(i).get_leg('wR').ind_len, 'wR')
+            groups, qc = [], []
+            if i > 0:
+                groups.append(['wL', 'vL'])
+                qc.append(+1)
+            if i < L - 1:
+                groups.append(['wR', 'vR'])
+                qc.append(-1)
+            if groups:
+                B = B.combine_legs(groups, qconj=qc)
+                B.ireplace_labels(['(wL.vL)', '(wR.vR)'][(0 if i > 0 else 1):(2 if i < L - 1 else 1)],
+                                  ['vL', 'vR'][(0 if i > 0 else 1):(2 if i < L - 1 else 1)])
+                for lab in ('vL', 'vR'):
+                    a = B.get_leg_index(lab)
+                    if hasattr(B.legs[a], 'q_map'):
+                        B.legs[a] = plain(B.legs[a])
+                        B._skey = None
+            psi.set_B(i, B, 'B')
+        psi.set_SL(0, np.ones(psi.get_B(0, None).get_leg('vL').ind_len))
+        for i in range(L):
+            psi.set_SR(i, np.ones(psi.get_B(i, None).get_leg('vR').ind_len))
+
+    def apply(self, psi, options):
+        """Apply to ``psi`` in place and compress; ``options['compression_method']`` = 'SVD' (reference :1562)."""
+        method = options.get('compression_method', 'SVD')
+        if method != 'SVD':
+            raise NotImplementedError("tenpy_amd: compression_method %r" % (method,))
+        self.apply_naively(psi)
+        return psi.compress_svd(dict(options.get('trunc_params', {})))
+
     @property
     def chi(self):
         return [W.get_leg('wR').ind_len for W in self._W[:-1]]
+
+
+def _make_W_II(t, A, B, C, D, expm):
+    """W_II tensor (Zaletel et al. 2015, Eq. 11) from the blocks of ``W = [[1, C, D], [0, A, B], [0, 0, 1]]``: for every
+    (row, column) of A one exponential in a space extended by two hard-core bosons."""
+    tC = np.sqrt(np.abs(t))
+    tB = t / tC
+    d = D.shape[0]
+    Nr, Nc = A.shape[0], A.shape[1]
+    W = np.zeros((1 + Nr, 1 + Nc, d, d), dtype=np.result_type(D, t))
+    Id2 = np.eye(2)
+    b = np.array([[0., 0.], [1., 0.]])
+    Id4, Br, Bc, Brc = np.kron(Id2, Id2), np.kron(b, Id2), np.kron(Id2, b), np.kron(b, b)
+
+    def part(h):
+        return expm(h).reshape((2, 2, d, 2, 2, d))[:, :, :, 0, 0, :]
+    for r in range(Nr):
+        for c in range(Nc):
+            w = part(np.kron(Brc, A[r, c]) + np.kron(Br, tB * B[r]) + np.kron(Bc, tC * C[c]) + t * np.kron(Id4, D))
+            W[1 + r, 1 + c] = w[1, 1]
+            if c == 0:
+                W[1 + r, 0] = w[1, 0]
+            if r == 0:
+                W[0, 1 + c] = w[0, 1]
+                if c == 0:
+                    W[0, 0] = w[0, 0]
+        if Nc == 0:
+            w = part(np.kron(Br, tB * B[r]) + t * np.kron(Id4, D))
+            W[1 + r, 0] = w[1, 0]
+            if r == 0:
+                W[0, 0] = w[0, 0]
+    if Nr == 0:
+        for c in range(Nc):
+            w = part(np.kron(Bc, tC * C[c]) + t * np.kron(Id4, D))
+            W[0, 1 + c] = w[0, 1]
+            if c == 0:
+                W[0, 0] = w[0, 0]
+        if Nc == 0:
+            W = expm(t * D).reshape([1, 1, d, d])
+    return W
 
 
 def mpo_from_dense(W_dense_list, p_legs, chinfo, dtype=np.float64, IdL=0, IdR=-1, bc='finite'):

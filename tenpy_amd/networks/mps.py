@@ -362,6 +362,29 @@ class MPS:
         res.norm = self.norm
         return res
 
+    def compress_svd(self, trunc_par):
+        """One right-sweep of QR decompositions without truncation, then a left-sweep of truncating SVDs (reference :5895).
+        Returns the truncation error."""
+        from ..linalg.truncation import svd_theta, TruncationError
+        if not self.finite:
+            raise NotImplementedError("tenpy_amd: compress_svd of infinite MPS")
+        trunc_err = TruncationError()
+        L = self.L
+        B = self.get_B(0, 'Th')
+        for i in range(L - 1):
+            q, r = npc.qr(B.combine_legs(['vL', 'p']), inner_labels=['vR', 'vL'])
+            self.set_B(i, q.split_legs(), form=None)
+            B = npc.tensordot(r, self.get_B(i + 1, 'B'), axes=('vR', 'vL'))
+        for i in range(L - 1, 0, -1):
+            U, S, VH, err, norm_new = svd_theta(B.combine_legs(['p', 'vR']), trunc_par)
+            trunc_err = trunc_err + err
+            self.norm *= norm_new
+            self.set_B(i, VH.split_legs(), form='B')
+            B = npc.tensordot(self._B[i - 1], U, axes=('vR', 'vL')).iscale_axis(S, 'vR')
+            self.set_SL(i, S)
+        self.set_B(0, B, form='Th')
+        return trunc_err
+
     def entanglement_entropy(self):
         res = []
         for s in (self._S[1:-1] if self.finite else self._S[:self.L]):      # infinite: the bond LEFT of every site

@@ -1041,7 +1041,34 @@ def gen_correlations():
     save('correlations.pkl', out)
 
 
-GENERATORS = dict(correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_mpo_evolution():
+    """ExpMPOEvolution (W_II, orders 1 and 2, SVD compression) after a quench from the Neel state, plus the W_II tensors."""
+    from tenpy.algorithms import mpo_evolution
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 6
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.8, 'hz': 0.1, 'bc_MPS': 'finite', 'sort_charge': True})
+        for order in (1, 2):
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+            opts = {'dt': 0.05, 'N_steps': 2, 'order': order, 'approximation': 'II', 'compression_method': 'SVD',
+                    'trunc_params': {'chi_max': 10, 'svd_min': 1.e-10}}
+            eng = mpo_evolution.ExpMPOEvolution(psi, M, dict(opts))
+            steps = []
+            for rep in range(4):
+                eng.run()
+                steps.append(dict(S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], Sz=np.array(psi.expectation_value('Sz')),
+                                  norm=float(psi.norm)))
+            U = M.H_MPO.make_U_II(-0.05j)
+            out.append(dict(L=L, Jxx=1., Jz=0.8, hz=0.1, order=order, options=opts, steps=steps, trunc_err=float(eng.trunc_err.eps),
+                            W_II=[U.get_W(i).transpose(['wL', 'wR', 'p', 'p*']).to_ndarray() for i in range(L)]))
+            print('mpo_evolution', order, steps[-1]['chi'], steps[-1]['S'][L // 2 - 1], steps[-1]['norm'])
+    save('mpo_evolution.pkl', out)
+
+
+GENERATORS = dict(mpo_evolution=gen_mpo_evolution, correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
