@@ -9,7 +9,7 @@ reference's disk cache ("long-context" row).
 import numpy as np
 
 from ..linalg import np_conserved as npc
-from ..linalg.charges import LegCharge
+from ..linalg.charges import ChargeInfo, LegCharge
 
 __all__ = ['MPO', 'MPOEnvironment', 'MPOTransferMatrix', 'mpo_from_dense']
 
@@ -37,10 +37,12 @@ class MPO:
         return self.make_U_II(dt)
 
     def make_U_II(self, dt):
-        """``U_II ~= exp(dt H)`` as an MPO (``dt`` imaginary for real time).  The small dense exponentials of the W_II
-        construction are host work done once per time step size, like the bond gates of TEBD; the result is an MPO of
-        device tensors with IdL = IdR = 0."""
-        import scipy.linalg
+        """``U_II ~= exp(dt H)`` as an MPO (``dt`` imaginary for real time), IdL = IdR = 0.  The (4d x 4d) exponentials of the
+        W_II construction go through the device ``npc.expm`` (charge-less blocks), once per time step size."""
+        def expm(h):
+            h = np.asarray(h)
+            leg = LegCharge.from_trivial(h.shape[0], ChargeInfo())
+            return npc.expm(npc.Array.from_ndarray(h, [leg, leg.conj()])).to_ndarray()
         if not self.finite:
             raise NotImplementedError("tenpy_amd: make_U_II for infinite MPO")
         Ws = []
@@ -68,7 +70,7 @@ class MPO:
             C = Wd[IdL_l][proj_R]
             B = Wd[proj_L][:, IdR_r]
             A = Wd[proj_L][:, proj_R]
-            Ws.append(_make_W_II(dt, A, B, C, D, scipy.linalg.expm))
+            Ws.append(_make_W_II(dt, A, B, C, D, expm))
         return mpo_from_dense(Ws, self.p_legs, self.chinfo, dtype=np.result_type(dt, self.dtype), IdL=0, IdR=0)
 
     def apply_naively(self, psi):

@@ -19,11 +19,12 @@ def test_exp_mpo_evolution(backend):
             mine = U.get_W(i).transpose(['wL', 'wR', 'p', 'p*']).to_ndarray()
             ref = rec['W_II'][i]
             assert mine.shape == ref.shape
-            # the middle MPO indices (S+, S-, Sz channels) may be ordered differently: compare as sets of matrices
-            if not np.allclose(mine, ref, atol=1e-13):
-                a = sorted([np.round(mine[x, y], 12).tobytes() for x in range(mine.shape[0]) for y in range(mine.shape[1])])
-                b = sorted([np.round(ref[x, y], 12).tobytes() for x in range(ref.shape[0]) for y in range(ref.shape[1])])
-                assert a == b
+            # (the S+ / S- / Sz channels of the MPO bond may be numbered differently: compare the multiset of operator entries)
+            def canon(W):
+                v = W.reshape(-1, W.shape[2] * W.shape[3])
+                key = np.round(np.concatenate([v.real, v.imag], axis=1), 9) + 0.
+                return v[np.lexsort(key.T[::-1])]
+            np.testing.assert_allclose(canon(mine), canon(ref), rtol=0, atol=1e-12)
         psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
         eng = ExpMPOEvolution(psi, H, dict(rec['options']))
         for step in rec['steps']:
