@@ -40,8 +40,9 @@ def test_single_site_dmrg(backend):
             eng.sweep()
             assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= 1e-10 * abs(rec['E_sweeps'][s])
         assert eng.update_stats['i0'] == rec['i0_updates']
-        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-10)
-        np.testing.assert_allclose(eng.update_stats['err'], rec['err_updates'], rtol=0, atol=1e-11)
+        tol_u = 1e-10 if backend == 'mock' else 1e-8      # (GPU: Jacobi instead of LAPACK rounding in every SVD)
+        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=tol_u, atol=tol_u)
+        np.testing.assert_allclose(eng.update_stats['err'], rec['err_updates'], rtol=0, atol=1e-11 if backend == 'mock' else 1e-9)
         eng.mixer_cleanup()
         assert list(psi.chi) == rec['chi_final']
         for i in range(1, L):
@@ -121,8 +122,9 @@ def test_two_site_dmrg_with_subspace_expansion(backend):
             assert (eng.mixer is not None) == rec['mixer_on'][s]
             eng.sweep()
             assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= 1e-10 * abs(rec['E_sweeps'][s])
-        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-10)
-        np.testing.assert_allclose(eng.update_stats['err'], rec['err_updates'], rtol=0, atol=1e-11)
+        tol_u = 1e-10 if backend == 'mock' else 1e-8
+        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=tol_u, atol=tol_u)
+        np.testing.assert_allclose(eng.update_stats['err'], rec['err_updates'], rtol=0, atol=1e-11 if backend == 'mock' else 1e-9)
         eng.mixer_cleanup()
         for i in range(1, L):
             np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i - 1])[::-1], rtol=0, atol=1e-9)

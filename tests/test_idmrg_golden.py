@@ -30,11 +30,14 @@ def test_idmrg(backend):
         assert eng.update_stats['i0'] == rec['i0']
         assert eng.update_stats['age'] == rec['age']
         # (the first environments are the dominant eigenvectors of the MPO transfer matrix, like the reference's)
-        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-9)
+        tol_u = 1e-10 if backend == 'mock' else 1e-8
+        np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=tol_u, atol=10 * tol_u)
         for k, tol in (('sweep', 0), ('N_updates', 0), ('E', 1e-10), ('Delta_E', 1e-10), ('S', 1e-8), ('Delta_S', 1e-8), ('max_S', 1e-8),
                        ('max_trunc_err', 1e-11), ('max_E_trunc', 1e-9), ('max_chi', 0)):
             a, b = np.array(eng.sweep_stats[k], dtype=float), np.array(rec['sweep_stats'][k], dtype=float)
             assert a.shape == b.shape, k
+            if backend != 'mock' and tol > 0:
+                tol = max(100 * tol, 1e-8)
             assert np.all(np.isnan(b) | (np.abs(a - b) <= tol * np.maximum(1., np.abs(b)))), (k, a, b)
         assert list(psi.chi) == rec['chi']
         for i in range(L):
@@ -62,7 +65,7 @@ def test_idmrg_benchmark_model(backend):
         eng.sweep(optimize=False)
     assert eng.update_stats['i0'] == rec['i0']
     assert eng.update_stats['age'] == rec['age']
-    np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=1e-10 if backend == 'mock' else 1e-8, atol=1e-8 if backend == 'mock' else 1e-6)
     assert list(psi.chi) == rec['chi_final']
     np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-7)
     assert labels['up'] in (0, d - 1) and n0 > 0

@@ -26,7 +26,8 @@ def test_engines_without_charges(backend, conserve):
     for s, E in enumerate(rec['single_E_sweeps']):
         eng.sweep()
         assert abs(eng.sweep_stats['E'][-1] - E) <= 1e-10 * abs(E)
-    np.testing.assert_allclose(eng.update_stats['E_total'], rec['single_E_updates'], rtol=1e-10, atol=1e-10)
+    tol_u = 1e-10 if backend == 'mock' else 1e-8
+    np.testing.assert_allclose(eng.update_stats['E_total'], rec['single_E_updates'], rtol=tol_u, atol=tol_u)
     eng.mixer_cleanup()
     np.testing.assert_allclose(psi.entanglement_entropy(), rec['single_S'], rtol=0, atol=1e-8)
     # TDVP
@@ -49,6 +50,6 @@ def test_engines_without_charges(backend, conserve):
     E, _ = ei.run()
     assert ei.sweeps == rec['idmrg_sweeps'] and abs(E - rec['idmrg_E']) < 1e-10
     assert abs(E - (-1.50082324)) < 1e-6        # the golden number of the reference's own iDMRG test (tests/test_dmrg.py:130)
-    np.testing.assert_allclose(ei.update_stats['E_total'], rec['idmrg_E_updates'], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(ei.update_stats['E_total'], rec['idmrg_E_updates'], rtol=tol_u, atol=10 * tol_u)
     for i in range(2):
         np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['idmrg_S'][i])[::-1], rtol=0, atol=1e-8)
