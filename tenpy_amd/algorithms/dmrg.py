@@ -507,7 +507,12 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
             raise NotImplementedError("tenpy_amd: single-site DMRG supports the SubspaceExpansion mixer (or none)")
 
     def get_sweep_schedule(self):
-        L = self.psi.L                      # reference mps_common.py:438-443 with n = 1
+        L = self.psi.L                      # reference mps_common.py:438-454 with n = 1
+        if not self.finite:
+            i0s = list(range(0, L)) + list(range(L, 0, -1))
+            move_right = [True] * L + [False] * L
+            update_LP_RP = [[True, True]] + [[True, False]] * (L - 1) + [[True, True]] + [[False, True]] * (L - 1)
+            return list(zip(i0s, move_right, update_LP_RP))
         i0s = list(range(0, L - 1)) + list(range(L - 1, 0, -1))
         move_right = [True] * (L - 1) + [False] * (L - 1)
         update_LP_RP = [[True, False]] * (L - 1) + [[False, True]] * (L - 1)
@@ -552,12 +557,20 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
         eff_H = OneSiteH(self.env, i0, combine=True, move_right=move_right)
         theta = eff_H.combine_theta(psi.get_theta(i0, n=1, cutoff=self.S_inv_cutoff))
         op = self._wrap_ortho_eff_H(eff_H, i0, 1)
+        age = (self.env.get_LP_age(i0) or 0) + 1 + (self.env.get_RP_age(i0) or 0)
         tick('heff')
-        E0, theta, N = self.diag(eff_H, op, theta)
+        if self._optimize:
+            E0, theta, N = self.diag(eff_H, op, theta)
+        else:
+            E0, N = None, 0
         tick('lanczos')
         U, S, VH, err, S_a = self.mixed_svd(eff_H, theta, i0, move_right)
         tick('svd')
         i_L, i_R = (i0, i0 + 1) if move_right else (i0 - 1, i0)
+        psi.set_B(i_L, U.split_legs(['(vL.p)']), form='A')       # the state first: the generic environment updates
+        psi.set_B(i_R, VH.split_legs(['(p.vR)']), form='B')      # (``env.get_LP / get_RP``) contract the NEW tensors
+        psi.set_SR(i_L, S)
+        tick('setB')
         self.env.del_LP(i_R)
         self.env.del_RP(i_L)
         if update_LP:
@@ -565,20 +578,20 @@ class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
         if update_RP:
             eff_H.update_RP(self.env, i_L, VH)
         tick('env')
-        psi.set_B(i_L, U.split_legs(['(vL.p)']), form='A')
-        psi.set_B(i_R, VH.split_legs(['(p.vR)']), form='B')
-        psi.set_SR(i_L, S)
-        tick('setB')
-        for j in range(i_R + 1, psi.L):      # environments built from the old tensors are stale now
-            if self.env._LP[j] is None:
-                break
-            self.env._LP[j] = None
-        for j in range(i_L - 1, -1, -1):
-            if self.env._RP[j] is None:
-                break
-            self.env._RP[j] = None
-        self._update_ortho_envs(i_L, i_R, update_LP, update_RP)
+        if self.finite:
+            for j in range(i_R + 1, psi.L):      # environments built from the old tensors are stale now
+                if self.env._LP[j] is None:
+                    break
+                self.env._LP[j] = None
+            for j in range(i_L - 1, -1, -1):
+                if self.env._RP[j] is None:
+                    break
+                self.env._RP[j] = None
+            self._update_ortho_envs(i_L, i_R, update_LP, update_RP)
+        if E0 is None:
+            E0 = float(np.real(self.env.full_contraction(i_L)))
         us = self.update_stats
+        us.setdefault('age', []).append(age)
         us['i0'].append(i0)
         us['E_total'].append(float(E0))
         us['N_lanczos'].append(N)

@@ -1068,7 +1068,33 @@ def gen_mpo_evolution():
     save('mpo_evolution.pkl', out)
 
 
-GENERATORS = dict(mpo_evolution=gen_mpo_evolution, correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_idmrg_single():
+    """Single-site infinite DMRG with the subspace expansion (reference defaults for the run loop)."""
+    from tenpy.algorithms import dmrg
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    import copy
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 2
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.5, 'hz': 0., 'bc_MPS': 'infinite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
+        opts = {'mixer': True, 'mixer_params': {'amplitude': 1.e-3, 'decay': 1.5, 'disable_after': 8}, 'combine': True, 'max_N_for_ED': 0,
+                'max_E_err': 1.e-9, 'max_sweeps': 40, 'N_sweeps_check': 5, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-6}}
+        opts_plain = copy.deepcopy(opts)
+        eng = dmrg.SingleSiteDMRGEngine(psi, M, opts)
+        E, _ = eng.run()
+        st = eng.sweep_stats
+        out.append(dict(E=float(E), sweeps=int(eng.sweeps), options=opts_plain, E_updates=[float(e) for e in eng.update_stats['E_total']],
+                        age=[int(a) for a in eng.update_stats['age']], i0=[int(i) for i in eng.update_stats['i0']],
+                        sweep_stats={k: [float(x) for x in st[k]] for k in ('sweep', 'E', 'Delta_E', 'S', 'max_chi')},
+                        S=[np.array(psi.get_SL(i)) for i in range(L)], chi=[int(c) for c in psi.chi], L=L, Jxx=1., Jz=1.5, hz=0.))
+        print('idmrg_single', E, eng.sweeps, psi.chi)
+    save('idmrg_single.pkl', out)
+
+
+GENERATORS = dict(idmrg_single=gen_idmrg_single, mpo_evolution=gen_mpo_evolution, correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':

@@ -69,3 +69,26 @@ def test_idmrg_benchmark_model(backend):
     assert list(psi.chi) == rec['chi_final']
     np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-7)
     assert labels['up'] in (0, d - 1) and n0 > 0
+
+
+def test_idmrg_single_site(backend):
+    """Single-site infinite DMRG with the subspace expansion vs the reference's run."""
+    from tenpy_amd.algorithms.dmrg import SingleSiteDMRGEngine
+    rec = golden('idmrg_single.pkl')[0]
+    L = rec['L']
+    H = xxz_chain_mpo(L, rec['Jxx'], rec['Jz'], rec['hz'], bc='infinite')
+    _, p = spin_half_leg('Sz')
+    psi = MPS.from_product_state([p] * L, [1, 0], bc='infinite')
+    opts = {k: v for k, v in rec['options'].items() if k not in ('combine', 'max_N_for_ED')}
+    eng = SingleSiteDMRGEngine(psi, H, opts)
+    E, _ = eng.run()
+    assert eng.sweeps == rec['sweeps'] and abs(E - rec['E']) < 1e-9
+    assert eng.update_stats['i0'] == rec['i0'] and eng.update_stats['age'] == rec['age']
+    tol_u = 1e-9 if backend == 'mock' else 1e-7
+    np.testing.assert_allclose(eng.update_stats['E_total'], rec['E_updates'], rtol=tol_u, atol=10 * tol_u)
+    for k in ('E', 'Delta_E', 'S'):
+        a, b = np.array(eng.sweep_stats[k], dtype=float), np.array(rec['sweep_stats'][k], dtype=float)
+        assert a.shape == b.shape and np.all(np.isnan(b) | (np.abs(a - b) < 1e-7)), (k, a, b)
+    assert list(psi.chi) == rec['chi']
+    for i in range(L):
+        np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S'][i])[::-1], rtol=0, atol=1e-7)
