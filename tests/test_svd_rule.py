@@ -80,3 +80,39 @@ def test_predicted_convergence_saves_the_verification_sweep():
             Wn = W[big] / nr[big, None]
             assert np.abs(Wn @ Wn.T - np.eye(big.sum())).max() < 1e-12
     assert saved >= 2
+
+
+def test_npc_svd_with_predicted_convergence(backend):
+    """`tpa_svd_set_algorithm(1024)`: the device iteration may stop after a sweep without big rotations.  Results must be
+    the same as with the default rule (singular values, reconstruction, orthogonality), with no more sweeps."""
+    from tenpy_amd import _lib
+    from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
+    rng = np.random.RandomState(21)
+    ch = ChargeInfo([1])
+    mats = []
+    for m, n, r in ((96, 96, 50), (70, 130, 70), (20, 24, 11)):
+        mats.append(rng.standard_normal((m, r)) @ np.diag(np.logspace(0, -9, r)) @ rng.standard_normal((r, n)))
+    lib = _lib.load()
+    results = {}
+    try:
+        for alg in (0, 1024):
+            lib.tpa_svd_set_algorithm(alg)
+            npc.svd_stats.update(calls=0, sweeps=0, max_block=0)
+            out = []
+            for A in mats:
+                m, n = A.shape
+                a = npc.Array.from_ndarray(A, [LegCharge.from_qflat(ch, np.zeros((m, 1), int)), LegCharge.from_qflat(ch, np.zeros((n, 1), int), -1)])
+                U, S, VH = npc.svd(a)
+                out.append((U.to_ndarray(), S, VH.to_ndarray()))
+            results[alg] = (out, npc.svd_stats['sweeps'])
+    finally:
+        lib.tpa_svd_set_algorithm(0)
+    assert results[1024][1] <= results[0][1]
+    for A, (U0, S0, V0), (U1, S1, V1) in zip(mats, results[0][0], results[1024][0]):
+        ref = np.linalg.svd(A, compute_uv=False)
+        for U, S, V in ((U0, S0, V0), (U1, S1, V1)):
+            np.testing.assert_allclose(np.sort(S)[::-1], ref[:len(S)], rtol=0, atol=1e-13 * ref[0])
+            np.testing.assert_allclose((U * S) @ V, A, rtol=0, atol=1e-12 * ref[0])
+            big = S > 1e-6 * ref[0]
+            np.testing.assert_allclose(U[:, big].T @ U[:, big], np.eye(big.sum()), rtol=0, atol=1e-11)
+            np.testing.assert_allclose(V[big] @ V[big].T, np.eye(big.sum()), rtol=0, atol=1e-11)
