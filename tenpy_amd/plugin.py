@@ -8,7 +8,9 @@ module attributes that the two-site DMRG driver resolves at call time are replac
   per bond, LHeff / RHeff are fused on the device, and the whole Krylov recurrence (2 GEMM launches per matvec + the
   fused vector update) runs there; only theta goes in and the ground state comes back;
 * ``tenpy.linalg.np_conserved.svd`` (np_conserved.py:3676, used by ``truncation.svd_theta`` :258) -- block SVD on the
-  device for ``full_matrices=False, compute_uv=True``.
+  device for ``full_matrices=False, compute_uv=True``;
+* ``tenpy.linalg.np_conserved.eigh`` (:3899, the density-matrix mixer) and ``qr`` (:4139, ``mode='reduced'``: QR-based
+  truncation, canonical forms) -- block decompositions on the device.
 
 Everything else (models, MPS bookkeeping, truncation masks, environment update) stays the reference's own code.  The
 conversion functions :func:`to_device` / :func:`to_reference` carry legs (incl. nested pipes), ``_qdata``, ``qtotal``
@@ -147,6 +149,28 @@ def _svd(orig_svd, tenpy):
     return svd
 
 
+def _eigh(orig_eigh, tenpy):
+    def eigh(a, UPLO='L', sort=None):
+        if a.rank != 2:
+            return orig_eigh(a, UPLO, sort)
+        W, V = npc.eigh(to_device(a), UPLO=UPLO, sort=sort)
+        return np.asarray(W), to_reference(V, tenpy, legs=[a.legs[0], a.legs[0].conj()])
+    return eigh
+
+
+def _qr(orig_qr, tenpy):
+    def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=False, qtotal_Q=None, inner_qconj=+1):
+        if mode != 'reduced' or cutoff is not None or a.rank != 2:
+            return orig_qr(a, mode, inner_labels, cutoff, pos_diag_R, qtotal_Q, inner_qconj)
+        Q, R = npc.qr(to_device(a), mode='reduced', inner_labels=list(inner_labels), pos_diag_R=pos_diag_R, qtotal_Q=qtotal_Q,
+                      inner_qconj=inner_qconj)
+        memo = {}
+        Qr = to_reference(Q, tenpy, legs=[a.legs[0], leg_to_reference(Q.legs[1], tenpy, memo)])
+        Rr = to_reference(R, tenpy, legs=[Qr.legs[1].conj(), a.legs[1]])
+        return Qr, Rr
+    return qr
+
+
 def install(tenpy):
     """Patch the imported TeNPy package object ``tenpy``.  Raises ``BackendError`` right away without a GPU."""
     dev.lib()                                  # fail loudly if the HIP library / device is missing
@@ -160,12 +184,17 @@ def install(tenpy):
     kb.LanczosGroundState.run = _lanczos_run(kb.LanczosGroundState.run, tenpy)
     _patched['svd'] = (rnpc, rnpc.svd)
     rnpc.svd = _svd(rnpc.svd, tenpy)
+    _patched['eigh'] = (rnpc, rnpc.eigh)           # density-matrix mixer (mps_common.py:2047/2055)
+    rnpc.eigh = _eigh(rnpc.eigh, tenpy)
+    _patched['qr'] = (rnpc, rnpc.qr)               # QR-based truncation / canonical forms (truncation.py:533, mps.py:4556)
+    rnpc.qr = _qr(rnpc.qr, tenpy)
 
 
 def uninstall():
     if 'lanczos' in _patched:
         cls, run = _patched.pop('lanczos')
         cls.run = run
-    if 'svd' in _patched:
-        mod, fn = _patched.pop('svd')
-        mod.svd = fn
+    for name in ('svd', 'eigh', 'qr'):
+        if name in _patched:
+            mod, fn = _patched.pop(name)
+            setattr(mod, name, fn)

@@ -21,9 +21,11 @@ def _run_reference(tenpy, L, chi, n_sweeps, mixer=None):
     M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.2, 'hz': 0.1, 'bc_MPS': 'finite', 'sort_charge': True})
     psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
     eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': mixer, 'combine': True, 'max_N_for_ED': 0,
-                                          'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}})
+                                          'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6 if mixer else 1.e-10}})   # (mixer: see gen_dmrg_mixer)
+    eng.mixer_activate()
     for _ in range(n_sweeps):
         eng.sweep()
+    eng.mixer_cleanup()
     return (np.array(eng.update_stats['E_total']), np.array([e.eps for e in eng.update_stats['err']]),
             [np.array(psi.get_SL(i)) for i in range(1, L)], list(eng.update_stats['N_lanczos']))
 
@@ -101,3 +103,44 @@ def test_array_conversion_round_trip(backend):
             np.testing.assert_array_equal(x, y)
         for lb, la in zip(back.legs, a.legs):
             lb.test_equal(la)
+
+
+def test_plugin_with_mixer_and_qr(backend):
+    """Reference DMRG with the density-matrix mixer (``npc.eigh`` of the mixed density matrices through the plugin) and the
+    reference's ``MPS.canonical_form`` (``npc.qr`` through the plugin) reproduce the un-patched runs."""
+    if backend != 'mock':
+        pytest.skip("reference tree is not on the GPU box")
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        import tenpy
+        from tenpy_amd import plugin
+        E0, err0, S0, N0 = _run_reference(tenpy, 8, 12, 3, mixer=True)
+        import tenpy.linalg.np_conserved as rnpc
+        plugin.install(tenpy)
+        try:
+            calls = {'eigh': 0, 'qr': 0}
+            eigh, qr = rnpc.eigh, rnpc.qr
+
+            def c_eigh(*a, **k):
+                calls['eigh'] += 1
+                return eigh(*a, **k)
+
+            def c_qr(*a, **k):
+                calls['qr'] += 1
+                return qr(*a, **k)
+            rnpc.eigh, rnpc.qr = c_eigh, c_qr
+            E1, err1, S1, N1 = _run_reference(tenpy, 8, 12, 3, mixer=True)
+            from tenpy.models.xxz_chain import XXZChain
+            from tenpy.networks.mps import MPS
+            M = XXZChain({'L': 6, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * 3, bc='finite')
+            psi.canonical_form()
+        finally:
+            plugin.uninstall()
+    assert calls['eigh'] > 0 and calls['qr'] > 0
+    np.testing.assert_allclose(E1, E0, rtol=1e-9, atol=1e-9)
+    for a, b in zip(S1, S0):
+        if np.ndim(a) == 1 and np.ndim(b) == 1:
+            np.testing.assert_allclose(np.sort(a)[::-1], np.sort(b)[::-1], rtol=0, atol=1e-8)
