@@ -1094,7 +1094,43 @@ def gen_idmrg_single():
     save('idmrg_single.pkl', out)
 
 
-GENERATORS = dict(idmrg_single=gen_idmrg_single, mpo_evolution=gen_mpo_evolution, correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
+def gen_hubbard2():
+    """Fermi-Hubbard 2 x 3 ladder (two U(1) charges, fermionic MPO with D = 10): single-site DMRG with subspace expansion and
+    two-site TDVP after a quench."""
+    from tenpy.algorithms import dmrg, tdvp
+    from tenpy.models.hubbard import FermiHubbardModel
+    from tenpy.networks.mps import MPS
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Lx = 3
+        M = FermiHubbardModel({'lattice': 'Ladder', 'L': Lx, 't': 1., 'U': 8., 'mu': 0., 'cons_N': 'N', 'cons_Sz': 'Sz',
+                               'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * Lx, bc='finite')
+        eng = dmrg.SingleSiteDMRGEngine(psi, M, {'combine': True, 'max_N_for_ED': 0, 'mixer': True,
+                                                 'mixer_params': {'amplitude': 1.e-2, 'decay': 2., 'disable_after': 4},
+                                                 'trunc_params': {'chi_max': 24, 'svd_min': 1.e-6}})
+        eng.mixer_activate()
+        Es = []
+        for s_ in range(7):
+            eng.sweep()
+            Es.append(float(eng.update_stats['E_total'][-1]))
+        eng.mixer_cleanup()
+        rec = dict(Lx=Lx, t=1., U=8., mu=0., single_E_sweeps=Es, single_S=np.array(psi.entanglement_entropy()), single_chi=[int(c) for c in psi.chi])
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * Lx, bc='finite')
+        topts = {'dt': 0.02, 'N_steps': 2, 'trunc_params': {'chi_max': 20, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 2, 'N_max': 20}}
+        e2 = tdvp.TwoSiteTDVPEngine(psi, M, dict(topts))
+        steps = []
+        for rep in range(3):
+            e2.run()
+            steps.append(dict(S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], n=np.array(psi.expectation_value('Ntot'))))
+        rec.update(tdvp_options=topts, tdvp_steps=steps)
+        out.append(rec)
+        print('hubbard2', Es[-1], rec['single_chi'], steps[-1]['chi'])
+    save('hubbard2.pkl', out)
+
+
+GENERATORS = dict(hubbard2=gen_hubbard2, idmrg_single=gen_idmrg_single, mpo_evolution=gen_mpo_evolution, correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
                   truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
