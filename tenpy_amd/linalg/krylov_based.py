@@ -332,5 +332,6 @@ def iadd_prefactor_other(w, alpha, v):
 def lanczos(H, psi, options={}, orthogonal_to=[]):
     """Convenience wrapper like the reference's (deprecated) ``lanczos`` function."""
     if len(orthogonal_to):
-        raise NotImplementedError("tenpy_amd: orthogonal_to")
+        from .sparse import OrthogonalNpcLinearOperator
+        H = OrthogonalNpcLinearOperator(H, [v.copy(deep=True) for v in orthogonal_to])
     return LanczosGroundState(H, psi, options).run()

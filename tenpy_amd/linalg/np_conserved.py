@@ -932,9 +932,18 @@ class Array:
         return res
 
     def norm(self, ord=None, convert_to_float=True):
-        """2-norm of the stored entries (one fused pass; ``ord`` other than None/2/'fro' unsupported)."""
+        """``np.linalg.norm(self.to_ndarray().flatten(), ord)`` (reference :2241): the 2-norm in one fused pass of the reduction
+        kernel; the other orders (inf, -inf, 0, 1, any p) as one element-wise reduction over the arena.  The zero entries
+        outside the stored blocks only matter for ``ord=-inf`` (minimum is 0 unless every entry is stored)."""
         if ord not in (None, 2, 'fro'):
-            raise NotImplementedError("tenpy_amd: only the 2-norm is implemented on device")
+            import torch
+            if self.stored_blocks == 0:
+                return 0.
+            flat = self._arena if self._is_packed() else self.copy(deep=True)._repack()._arena
+            val = float(torch.linalg.vector_norm(flat, ord=ord))
+            if ord == -np.inf and flat.numel() < self.size:
+                val = 0.
+            return val
         if self.stored_blocks == 0:
             return 0.
         if self._is_packed():

@@ -350,8 +350,27 @@ class MPS:
 
     def overlap(self, other):
         """``<self|other>`` including the norms of both states (reference ``MPS.overlap`` for finite MPS)."""
-        if not (self.finite and other.finite):
-            raise NotImplementedError("tenpy_amd: overlap of infinite MPS (transfer-matrix eigenvalue) is not implemented")
+        if self.finite != other.finite:
+            raise ValueError("can't take overlap between MPS with different bc")
+        if not self.finite:
+            # per unit cell: the dominant eigenvalue of the mixed transfer matrix in the zero-charge sector (reference :4278)
+            from ..linalg.krylov_based import Arnoldi
+            if self.L != other.L:
+                raise NotImplementedError("tenpy_amd: overlap of infinite MPS with different unit cells")
+            Ns = [self.get_B(i, 'B') for i in range(self.L)]
+            Ms = [other.get_B(i, 'B') for i in range(self.L)]
+            TM = TransferMatrix(Ns, Ms, transpose=False)
+            leg_ket, leg_bra = Ms[-1].get_leg('vR'), Ns[-1].get_leg('vR')
+            guess = npc.ones([leg_ket.conj(), leg_bra], dtype=np.result_type(self.dtype, other.dtype), labels=['vL', 'vL*'])
+            if guess.stored_blocks == 0:
+                return 0.
+            val = None
+            for _ in range(10):
+                vals, vecs, N = Arnoldi(TM, guess, dict(N_min=2, N_max=30, P_tol=1.e-24, which='LM')).run()
+                val, guess = vals[0], vecs[0]
+                if N < 30:
+                    break
+            return val * self.norm * other.norm
         ov = MPSEnvironment(self, other).full_contraction(max(self.L // 2 - 1, 0))
         return ov * self.norm * other.norm
 

@@ -935,8 +935,13 @@ def gen_canonical_form_infinite():
                 Bs_in.append(dump_array(Bn.transpose(['vL', 'p', 'vR'])))
             S_in = [np.array(psi.get_SL(i)) for i in range(L)]
             err_in = np.array(psi.norm_test())
+            psi_before = psi.copy()
             psi.canonical_form()
-            out.append(dict(L=L, cplx=cplx, B_in=Bs_in, S_in=S_in, err_in=err_in, err_out=np.array(psi.norm_test()),
+            import warnings as _w
+            ov_self = complex(psi.overlap(psi, understood_infinite=True))
+            other = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
+            ov_prod = complex(psi.overlap(other, understood_infinite=True))
+            out.append(dict(L=L, cplx=cplx, ov_self=ov_self, ov_prod=ov_prod, norm=float(psi.norm), B_in=Bs_in, S_in=S_in, err_in=err_in, err_out=np.array(psi.norm_test()),
                             S_out=[np.array(psi.get_SL(i)) for i in range(L)], S_ent=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
                             Sz=np.array(psi.expectation_value('Sz'))))
             print('canonical_form_infinite', cplx, np.linalg.norm(err_in), np.linalg.norm(out[-1]['err_out']), out[-1]['chi'], out[-1]['S_ent'])

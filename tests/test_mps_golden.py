@@ -42,6 +42,12 @@ def test_canonical_form_infinite(backend):
             np.testing.assert_allclose(np.sort(psi.get_SL(i))[::-1], np.sort(rec['S_out'][i])[::-1], rtol=0, atol=1e-10)
         np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-10)
         np.testing.assert_allclose(psi.expectation_value(np.diag([-0.5, 0.5])), rec['Sz'], rtol=0, atol=1e-10)
+        # overlap per unit cell = dominant eigenvalue of the (mixed) transfer matrix
+        psi.norm = rec['norm']              # (the reference state carries the norm accumulated by its time evolution)
+        assert abs(psi.overlap(psi) - rec['ov_self']) < 1e-10 * abs(rec['ov_self'])
+        p = Bs[0].get_leg('p')
+        other = MPS.from_product_state([p] * L, [1, 0], dtype=psi.dtype, bc='infinite')
+        assert abs(abs(psi.overlap(other)) - abs(rec['ov_prod'])) < 1e-10 * max(1., abs(rec['ov_prod']))
 
 
 def test_correlation_function(backend):

@@ -50,6 +50,8 @@ def test_tensordot_inner_outer_random(backend, mod, cplx):
         o = npc.outer(_rand(rng, [la], cplx), _rand(rng, [ld], False))
         o.test_sanity()
         assert abs(npc.norm(a) - np.linalg.norm(A)) < 1e-12
+        for o in (np.inf, 1, 3, 0, -np.inf):
+            assert abs(npc.norm(a, o) - np.linalg.norm(A.reshape(-1), o)) < 1e-11 * max(1., np.linalg.norm(A.reshape(-1), o))
 
 
 @pytest.mark.parametrize("mod,cplx", CASES)
