@@ -43,6 +43,18 @@ def timeit(f, reps=5):
 
 
 tp = {'chi_max': chi, 'svd_min': 1.e-14}
+if os.environ.get('SVD_ALG'):       # e.g. SVD_ALG=1024: predicted convergence; compare singular values / orthogonality with the default
+    from tenpy_amd import _lib
+    U0, S0, V0 = npc.svd(theta, inner_labels=['vR', 'vL'])
+    _lib.load().tpa_svd_set_algorithm(int(os.environ['SVD_ALG']))
+    npc.svd_stats.update(calls=0, sweeps=0)
+    U1, S1, V1 = npc.svd(theta, inner_labels=['vR', 'vL'])
+    u = U1.to_ndarray()
+    keep = S1 > 1e-6 * S1.max()
+    print("SVD_ALG=%s: sweeps %d, max |S - S_default| = %.2e, |U^T U - 1| (sigma > 1e-6) = %.2e, |U S V - theta| = %.2e"
+          % (os.environ['SVD_ALG'], npc.svd_stats['sweeps'], np.abs(S1 - S0).max(),
+             np.abs(u[:, keep].conj().T @ u[:, keep] - np.eye(keep.sum())).max(),
+             np.abs((u * S1) @ V1.to_ndarray() - theta.to_ndarray()).max()), flush=True)
 t_theta = timeit(lambda: svd_theta(theta, tp, qtotal_LR=[psi.get_B(i0, None).qtotal, None], inner_labels=['vR', 'vL']))
 t_svd = timeit(lambda: npc.svd(theta, inner_labels=['vR', 'vL']))
 import cProfile, pstats
