@@ -102,3 +102,4 @@ def check(rc, what=""):
 
 c_int = ctypes.c_int
 byref = ctypes.byref
+E_NOCONV, E_NAN = _lib.E_NOCONV, _lib.E_NAN

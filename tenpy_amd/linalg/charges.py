@@ -10,7 +10,7 @@ import copy as _copy
 
 import numpy as np
 
-__all__ = ['ChargeInfo', 'LegCharge', 'LegPipe', 'QTYPE']
+__all__ = ['ChargeInfo', 'DipolarChargeInfo', 'LegCharge', 'LegPipe', 'QTYPE']
 
 QTYPE = np.int64  # reference charges.py:36 / _npc_helper.pyx:77
 
@@ -27,6 +27,8 @@ class ChargeInfo:
     Same semantics as the reference (charges.py:39-372): ``make_valid`` reduces charges with a
     non-negative (python-style) modulo where ``mod != 1``; ``check_valid`` tests that.
     """
+
+    trivial_shift = True       # translations act trivially on these charges (reference charges.py:82)
 
     def __init__(self, mod=[], names=None):
         mod = np.array(mod, dtype=QTYPE).reshape(-1)
@@ -56,6 +58,38 @@ class ChargeInfo:
         drop = [chinfo.names.index(c) if isinstance(c, str) else int(c) for c in charge]
         keep = [i for i in range(chinfo.qnumber) if i not in drop]
         return cls([chinfo.mod[i] for i in keep], [chinfo.names[i] for i in keep])
+
+    @classmethod
+    def change(cls, chinfo, charge, new_qmod, new_name=''):
+        """Same charges, but charge number / name ``charge`` gets modulus ``new_qmod`` (reference :215)."""
+        idx = chinfo.names.index(charge) if isinstance(charge, str) else int(charge)
+        mod = np.array(chinfo.mod, dtype=QTYPE)
+        mod[idx] = new_qmod
+        names = list(chinfo.names)
+        names[idx] = new_name
+        return cls(mod, names)
+
+    def shift_charges(self, charges, dx):
+        """Action of a lattice translation by ``dx`` on charge values: none for ordinary charges (reference :306)."""
+        return charges
+
+    def shift_charges_horizontal(self, charges, dx_0):
+        return charges
+
+    def save_hdf5(self, hdf5_saver, h5gr, subpath):
+        """HDF5 layout of the reference (charges.py:111): attribute ``num_charges``, datasets ``U1_ZN`` and ``names``."""
+        h5gr.attrs['num_charges'] = self._qnumber
+        hdf5_saver.save(self._mod, subpath + 'U1_ZN')
+        hdf5_saver.save(self.names, subpath + 'names')
+
+    @classmethod
+    def from_hdf5(cls, hdf5_loader, h5gr, subpath):
+        obj = cls.__new__(cls)
+        hdf5_loader.memorize_load(h5gr, obj)
+        mod = np.asarray(hdf5_loader.load(subpath + 'U1_ZN'), dtype=QTYPE)
+        names = hdf5_loader.load(subpath + 'names') if 'names' in h5gr else [''] * len(mod)
+        obj.__setstate__((len(mod), mod, names))
+        return obj
 
     def test_sanity(self):
         if self._mod.ndim != 1 or len(self.names) != self._qnumber:
@@ -108,7 +142,105 @@ class ChargeInfo:
 
     def __setstate__(self, state):
         qnumber, mod, names = state
-        self.__init__(mod, names)
+        ChargeInfo.__init__(self, mod, names)
+
+
+def _is_subgroup_by_qmod(qmod1, qmod2):
+    """Whether the group with modulus ``qmod1`` (1 = U(1)) is a subgroup of the one with ``qmod2`` (reference :1887)."""
+    if qmod2 == 1:
+        return True
+    return qmod1 != 1 and qmod2 % qmod1 == 0
+
+
+class DipolarChargeInfo(ChargeInfo):
+    """ChargeInfo in which some charges are dipole moments ``p = x * q`` of other charges (reference :375-549).
+
+    Host-side integer bookkeeping only; what differs from :class:`ChargeInfo` is how charge values move under a
+    lattice translation: ``p -> p + dx[dim] * q`` for every (charge, dipole, dim) triple.
+    """
+
+    trivial_shift = False
+
+    def __init__(self, mod=[], names=None, charge_idcs=[], dipole_idcs=[], dipole_dims=None):
+        charge_idcs, dipole_idcs = list(charge_idcs), list(dipole_idcs)
+        dipole_dims = [0] * len(dipole_idcs) if dipole_dims is None else list(dipole_dims)
+        nq = len(mod)
+        for what, idcs in (('charge_idcs', charge_idcs), ('dipole_idcs', dipole_idcs)):
+            for n, i in enumerate(idcs):
+                if not 0 <= i < nq:
+                    raise ValueError("{0}[{1:d}] out of bounds".format(what, n))
+        if set(charge_idcs) & set(dipole_idcs):
+            raise ValueError("dipole_idcs and charge_idcs must be disjoint.")
+        for ci, di, dim in zip(charge_idcs, dipole_idcs, dipole_dims):
+            if dim > 0 and mod[di] == 1:
+                raise ValueError("Can not conserve U(1) dipole charge (qmod==1) along dipole_dim > 0.")
+            if not _is_subgroup_by_qmod(mod[di], mod[ci]):
+                raise ValueError("Dipole charge can not have qmod={0} if underlying charge has qmod={1}. "
+                                 "(Not a subgroup)".format(mod[di], mod[ci]))
+        self._charge_idcs, self._dipole_idcs, self._dipole_dims = charge_idcs, dipole_idcs, dipole_dims
+        ChargeInfo.__init__(self, mod, names)
+
+    def _triples(self):
+        return zip(self._charge_idcs, self._dipole_idcs, self._dipole_dims)
+
+    def shift_charges(self, charges, dx):
+        if dx[-1] != 0:
+            raise NotImplementedError("translation between different sites of the unit cell")
+        res = np.array(charges, dtype=QTYPE)
+        for ci, di, dim in self._triples():
+            res[..., di] += dx[dim] * res[..., ci]
+        return self.make_valid(res)
+
+    def shift_charges_horizontal(self, charges, dx_0):
+        res = np.array(charges, dtype=QTYPE)
+        for ci, di, dim in self._triples():
+            if dim == 0:
+                res[..., di] += dx_0 * res[..., ci]
+        return self.make_valid(res)
+
+    def test_sanity(self):
+        n = len(self._charge_idcs)
+        if len(self._dipole_idcs) != n or len(self._dipole_dims) != n:
+            raise ValueError("dipole_idcs / dipole_dims have wrong length")
+        if len(set(self._dipole_idcs)) != n:
+            raise ValueError("duplicates in dipole_idcs")
+        ChargeInfo.test_sanity(self)
+
+    def __repr__(self):
+        return "DipolarChargeInfo({0!s}, {1!s}, {2!s}, {3!s}, {4!s})".format(
+            list(self.mod), self.names, self._charge_idcs, self._dipole_idcs, self._dipole_dims)
+
+    def __eq__(self, other):
+        if self is other:
+            return True
+        if not isinstance(other, DipolarChargeInfo):
+            return False
+        return ChargeInfo.__eq__(self, other) is True and \
+            (self._charge_idcs, self._dipole_idcs, self._dipole_dims) == \
+            (other._charge_idcs, other._dipole_idcs, other._dipole_dims)
+
+    def __getstate__(self):
+        return (ChargeInfo.__getstate__(self), (self._charge_idcs, self._dipole_idcs, self._dipole_dims))
+
+    def __setstate__(self, state):
+        base, (self._charge_idcs, self._dipole_idcs, self._dipole_dims) = state
+        ChargeInfo.__setstate__(self, base)
+
+    def save_hdf5(self, hdf5_saver, h5gr, subpath):
+        ChargeInfo.save_hdf5(self, hdf5_saver, h5gr, subpath)
+        for key in ('charge_idcs', 'dipole_idcs', 'dipole_dims'):
+            hdf5_saver.save(getattr(self, '_' + key), subpath + key)
+
+    @classmethod
+    def from_hdf5(cls, hdf5_loader, h5gr, subpath):
+        obj = cls.__new__(cls)
+        hdf5_loader.memorize_load(h5gr, obj)
+        mod = np.asarray(hdf5_loader.load(subpath + 'U1_ZN'), dtype=QTYPE)
+        names = hdf5_loader.load(subpath + 'names') if 'names' in h5gr else [''] * len(mod)
+        rest = tuple(hdf5_loader.load(subpath + key) for key in ('charge_idcs', 'dipole_idcs', 'dipole_dims'))
+        obj.__setstate__(((len(mod), mod, names), rest))
+        obj.test_sanity()
+        return obj
 
 
 class LegCharge:
@@ -178,6 +310,113 @@ class LegCharge:
         res.bunched = res.is_bunched()
         return res
 
+    @classmethod
+    def from_add_charge(cls, legs, chargeinfo=None):
+        """Leg carrying the charges of all ``legs`` side by side (reference :843): the block boundaries are the union
+        of the boundaries of the given legs; neither sorted nor bunched."""
+        legs = list(legs)
+        chinfo = ChargeInfo.add([leg.chinfo for leg in legs])
+        if chargeinfo is not None:
+            assert chinfo == chargeinfo
+            chinfo = chargeinfo
+        if any(leg.ind_len != legs[0].ind_len for leg in legs):
+            raise ValueError("different length")
+        if any(leg.qconj != legs[0].qconj for leg in legs):
+            raise ValueError("different qconj")
+        ind_len = legs[0].ind_len
+        ptr = [0] * len(legs)                       # current block of every leg
+        cuts, rows = [0], []
+        while True:
+            rows.append(np.concatenate([leg.charges[q] for leg, q in zip(legs, ptr)]) if legs[0].chinfo is not None else [])
+            ends = [int(leg.slices[q + 1]) for leg, q in zip(legs, ptr)]
+            cut = min(ends)
+            if cut >= ind_len:
+                break
+            ptr = [q + 1 if e == cut else q for q, e in zip(ptr, ends)]
+            cuts.append(cut)
+        cuts.append(ind_len)
+        return cls.from_qind(chinfo, cuts, np.array(rows, dtype=QTYPE).reshape(len(rows), chinfo.qnumber), legs[0].qconj)
+
+    @classmethod
+    def from_drop_charge(cls, leg, charge=None, chargeinfo=None):
+        """Leg without charge number / name ``charge`` (``None``: without any charge), reference :896."""
+        if charge is None:
+            return cls.from_trivial(leg.ind_len, chargeinfo, leg.qconj)
+        chinfo = ChargeInfo.drop(leg.chinfo, charge)
+        if chargeinfo is not None:
+            assert chinfo == chargeinfo
+            chinfo = chargeinfo
+        idx = leg.chinfo.names.index(charge) if isinstance(charge, str) else int(charge)
+        return cls.from_qind(chinfo, leg.slices, np.delete(leg.charges, idx, axis=1), leg.qconj)
+
+    @classmethod
+    def from_change_charge(cls, leg, charge, new_qmod, new_name='', chargeinfo=None):
+        """Leg whose charge ``charge`` is taken modulo ``new_qmod`` instead (reference :926)."""
+        chinfo = ChargeInfo.change(leg.chinfo, charge, new_qmod, new_name)
+        if chargeinfo is not None:
+            assert chinfo == chargeinfo
+            chinfo = chargeinfo
+        return cls.from_qind(chinfo, leg.slices, chinfo.make_valid(leg.charges), leg.qconj)
+
+    def apply_charge_mapping(self, map_func, func_args=(), func_kwargs={}):
+        """Shallow copy with ``charges = map_func(charges, ...)`` (reference :1010)."""
+        res = self.copy()
+        res.charges = map_func(self.charges, *func_args, **func_kwargs)
+        res.sorted = res.bunched = False
+        return res
+
+    def _slice_start_stop(self):
+        return zip(self.slices[:-1], self.slices[1:])
+
+    # ---- HDF5 (layout of the reference, charges.py:649-755) -------------------------------------------------
+    def save_hdf5(self, hdf5_saver, h5gr, subpath):
+        fmt = hdf5_saver.format_selection.get('LegCharge', 'blocks')
+        h5gr.attrs['format'] = fmt
+        h5gr.attrs['ind_len'] = self.ind_len
+        h5gr.attrs['qconj'] = self.qconj
+        hdf5_saver.save(self.chinfo, subpath + 'chinfo')
+        if fmt in ('blocks', 'compact'):
+            for key in ('block_number', 'sorted', 'bunched'):
+                h5gr.attrs[key] = getattr(self, key)
+            if fmt == 'blocks':
+                hdf5_saver.save(self.slices, subpath + 'slices')
+                hdf5_saver.save(self.charges, subpath + 'charges')
+            else:
+                table = np.hstack([self.slices[:-1, np.newaxis], self.slices[1:, np.newaxis], self.charges])
+                hdf5_saver.save(table, subpath + 'blockcharges')
+        elif fmt == 'flat':
+            hdf5_saver.save(self.to_qflat(), subpath + 'charges')
+        else:
+            raise ValueError("Unknown format")
+
+    @classmethod
+    def from_hdf5(cls, hdf5_loader, h5gr, subpath):
+        obj = cls.__new__(cls)
+        hdf5_loader.memorize_load(h5gr, obj)
+        fmt = hdf5_loader.get_attr(h5gr, 'format')
+        ind_len = hdf5_loader.get_attr(h5gr, 'ind_len')
+        qconj = hdf5_loader.get_attr(h5gr, 'qconj')
+        chinfo = hdf5_loader.load(subpath + 'chinfo')
+        if fmt == 'flat':
+            charges = np.asarray(hdf5_loader.load(subpath + 'charges'), dtype=QTYPE)
+            obj.__setstate__((ind_len, ind_len, chinfo, np.arange(ind_len + 1, dtype=np.intp), charges, qconj, False, False))
+            obj.sorted, obj.bunched = obj.is_sorted(), obj.is_bunched()
+        elif fmt in ('blocks', 'compact'):
+            nblk = hdf5_loader.get_attr(h5gr, 'block_number')
+            flags = [hdf5_loader.get_attr(h5gr, key) for key in ('sorted', 'bunched')]
+            if fmt == 'blocks':
+                slices = np.asarray(hdf5_loader.load(subpath + 'slices'), dtype=np.intp)
+                charges = np.asarray(hdf5_loader.load(subpath + 'charges'), dtype=QTYPE)
+            else:
+                table = hdf5_loader.load(subpath + 'blockcharges')
+                slices = np.concatenate([table[:, 0], table[-1:, 1]]).astype(np.intp)
+                charges = np.ascontiguousarray(table[:, 2:], dtype=QTYPE)
+            obj.__setstate__((ind_len, nblk, chinfo, slices, charges.reshape(nblk, -1), qconj, flags[0], flags[1]))
+        else:
+            raise ValueError("Unknown format")
+        obj.test_sanity()
+        return obj
+
     # ---- checks ------------------------------------------------------------------------------------
     def test_sanity(self):
         sl, ch = self.slices, self.charges
@@ -230,28 +469,30 @@ class LegCharge:
     def is_bunched(self):
         return len(_find_row_differences(self.charges)) == self.block_number + 1
 
+    def _same_charges(self, other, sign):
+        """``self.charges * self.qconj == sign * other.charges * other.qconj`` modulo the moduli of the charges."""
+        if self.charges is other.charges and self.qconj == sign * other.qconj and \
+                (self.slices is other.slices or np.array_equal(self.slices, other.slices)):
+            return True
+        if self.block_number != other.block_number or not np.array_equal(self.slices, other.slices):
+            return False
+        mv = self.chinfo.make_valid
+        return bool(np.array_equal(mv(self.charges * self.qconj), mv(other.charges * (sign * other.qconj))))
+
     def test_contractible(self, other):
-        """Raise ValueError unless ``self`` can be contracted with ``other`` (reference :1071)."""
+        """Raise ValueError unless ``self`` can be contracted with ``other``: equal ChargeInfo and slices, charges equal
+        up to the opposite sign convention (reference :1071)."""
         if self.chinfo != other.chinfo:
             raise ValueError(''.join(["incompatible ChargeInfo\n", str(self.chinfo), str(other.chinfo)]))
-        if self.charges is other.charges and self.qconj == -other.qconj and \
-                (self.slices is other.slices or np.array_equal(self.slices, other.slices)):
-            return
-        if self.qconj != -other.qconj:
-            raise ValueError("incompatible LegCharge: qconj must be opposite\n" + str(self) + "\n" + str(other))
-        if self.block_number != other.block_number or not np.array_equal(self.slices, other.slices) or \
-                not np.array_equal(self.charges, other.charges):
-            raise ValueError("incompatible LegCharge: different charges/slices\n" + str(self) + "\n" + str(other))
+        if not self._same_charges(other, -1):
+            raise ValueError("incompatible LegCharge\nself\n" + str(self) + "\nother (conjugated)\n" + str(other.conj()))
 
     def test_equal(self, other):
+        """Raise ValueError unless slices and charges (with ``qconj``, modulo the charge moduli) agree (reference :1114)."""
         if self.chinfo != other.chinfo:
             raise ValueError(''.join(["incompatible ChargeInfo\n", str(self.chinfo), str(other.chinfo)]))
-        if self.charges is other.charges and self.qconj == other.qconj and \
-                (self.slices is other.slices or np.array_equal(self.slices, other.slices)):
-            return
-        if not np.array_equal(self.slices, other.slices) or \
-                not np.array_equal(self.charges * self.qconj, other.charges * other.qconj):
-            raise ValueError("incompatible LegCharge\n" + str(self) + "\n" + str(other))
+        if not self._same_charges(other, +1):
+            raise ValueError("incompatible LegCharge\nself\n" + str(self) + "\nother\n" + str(other))
 
     def __eq__(self, other):
         if self is other:
@@ -500,6 +741,30 @@ class LegPipe(LegCharge):
         if any(l.chinfo != self.chinfo for l in self.legs):
             raise ValueError("leg with different ChargeInfo")
 
+    def copy(self):
+        res = _copy.copy(self)
+        res._bsizes = None
+        return res
+
+    def apply_charge_mapping(self, map_func, func_args=(), func_kwargs={}):
+        res = self.copy()
+        res.legs = tuple(l.apply_charge_mapping(map_func, func_args, func_kwargs) for l in self.legs)
+        res.charges = map_func(self.charges, *func_args, **func_kwargs)
+        res.sorted = res.bunched = False
+        return res
+
+    def save_hdf5(self, hdf5_saver, h5gr, subpath):
+        """The reference's layout (charges.py:1598): the LegCharge fields plus the incoming ``legs``."""
+        LegCharge.save_hdf5(self, hdf5_saver, h5gr, subpath)
+        hdf5_saver.save(list(self.legs), subpath + 'legs')
+
+    @classmethod
+    def from_hdf5(cls, hdf5_loader, h5gr, subpath):
+        flags = [hdf5_loader.get_attr(h5gr, key) for key in ('sorted', 'bunched')]
+        obj = cls(hdf5_loader.load(subpath + 'legs'), hdf5_loader.get_attr(h5gr, 'qconj'), flags[0], flags[1])
+        hdf5_loader.memorize_load(h5gr, obj)
+        return obj
+
     def to_LegCharge(self):
         res = LegCharge(self.chinfo, self.slices, self.charges, self.qconj)
         res.sorted, res.bunched = self.sorted, self.bunched
@@ -606,3 +871,19 @@ def _make_stride(shape, cstyle=True):
         res[a] = stride
         stride *= shape[a]
     return res
+
+
+def _map_blocks(blocksizes):
+    """For blocks of the given sizes laid out one after the other: the block number of every index (reference :1945)."""
+    return np.repeat(np.arange(len(blocksizes), dtype=np.intp), np.asarray(blocksizes, dtype=np.intp))
+
+
+def _sliced_copy(dest, dest_beg, src, src_beg, slice_shape):
+    """``dest[dest_beg : dest_beg + slice_shape] = src[src_beg : src_beg + slice_shape]`` on host arrays
+    (reference :1956; the device twin is ``tpa_copy_batch``)."""
+    nd = dest.ndim
+    dest_beg = [0] * nd if dest_beg is None else dest_beg
+    src_beg = [0] * nd if src_beg is None else src_beg
+    assert src.ndim == nd == len(dest_beg) == len(src_beg) == len(slice_shape)
+    dest[tuple(slice(b, b + n) for b, n in zip(dest_beg, slice_shape))] = \
+        src[tuple(slice(b, b + n) for b, n in zip(src_beg, slice_shape))]

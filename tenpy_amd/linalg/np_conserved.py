@@ -21,11 +21,12 @@ from collections import OrderedDict
 import numpy as np
 
 from . import _device as dev
-from .charges import ChargeInfo, LegCharge, LegPipe, _find_row_differences, _partial_qtotal
+from .charges import QTYPE, ChargeInfo, DipolarChargeInfo, LegCharge, LegPipe, _find_row_differences, _partial_qtotal
 
-__all__ = ['lq', 'eigvalsh', 'QCUTOFF', 'ChargeInfo', 'LegCharge', 'LegPipe', 'Array', 'zeros', 'eye_like', 'diag', 'outer', 'inner',
-           'tensordot', 'svd', 'qr', 'eigh', 'norm', 'trace', 'to_iterable_arrays', 'TensordotPlan', 'ones', 'concatenate',
-           'expm', 'pinv', 'polar']
+__all__ = ['QCUTOFF', 'ChargeInfo', 'DipolarChargeInfo', 'LegCharge', 'LegPipe', 'Array', 'zeros', 'ones', 'eye_like', 'diag',
+           'concatenate', 'grid_concat', 'grid_outer', 'detect_grid_outer_legcharge', 'detect_qtotal', 'detect_legcharge',
+           'trace', 'outer', 'inner', 'tensordot', 'svd', 'pinv', 'norm', 'eigh', 'eig', 'eigvalsh', 'eigvals', 'speigs',
+           'expm', 'qr', 'lq', 'polar', 'orthogonal_columns', 'to_iterable_arrays', 'TensordotPlan']
 
 QCUTOFF = np.finfo(np.float64).eps * 10
 
@@ -45,6 +46,40 @@ def _is_iterable(x):
 
 def _to_iterable(x):
     return list(x) if _is_iterable(x) else [x]
+
+
+class _HostBlockList(list):
+    """What ``Array._data`` returns: a list of host blocks that remembers its Array, so that *mutating* the list
+    (``append``, item assignment, ...) registers the blocks for upload; reading it costs nothing extra."""
+
+    def __init__(self, owner, blocks, dirty=False):
+        list.__init__(self, blocks)
+        self._owner = owner
+        if dirty:
+            owner.__dict__['_host_blocks'] = self
+
+    def _touch(self):
+        self._owner.__dict__['_host_blocks'] = self
+        self._owner._skey = None
+
+    def append(self, blk):
+        list.append(self, blk)
+        self._touch()
+
+    def extend(self, blks):
+        list.extend(self, blks)
+        self._touch()
+
+    def insert(self, i, blk):
+        list.insert(self, i, blk)
+        self._touch()
+
+    def __setitem__(self, i, blk):
+        list.__setitem__(self, i, blk)
+        self._touch()
+
+    def __reduce__(self):
+        return (list, (list(self),))
 
 
 class Array:
@@ -142,15 +177,68 @@ class Array:
         return (self._qdata.shape == other._qdata.shape and np.array_equal(self._qdata, other._qdata)
                 and np.array_equal(self._offsets, other._offsets))
 
+    # ---- block storage: one arena in HBM; ``_data`` is the reference's host-side view of it ---------------------------
+    @property
+    def _arena(self):
+        """1-D device tensor holding all stored blocks.  If host blocks were assigned through ``_data`` (see below) they
+        are uploaded here, on first use."""
+        if self.__dict__.get('_host_blocks') is not None:
+            self._upload_host_blocks()
+        return self.__dict__.get('_arena_t')
+
+    @_arena.setter
+    def _arena(self, tensor):
+        self.__dict__['_arena_t'] = tensor
+        self.__dict__['_host_blocks'] = None
+
+    @property
+    def _offsets(self):
+        """int64 start of every stored block inside the arena (row order of ``_qdata``)."""
+        if self.__dict__.get('_host_blocks') is not None:
+            self._upload_host_blocks()
+        return self.__dict__['_offsets_v']
+
+    @_offsets.setter
+    def _offsets(self, offs):
+        self.__dict__['_offsets_v'] = offs
+
     @property
     def _data(self):
-        """Host copies of the blocks (list of numpy arrays) -- for tests and debugging only."""
-        if self.stored_blocks == 0:
-            return []
+        """The reference's ``_data``: list of the stored blocks as numpy arrays, in the order of ``_qdata`` -- here host
+        COPIES of the arena (tests, ``__iter__``, HDF5, and the few reference callers that read blocks directly:
+        ``linalg/sparse.py:549-560``, ``linalg/truncation.py:456``).  Assigning a list of host arrays (``a._data = [...]``,
+        ``linalg/sparse.py:511``) or appending to the list of an empty Array (``sparse.py:523``) is honoured too: the
+        blocks are uploaded when the arena is next needed, laid out in the order of the ``_qdata`` valid at that time."""
+        pending = self.__dict__.get('_host_blocks')
+        if pending is not None:
+            return pending
+        if self.stored_blocks == 0 or self.__dict__.get('_arena_t') is None:
+            return _HostBlockList(self, [])
         host = dev.to_host(self._arena)
         shapes = self._block_shapes()
         sizes = np.prod(shapes, axis=1)
-        return [host[o:o + s].reshape(tuple(sh)) for o, s, sh in zip(self._offsets, sizes, shapes)]
+        return _HostBlockList(self, [host[o:o + s].reshape(tuple(sh)) for o, s, sh in zip(self._offsets, sizes, shapes)])
+
+    @_data.setter
+    def _data(self, blocks):
+        self.__dict__['_host_blocks'] = _HostBlockList(self, list(blocks), dirty=True)
+        self._skey = None
+
+    def _upload_host_blocks(self):
+        blocks = list(self.__dict__['_host_blocks'])
+        self.__dict__['_host_blocks'] = None
+        if len(blocks) != self._qdata.shape[0]:
+            raise ValueError("len(_data) = %d does not match the %d rows of _qdata" % (len(blocks), self._qdata.shape[0]))
+        if any(np.asarray(b).dtype.kind == 'c' for b in blocks) and self.dtype.kind != 'c':
+            self.dtype = np.dtype(np.complex128)
+        sizes = np.array([np.asarray(b).size for b in blocks], dtype=np.int64)
+        self._offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(blocks) else np.zeros(0, np.int64)
+        flat = np.concatenate([np.ascontiguousarray(b, dtype=self.dtype).reshape(-1) for b in blocks]) if len(blocks) \
+            else np.zeros(0, self.dtype)
+        self.__dict__['_arena_t'] = dev.to_device(flat)
+        self._skey = None
+        self.__dict__.pop('_sz_cache', None)
+        self.__dict__.pop('_pk_cache', None)
 
     # ---- sanity ------------------------------------------------------------------------------------
     def test_sanity(self):
@@ -183,6 +271,7 @@ class Array:
     # ---- copies ------------------------------------------------------------------------------------
     def copy(self, deep=True):
         res = Array.__new__(Array)
+        self._arena                 # (uploads blocks assigned through `_data`, if any, before the fields are shared)
         res.__dict__.update(self.__dict__)
         res.legs = list(self.legs)
         res._labels = list(self._labels)
@@ -306,17 +395,19 @@ class Array:
 
     # ---- labels --------------------------------------------------------------------------------------
     def get_leg_index(self, label):
-        if isinstance(label, str):
-            try:
-                return self._labels.index(label)
-            except ValueError:
-                raise KeyError("label not found: " + repr(label) + ", current labels" + repr(self._labels)) from None
-        label = int(label)
-        if label < 0:
-            label += self.rank
-        if label < 0 or label >= self.rank:
-            raise ValueError("axis {0:d} out of rank {1:d}".format(label, self.rank))
-        return label
+        """Leg index for a leg index (negative counts from the end) or a label; anything that is not an integer is looked
+        up among the labels, so ``None`` finds the first unlabeled leg (reference :683)."""
+        if isinstance(label, (int, np.integer)) and not isinstance(label, bool):
+            idx = int(label)
+            if idx < 0:
+                idx += self.rank
+            if idx < 0 or idx >= self.rank:
+                raise ValueError("axis {0:d} out of rank {1:d}".format(int(label), self.rank))
+            return idx
+        try:
+            return self._labels.index(label)
+        except ValueError:
+            raise KeyError("label not found: " + repr(label) + ", current labels" + repr(self._labels)) from None
 
     def get_leg_indices(self, labels):
         return [self.get_leg_index(l) for l in labels]
@@ -413,8 +504,12 @@ class Array:
         return dev.to_host(self._arena[int(self._offsets[i]):int(self._offsets[i]) + n]).reshape(sh)
 
     def __getstate__(self):
+        arena = self._arena
         state = dict(self.__dict__)
-        state['_arena'] = None if self._arena is None else dev.to_host(self._arena)
+        state.pop('_arena_t', None)
+        state['_offsets'] = state.pop('_offsets_v')
+        state.pop('_host_blocks', None)
+        state['_arena'] = None if arena is None else dev.to_host(arena)
         state['_skey'] = None
         state.pop('_sz_cache', None)
         state.pop('_pk_cache', None)
@@ -422,7 +517,9 @@ class Array:
 
     def __setstate__(self, state):
         arena = state.pop('_arena')
+        offs = state.pop('_offsets')
         self.__dict__.update(state)
+        self._offsets = offs
         self._arena = None if arena is None else dev.to_device(arena)
 
     # ---- leg structure ---------------------------------------------------------------------------------------
@@ -858,9 +955,13 @@ class Array:
         return self.itranspose(axes)
 
     def _transpose_same_labels(self, other_labels):
-        if self._labels == list(other_labels):
+        """``self`` with its legs in the order of ``other_labels`` if both carry the same complete set of labels."""
+        other_labels = list(other_labels)
+        if self._labels == other_labels or None in self._labels or None in other_labels:
             return self
-        return self.transpose(list(other_labels))
+        if set(self._labels) == set(other_labels):
+            return self.transpose(other_labels)
+        return self
 
     # ---- elementwise / scaling -------------------------------------------------------------------------------------
     def iscale_axis(self, s, axis=-1):
@@ -892,6 +993,7 @@ class Array:
         return self.copy(deep=True).iscale_axis(s, axis)
 
     def _become(self, other):
+        other._arena
         self.__dict__.update(other.__dict__)
 
     def astype(self, dtype, copy=True):
@@ -1011,6 +1113,7 @@ class Array:
 
     def iadd_prefactor_other(self, prefactor, other):
         """``self += prefactor * other`` (reference :2372 / _npc_helper.pyx:860)."""
+        other = other._transpose_same_labels(self._labels)
         if self.rank != other.rank:
             raise ValueError("different rank!")
         for self_leg, other_leg in zip(self.legs, other.legs):
@@ -1099,8 +1202,9 @@ class Array:
         """Keep only the indices selected by ``mask`` (bool or index array) on the given ``axes``
         (reference :1914).  Returns ``(map_qind, block_masks)`` lists per axis; ``self`` is modified."""
         axes = self.get_leg_indices(_to_iterable(axes))
-        mask = list(mask) if _is_iterable(mask) and len(axes) > 1 and _is_iterable(mask[0]) else \
-            ([mask] if len(axes) == 1 else list(mask))
+        mask = list(mask)
+        if len(mask) == 0 or not _is_iterable(mask[0]):       # a single mask, not a list of masks
+            mask = [mask]
         if len(axes) != len(mask):
             raise ValueError("len(axes) != len(mask)")
         masks = []
@@ -1488,8 +1592,8 @@ def expm(a):
     """Matrix exponential of a square block-diagonal matrix (reference :4103, which runs scipy's Pade ``expm`` block by block on the host).
 
     Device version: scaling and squaring with a Taylor polynomial, all in block GEMMs -- ``X = a / 2**s`` with
-    ``||X||_F <= 1/2``, ``T = sum_{k<=18} X**k / k!`` by Horner's rule (truncation error 0.5**19 / 19! < 1e-22),
-    then ``T <- T T`` s times.  Sectors without a stored block get the identity, like the reference."""
+    ``||X||_F <= 2``, ``T = sum_{k<=28} X**k / k!`` by Horner's rule (truncation error 2**29 / 29! < 1e-22),
+    then ``T <- T T`` s times (few squarings: each one doubles the rounding error that scipy's Pade route does not have).  Sectors without a stored block get the identity, like the reference."""
     if a.rank != 2 or a.shape[0] != a.shape[1]:
         raise ValueError("expect a square matrix!")
     a.legs[0].test_contractible(a.legs[1])
@@ -1505,11 +1609,11 @@ def expm(a):
     else:
         if not np.isfinite(nrm):
             raise ValueError("expm of a matrix with non-finite entries")
-        s_pow = max(0, int(np.ceil(np.log2(nrm / 0.5))))
+        s_pow = max(0, int(np.ceil(np.log2(nrm / 2.))))
         X = a.astype(res_dtype, copy=True)
         X.idrop_labels()
         X.iscale_prefactor(0.5**s_pow)
-        order = 18
+        order = 28
         T = eye.copy(deep=True)
         for k in range(order, 0, -1):
             T = tensordot(X, T, axes=1)
@@ -1568,9 +1672,10 @@ def detect_qtotal(flat_array, legcharges, cutoff=None):
 
 
 def to_iterable_arrays(array_list):
+    """A single Array / string / scalar becomes a one-element list; other iterables are left alone (reference :4383)."""
     if isinstance(array_list, Array):
-        array_list = [array_list]
-    return array_list
+        return [array_list]
+    return array_list if _is_iterable(array_list) else [array_list]
 
 
 # ======================================================================================================
@@ -2097,18 +2202,83 @@ def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, swee
     sweeps.value = int(sw.item())
 
 
+# Algorithm chain of the block SVD, the device counterpart of svd_robust.py:65-75 (gesdd, on LinAlgError gesvd) and of the
+# NaN re-try of np_conserved.py:4970-4982: every entry is a `tpa_svd_set_algorithm` code that is tried when the previous
+# one returned TPA_E_NOCONV or produced NaNs: default (pivoted-QR preconditioner + fused block Jacobi), block Jacobi
+# without the preconditioner and with two-kernel rounds, then the plain one-wavefront-per-row-pair Jacobi.
+SVD_ALGORITHM_CHAIN = (0, 512 | 2, 1 | 512)
+SVD_MAX_SWEEPS = 80
+svd_robust_stats = {'retries': 0, 'last_chain': ()}
+
+
+def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, sweeps):
+    """One batched device SVD with the fallback chain; returns the singular values on the host."""
+    wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
+    work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
+    tried = []
+    last_err = None
+    for hop, alg in enumerate(SVD_ALGORITHM_CHAIN):
+        if hop:
+            warnings.warn("tenpy_amd: block SVD (algorithm %s) gave %s. Try again with algorithm %d"
+                          % (tried[-1], last_err, alg), stacklevel=3)
+            svd_robust_stats['retries'] += 1
+            L.tpa_svd_set_algorithm(alg)
+        tried.append(alg)
+        try:
+            rc = L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a_arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
+                                 V_arena.data_ptr(), work.data_ptr(), int(wb), SVD_MAX_SWEEPS, SVD_ABS_FLOOR,
+                                 dev.byref(sweeps), dev.stream())
+        finally:
+            if hop:
+                L.tpa_svd_set_algorithm(SVD_ALGORITHM_CHAIN[0])
+        svd_robust_stats['last_chain'] = tuple(tried)
+        if rc == dev.E_NOCONV:
+            last_err = "no convergence"
+            continue
+        dev.check(rc, "svd_batch")          # bad arguments, NaN / Inf in the INPUT, HIP errors: no second try helps
+        S_host = dev.to_host(S_dev)
+        if np.any(np.isnan(S_host)):
+            last_err = "NaNs"
+            continue
+        return S_host
+    if last_err == "NaNs":
+        raise ValueError("NaN in S: " + str(int(np.sum(np.isnan(S_host)))))
+    raise np.linalg.LinAlgError("tenpy_amd svd_batch: no convergence with any of the algorithms " + repr(tuple(tried)))
+
+
+def _copy_jobs_2d(dst_off, dst_ld, src_off, src_ld, rows, cols, src_transposed=False, conj=False):
+    """Strided-copy jobs ``dst[r, c] = src[r, c]`` (or ``src[c, r]``, optionally conjugated) for row-major sub-matrices."""
+    n = len(rows)
+    jobs = np.zeros((n, 4 + 3 * COPY_MAXDIM), dtype=np.int64)
+    jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3] = dst_off, src_off, 2, int(bool(conj))
+    jobs[:, 4], jobs[:, 5] = rows, cols
+    jobs[:, 4 + COPY_MAXDIM], jobs[:, 5 + COPY_MAXDIM] = dst_ld, 1
+    if src_transposed:
+        jobs[:, 4 + 2 * COPY_MAXDIM], jobs[:, 5 + 2 * COPY_MAXDIM] = 1, src_ld
+    else:
+        jobs[:, 4 + 2 * COPY_MAXDIM], jobs[:, 5 + 2 * COPY_MAXDIM] = src_ld, 1
+    return jobs
+
+
+def _complement_blocks(Q):
+    """Orthonormal completion of the isometry ``Q`` (legs ``[left, inner]``, blocked): a device Array ``C`` with legs
+    ``[left, c]`` whose blocks span the orthogonal complement of the column space of ``Q`` inside every sector of
+    ``left``; ``None`` if ``Q`` is already unitary.  See ``_npc_cold.complement_columns`` (SVD of ``1 - Q Q^dagger``)."""
+    from . import _npc_cold
+    return _npc_cold.complement_columns(Q)
+
+
 def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, None], inner_labels=[None, None],
         inner_qconj=+1):
     """Block-wise SVD ``a = U diag(S) VH`` (reference np_conserved.py:3676, worker :4950).
 
-    All charge blocks are decomposed in one batched one-sided-Jacobi call on the device; ``S`` is
-    returned on the host (1-D ndarray, concatenated block by block, not globally sorted) because the
-    truncation decision (``truncation.truncate``) is host logic.
+    All charge blocks are decomposed in one batched device call (rank-revealing QR + one-sided block Jacobi, with
+    the fallback chain ``SVD_ALGORITHM_CHAIN``); ``S`` is returned on the host (1-D ndarray, concatenated block by
+    block, not globally sorted) because the truncation decision (``truncation.truncate``) is host logic.
+    ``full_matrices=True``: ``U`` and ``VH`` are completed to square unitary blocks on the device.
     """
     if a.rank != 2:
         raise ValueError("SVD is only defined for a 2D matrix. Use LegPipes!")
-    if full_matrices:
-        raise NotImplementedError("tenpy_amd: full_matrices=True is not implemented")
     labL, labR = inner_labels
     a_labels = a._labels
     piped_axes, a = a.as_completely_blocked()
@@ -2124,6 +2294,8 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     qtotal_L, qtotal_R = a.chinfo.make_valid(qtotal_L), a.chinfo.make_valid(qtotal_R)
     if a.stored_blocks == 0:
         raise RuntimeError("SVD found no singular values")
+    if full_matrices and cutoff is not None:
+        raise ValueError("full_matrices=True with a cutoff is not defined")     # the reference asserts (:4995)
     offs, ms, ns = _blocked_matrix_jobs(a)
     ks = np.minimum(ms, ns)
     nblk = len(ms)
@@ -2138,21 +2310,18 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     U_arena = dev.empty(int(u_offs[-1]), a.dtype)
     V_arena = dev.empty(int(v_offs[-1]), a.dtype)
     S_dev = dev.empty(int(s_offs[-1]), np.float64)
-    wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
-    work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
     sweeps = dev.c_int()
     if SVD_DIST_GROUP is not None and nblk > 1:
+        wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
         _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, sweeps)
+        S_host = dev.to_host(S_dev)
+        if np.any(np.isnan(S_host)):
+            raise ValueError("NaN in S: " + str(np.sum(np.isnan(S_host))))
     else:
-        dev.check(L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
-                                  V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
-                  "svd_batch")
+        S_host = _svd_batch_robust(L, code, jobs, nblk, a._arena, U_arena, S_dev, V_arena, sweeps)
     svd_stats['calls'] += 1
     svd_stats['sweeps'] += sweeps.value
     svd_stats['max_block'] = max(svd_stats['max_block'], int(np.max(ks)))
-    S_host = dev.to_host(S_dev)
-    if np.any(np.isnan(S_host)):
-        raise ValueError("NaN in S: " + str(np.sum(np.isnan(S_host))))
     if not compute_uv:
         if cutoff is not None:
             S_host = S_host[S_host > cutoff]
@@ -2177,7 +2346,9 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     VH._arena = V_arena
     VH._qdata_sorted = a._qdata_sorted
     S = S_host
-    if cutoff is not None:
+    if full_matrices:
+        U, VH = _svd_full_matrices(a, U, VH, ms, ns, ks, qtotal_L, qtotal_R)
+    elif cutoff is not None:
         keep = S > cutoff
         if not np.any(keep):
             raise RuntimeError("SVD found no singular values")
@@ -2194,14 +2365,89 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     return U, S, VH
 
 
+def _widen_isometry(thin, ms, ks, sectors, leg, transposed_rows=False):
+    """Square unitary blocks ``[thin | complement]`` for the sectors ``sectors`` (qindices of ``leg``) of an isometry
+    ``thin`` = Array ``[leg, inner]`` whose b-th block is ``ms[b] x ks[b]``.  Returns ``(arena, offsets)`` of the
+    ``ms[b] x ms[b]`` blocks; with ``transposed_rows`` the blocks are stored as the conjugate transpose (rows = vectors)."""
+    comp = _complement_blocks(thin) if np.any(ms > ks) else None
+    nblk = len(ms)
+    offs = np.concatenate([[0], np.cumsum(ms * ms)]).astype(np.int64)
+    arena = dev.empty(int(offs[-1]), thin.dtype)
+    cplx = thin.dtype.kind == 'c'
+
+    def put(src, src_offs, widths, col0):
+        sel = np.nonzero(widths > 0)[0]
+        if len(sel) == 0:
+            return
+        m, w, c0 = ms[sel], widths[sel], col0[sel]
+        if not transposed_rows:     # dst[r, c0 + c] = src[r, c]
+            jobs = _copy_jobs_2d(offs[sel] + c0, m, src_offs[sel], w, m, w)
+        else:                       # dst[c0 + c, r] = conj(src[r, c])
+            jobs = _copy_jobs_2d(offs[sel] + c0 * m, m, src_offs[sel], w, w, m, src_transposed=True, conj=cplx)
+        _run_copy(thin.dtype, jobs, int(np.max(m * w)), src._arena, arena)
+
+    put(thin, thin._offsets, ks.astype(np.int64), np.zeros(nblk, np.int64))
+    if comp is not None and comp.stored_blocks:
+        where = {int(q): i for i, q in enumerate(comp._qdata[:, 0])}
+        c_offs = np.array([comp._offsets[where[int(q)]] if int(q) in where else 0 for q in sectors], dtype=np.int64)
+        put(comp, c_offs, (ms - ks).astype(np.int64), ks.astype(np.int64))
+    return arena, offs[:-1]
+
+
+def _svd_full_matrices(a, U, VH, ms, ns, ks, qtotal_L, qtotal_R):
+    """``U`` -> ``m x m`` and ``VH`` -> ``n x n`` unitary blocks (reference :5012-5017: legs ``[leg0, leg0*]`` and
+    ``[leg1*, leg1]``, block (q, q) for every stored block of ``a``)."""
+    qi_L, qi_R = a._qdata[:, 0], a._qdata[:, 1]
+    Uf = Array([a.legs[0], a.legs[0].conj()], a.dtype, qtotal_L)
+    Uf._arena, Uf._offsets = _widen_isometry(U, ms, ks, qi_L, a.legs[0])
+    Uf._qdata = np.ascontiguousarray(np.stack([qi_L, qi_L], axis=1), dtype=np.intp)
+    Uf._qdata_sorted = bool(np.all(qi_L[:-1] < qi_L[1:]))
+    V = VH.conj().itranspose()           # columns = right singular vectors, legs [leg1*, inner]
+    V._repack()
+    Vf = Array([a.legs[1].conj(), a.legs[1]], a.dtype, qtotal_R)
+    Vf._arena, Vf._offsets = _widen_isometry(V, ns, ks, qi_R, V.legs[0], transposed_rows=True)
+    Vf._qdata = np.ascontiguousarray(np.stack([qi_R, qi_R], axis=1), dtype=np.intp)
+    Vf._qdata_sorted = a._qdata_sorted
+    return Uf, Vf
+
+
+def _qr_device(a):
+    """Reduced block QR of a blocked matrix on the device: returns ``(Q_arena, q_offs, R_arena, r_offs, ms, ns, ks)``."""
+    offs, ms, ns = _blocked_matrix_jobs(a)
+    ks = np.minimum(ms, ns)
+    nblk = len(ms)
+    q_offs = np.concatenate([[0], np.cumsum(ms * ks)])
+    r_offs = np.concatenate([[0], np.cumsum(ks * ns)])
+    jobs = np.zeros((nblk, 8), dtype=np.int64)
+    jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3], jobs[:, 4] = offs, ms, ns, q_offs[:-1], r_offs[:-1]
+    Q_arena = dev.empty(int(q_offs[-1]), a.dtype)
+    R_arena = dev.empty(int(r_offs[-1]), a.dtype)
+    dev.check(dev.lib().tpa_qr_batch(dev.code(a.dtype), jobs.ctypes.data, nblk, a._arena.data_ptr(), Q_arena.data_ptr(),
+                                     R_arena.data_ptr(), dev.stream()), "qr_batch")
+    return Q_arena, q_offs, R_arena, r_offs, ms, ns, ks
+
+
+def _qr_rank_cut(a, cutoff):
+    """``qr(a, cutoff=...)``: discard (numerically) linearly dependent directions, reference :4191 -> ``tools/math.py:255``
+    ``qr_li`` (pivoted QR, drop ``|R_ii| <= cutoff``, un-pivot, second QR).  Device route: the rank-revealing block SVD
+    plays the part of the pivoted QR -- ``a = U_k (S_k VH_k)`` with the singular values ``> cutoff`` kept (``sigma_i`` and
+    the ``|R_ii|`` of a pivoted QR bound each other, so the same directions go) -- and one more block QR of
+    ``S_k VH_k`` makes ``R`` upper triangular: ``Q = U_k q``.  Returns blocked ``(Q, R)`` with a fresh inner leg."""
+    U, S, VH = svd(a, cutoff=cutoff, inner_labels=[None, None])
+    VH.iscale_axis(S, 0)
+    q, R = qr(VH, mode='reduced')
+    return tensordot(U, q, axes=1), R
+
+
 def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=False, qtotal_Q=None, inner_qconj=+1):
-    """Block-wise QR ``a = Q R`` (reference np_conserved.py:4139), ``mode='reduced'`` only."""
+    """Block-wise QR ``a = Q R`` (reference np_conserved.py:4139): Householder panels / compact-WY updates on the device
+    for all charge blocks at once.  ``mode='complete'``: ``Q`` is completed to square unitary blocks (plus identity
+    blocks for the sectors of the first leg in which ``a`` vanishes, reference :4244-4262) and ``R`` padded with zero
+    rows.  ``cutoff``: see :func:`_qr_rank_cut`."""
     if a.rank != 2:
         raise ValueError("expect a matrix!")
-    if mode != 'reduced':
-        raise NotImplementedError("tenpy_amd: only mode='reduced' is implemented")
-    if cutoff is not None:
-        raise NotImplementedError("tenpy_amd: qr with cutoff")
+    if mode not in ('reduced', 'complete'):
+        raise ValueError("unknown mode " + repr(mode))
     a_labels = a._labels
     label_Q, label_R = inner_labels
     piped_axes, a = a.as_completely_blocked()
@@ -2209,29 +2455,50 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
     qtotal_Q_given = qtotal_Q is not None
     qtotal_Q = chinfo.make_valid(qtotal_Q)
     qtotal_R = chinfo.make_valid(a.qtotal - qtotal_Q)
-    if a.stored_blocks == 0:
-        raise ValueError("QR of an Array without blocks")
-    offs, ms, ns = _blocked_matrix_jobs(a)
-    ks = np.minimum(ms, ns)
-    nblk = len(ms)
-    q_offs = np.concatenate([[0], np.cumsum(ms * ks)])
-    r_offs = np.concatenate([[0], np.cumsum(ks * ns)])
-    k_offs = np.concatenate([[0], np.cumsum(ks)])
-    jobs = np.zeros((nblk, 8), dtype=np.int64)
-    jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3], jobs[:, 4] = offs, ms, ns, q_offs[:-1], r_offs[:-1]
-    Q_arena = dev.empty(int(q_offs[-1]), a.dtype)
-    R_arena = dev.empty(int(r_offs[-1]), a.dtype)
-    dev.check(dev.lib().tpa_qr_batch(dev.code(a.dtype), jobs.ctypes.data, nblk, a._arena.data_ptr(), Q_arena.data_ptr(),
-                                     R_arena.data_ptr(), dev.stream()), "qr_batch")
-    # inner leg = leg 0 projected onto the first k indices of every block row (reference :4186-4232)
     a_leg0 = a.legs[0]
+    complete = (mode == 'complete')
+    if a.stored_blocks == 0 and not complete:
+        raise ValueError("QR of an Array without blocks")
     qi_L, qi_R = a._qdata[:, 0], a._qdata[:, 1]
-    mask = np.zeros(a_leg0.ind_len, dtype=np.bool_)
-    for q1, k in zip(qi_L, ks):
-        i0 = a_leg0.slices[q1]
-        mask[i0:i0 + k] = True
+    if cutoff is not None:
+        if complete:
+            raise NotImplementedError("tenpy_amd: qr with both cutoff and mode='complete'")
+        Qc, Rc = _qr_rank_cut(a, cutoff)
+        Qc._repack()
+        Rc._repack()
+        order_q = np.argsort(Qc._qdata[:, 0], kind='stable')
+        # blocks of `a` that survive, in the order of a._qdata; ks = kept rank per block
+        rank_of = {int(q): int(Qc.legs[1].get_block_sizes()[c]) for q, c in Qc._qdata}
+        ks_all = np.array([rank_of.get(int(q), 0) for q in qi_L], dtype=np.int64)
+        keep_blocks = ks_all > 0
+        qi_L, qi_R = qi_L[keep_blocks], qi_R[keep_blocks]
+        ks = ks_all[keep_blocks]
+        q_pos = {int(q): i for i, q in enumerate(Qc._qdata[:, 0])}
+        r_pos = {int(q): i for i, q in enumerate(Rc._qdata[:, 1])}
+        Q_arena, R_arena = Qc._arena, Rc._arena
+        q_offs_b = np.array([Qc._offsets[q_pos[int(q)]] for q in qi_L], dtype=np.int64)
+        r_offs_b = np.array([Rc._offsets[r_pos[int(q)]] for q in qi_R], dtype=np.int64)
+        ms = a_leg0.get_block_sizes()[qi_L].astype(np.int64)
+        ns = a.legs[1].get_block_sizes()[qi_R].astype(np.int64)
+        del order_q
+    elif a.stored_blocks:
+        Q_arena, q_offs, R_arena, r_offs, ms, ns, ks = _qr_device(a)
+        q_offs_b, r_offs_b = q_offs[:-1].astype(np.int64), r_offs[:-1].astype(np.int64)
+    else:
+        ms = ns = ks = q_offs_b = r_offs_b = np.zeros(0, np.int64)
+        Q_arena = R_arena = dev.empty(0, a.dtype)
+    nblk = len(ms)
+    # ---- inner leg (reference :4186-4232): leg 0 restricted to the first k indices of every block row ('reduced')
     inner_leg = a_leg0.to_LegCharge() if isinstance(a_leg0, LegPipe) else a_leg0.copy()
-    map_qind, _, inner_leg = inner_leg.project(mask)
+    if not complete:
+        mask = np.zeros(a_leg0.ind_len, dtype=np.bool_)
+        for q1, k in zip(qi_L, ks):
+            i0 = a_leg0.slices[q1]
+            mask[i0:i0 + k] = True
+        map_qind, _, inner_leg = inner_leg.project(mask)
+        qi_C = map_qind[qi_L]
+    else:
+        qi_C = qi_L
     if qtotal_Q_given:
         inner_leg.charges = chinfo.make_valid(inner_leg.charges - inner_leg.qconj * qtotal_Q)
         inner_leg.sorted = False
@@ -2239,27 +2506,40 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
         inner_leg.charges = chinfo.make_valid(-inner_leg.charges)
         inner_leg.sorted = False
         inner_leg.qconj = inner_qconj
-    qi_C = map_qind[qi_L]
     Q = Array([a_leg0, inner_leg.conj()], a.dtype, qtotal_Q)
     R = Array([inner_leg, a.legs[1]], a.dtype, qtotal_R)
-    Q._qdata = np.ascontiguousarray(np.stack([qi_L, qi_C], axis=1), dtype=np.intp)
-    Q._offsets, Q._arena, Q._qdata_sorted = q_offs[:-1].astype(np.int64), Q_arena, False
-    R._qdata = np.ascontiguousarray(np.stack([qi_C, qi_R], axis=1), dtype=np.intp)
-    R._offsets, R._arena, R._qdata_sorted = r_offs[:-1].astype(np.int64), R_arena, False
-    if pos_diag_R:
+    Q._qdata = np.ascontiguousarray(np.stack([qi_L, qi_C], axis=1), dtype=np.intp).reshape(nblk, 2)
+    Q._offsets, Q._arena, Q._qdata_sorted = q_offs_b, Q_arena, False
+    R._qdata = np.ascontiguousarray(np.stack([qi_C, qi_R], axis=1), dtype=np.intp).reshape(nblk, 2)
+    R._offsets, R._arena, R._qdata_sorted = r_offs_b, R_arena, False
+    if pos_diag_R and nblk:
         # phases of diag(R) per block: tiny D2H of the diagonals, then two axis scalings on the device
-        diag_idx = np.concatenate([r_offs[b] + np.arange(ks[b]) * (ns[b] + 1) for b in range(nblk)])
+        k_offs = np.concatenate([[0], np.cumsum(ks)])
+        diag_idx = np.concatenate([r_offs_b[b] + np.arange(ks[b]) * (ns[b] + 1) for b in range(nblk)])
         d = dev.to_host(dev.take(R_arena, diag_idx))
         phb = np.where(np.abs(d) > 0, d / np.where(np.abs(d) > 0, np.abs(d), 1.), 1.)
         if a.dtype.kind != 'c':
             phb = phb.real
-        # block order -> flat index order of the inner leg
-        ph = np.ones(inner_leg.ind_len, dtype=phb.dtype)
+        # block order -> flat index order of the (reduced) inner leg
+        red_slices = np.concatenate([[0], np.cumsum(ks)]) if complete else None
+        ph = np.ones(int(np.sum(ks)) if complete else inner_leg.ind_len, dtype=phb.dtype)
         for b in range(nblk):
-            i0 = inner_leg.slices[qi_C[b]]
+            i0 = red_slices[b] if complete else inner_leg.slices[qi_C[b]]
             ph[i0:i0 + ks[b]] = phb[k_offs[b]:k_offs[b + 1]]
-        Q.iscale_axis(ph, 1)
-        R.iscale_axis(np.conj(ph), 0)
+        if complete:        # scale the thin factors through temporary views with the reduced inner leg
+            thin_leg = LegCharge.from_qind(chinfo, red_slices, inner_leg.charges[qi_C], inner_leg.qconj)
+            Qt = Array([a_leg0, thin_leg.conj()], a.dtype, qtotal_Q)
+            Rt = Array([thin_leg, a.legs[1]], a.dtype, qtotal_R)
+            seq = np.arange(nblk, dtype=np.intp)
+            Qt._qdata, Qt._offsets, Qt._arena = np.ascontiguousarray(np.stack([qi_L, seq], axis=1)), q_offs_b, Q_arena
+            Rt._qdata, Rt._offsets, Rt._arena = np.ascontiguousarray(np.stack([seq, qi_R], axis=1)), r_offs_b, R_arena
+            Qt.iscale_axis(ph, 1)
+            Rt.iscale_axis(np.conj(ph), 0)
+        else:
+            Q.iscale_axis(ph, 1)
+            R.iscale_axis(np.conj(ph), 0)
+    if complete:
+        Q, R = _qr_complete(a, Q, R, ms, ns, ks, inner_leg, qtotal_Q, qtotal_R)
     if 0 in piped_axes:
         Q = Q.split_legs(0)
     if 1 in piped_axes:
@@ -2267,6 +2547,102 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
     Q.iset_leg_labels([a_labels[0], label_Q])
     R.iset_leg_labels([label_R, a_labels[1]])
     return Q, R
+
+
+def _qr_complete(a, Q, R, ms, ns, ks, inner_leg, qtotal_Q, qtotal_R):
+    """Square ``Q`` blocks ``[Q_thin | complement]``, identity for the sectors of leg 0 without a block of ``a``, and
+    ``R`` blocks ``m x n`` with zero rows below the ``k x n`` triangle (reference :4244-4262)."""
+    a_leg0 = a.legs[0]
+    chinfo = a.chinfo
+    nblk = len(ms)
+    qi_L, qi_R = a._qdata[:, 0], a._qdata[:, 1]
+    # thin Q with a plain sector-per-block inner leg, for the completion routine
+    thin_leg = LegCharge.from_qind(chinfo, np.concatenate([[0], np.cumsum(ks)]), np.zeros((nblk, chinfo.qnumber), QTYPE), -a_leg0.qconj)
+    Qt = Array.__new__(Array)
+    Q._arena
+    Qt.__dict__.update(Q.__dict__)
+    thin_charges = chinfo.make_valid(-a_leg0.charges[qi_L] * a_leg0.qconj * thin_leg.qconj)
+    thin_leg = LegCharge.from_qind(chinfo, thin_leg.slices, thin_charges, thin_leg.qconj)
+    Qt.legs = [a_leg0, thin_leg]
+    Qt.qtotal = chinfo.make_valid()
+    Qt._labels = [None, None]
+    Qt._qdata = np.ascontiguousarray(np.stack([qi_L, np.arange(nblk)], axis=1), dtype=np.intp).reshape(nblk, 2)
+    Qt._set_shape()
+    Qt._skey = None
+    Qt.__dict__.pop('_sz_cache', None)
+    Qt.__dict__.pop('_pk_cache', None)
+    all_q = np.arange(a_leg0.block_number, dtype=np.intp)
+    sizes_all = a_leg0.get_block_sizes().astype(np.int64)
+    have = np.zeros(a_leg0.block_number, dtype=bool)
+    have[qi_L] = True
+    missing = all_q[~have]
+    # square blocks for the sectors that have data
+    if nblk:
+        arena_have, offs_have = _widen_isometry(Qt, ms, ks, qi_L, a_leg0)
+    else:
+        arena_have, offs_have = dev.empty(0, a.dtype), np.zeros(0, np.int64)
+    qdata = [np.stack([qi_L, qi_L], axis=1)] if nblk else []
+    if len(missing):
+        eye = np.concatenate([np.eye(int(n), dtype=a.dtype).reshape(-1) for n in sizes_all[missing]])
+        n_have = int(arena_have.numel())
+        full = dev.empty(n_have + len(eye), a.dtype)
+        if n_have:
+            _run_copy(a.dtype, _copy_jobs_contiguous(np.zeros(1, np.int64), np.zeros(1, np.int64), np.array([n_have])), n_have,
+                      arena_have, full)
+        eye_dev = dev.to_device(eye)
+        _run_copy(a.dtype, _copy_jobs_contiguous(np.array([n_have], np.int64), np.zeros(1, np.int64), np.array([len(eye)])),
+                  len(eye), eye_dev, full)
+        m_offs = n_have + np.concatenate([[0], np.cumsum(sizes_all[missing] ** 2)])[:-1]
+        arena_have, offs_have = full, np.concatenate([offs_have, m_offs]).astype(np.int64)
+        qdata.append(np.stack([missing, missing], axis=1))
+    Qf = Array([a_leg0, inner_leg.conj()], a.dtype, qtotal_Q)
+    Qf._qdata = np.ascontiguousarray(np.concatenate(qdata, axis=0), dtype=np.intp)
+    Qf._offsets, Qf._arena, Qf._qdata_sorted = offs_have, arena_have, False
+    # R: zero-padded m x n blocks
+    Rf = Array([inner_leg, a.legs[1]], a.dtype, qtotal_R)
+    if nblk:
+        Rf._set_blocks(np.stack([qi_L, qi_R], axis=1), zero=True, qdata_sorted=False)
+        _run_copy(a.dtype, _copy_jobs_2d(Rf._offsets, ns, R._offsets, ns, ks, ns), int(np.max(ks * ns)), R._arena, Rf._arena)
+    return Qf, Rf
+
+
+def orthogonal_columns(a, new_label=None):
+    """Isometry whose columns are orthonormal and orthogonal to all columns of the full-rank ``M x N`` matrix ``a``,
+    ``M >= N`` (reference np_conserved.py:4291): the block QR gives ``range(a)``, the completion of that isometry on
+    the device (``_complement_blocks``) the rest; sectors in which ``a`` vanishes contribute identity blocks."""
+    if a.rank != 2:
+        raise ValueError("expect a matrix!")
+    M, N = a.shape
+    a_labels = a._labels
+    if new_label is None:
+        new_label = a_labels[1]
+    if M < N:
+        raise ValueError("orthogonal_columns with M={0:d} < N{1:d}: overcomplete! ".format(M, N))
+    right_qconj = a.legs[1].qconj
+    if M == N:
+        warnings.warn("orthogonal_columns(a) for square `a` yields zero matrix!")
+        right_leg = LegCharge(a.chinfo, [0], np.zeros([0, a.chinfo.qnumber], dtype=QTYPE), right_qconj)
+        return Array([a.legs[0], right_leg], a.dtype, a.qtotal, [a_labels[0], new_label])
+    piped_axes, a = a.as_completely_blocked()
+    left = a.legs[0]
+    if a.stored_blocks:
+        Qa, _ = qr(a.copy(deep=False).idrop_labels(), mode='reduced')
+        comp = _complement_blocks(Qa)
+    else:
+        comp = diag(1., left, dtype=a.dtype)
+    comp._repack()
+    order = np.argsort(comp._qdata[:, 0], kind='stable')
+    kept = comp._qdata[order, 0]
+    widths = comp.legs[1].get_block_sizes()[comp._qdata[order, 1]]
+    right_charges = a.chinfo.make_valid(right_qconj * (a.qtotal - left.get_charge(kept)))
+    right_leg = LegCharge(a.chinfo, np.concatenate([[0], np.cumsum(widths)]), right_charges, right_qconj)
+    ortho = Array([left, right_leg], a.dtype, a.qtotal)
+    ortho._qdata = np.ascontiguousarray(np.stack([kept, np.arange(len(kept))], axis=1), dtype=np.intp)
+    ortho._offsets, ortho._arena, ortho._qdata_sorted = comp._offsets[order].astype(np.int64), comp._arena, True
+    if 0 in piped_axes:
+        ortho = ortho.split_legs(0)
+    ortho.iset_leg_labels([a_labels[0], new_label])
+    return ortho
 
 
 def _permute_within_blocks(a, perm_flat, axis):
@@ -2383,3 +2759,26 @@ def eigh(a, UPLO='L', sort=None):
         V = V.split_legs(0)
     V.iset_leg_labels([a_labels[0], 'eig'])
     return resw, V
+
+
+def eig(a, sort=None):
+    """General (non-hermitian) eigendecomposition ``a V = V diag(W)`` (reference :3937) -- not on the DMRG / TEBD path;
+    see :mod:`tenpy_amd.linalg._host_eig`."""
+    from ._host_eig import eig as _eig
+    return _eig(a, sort)
+
+
+def eigvals(a, sort=None):
+    """Eigenvalues of a general square matrix (reference :4000); see :mod:`tenpy_amd.linalg._host_eig`."""
+    from ._host_eig import eigvals as _eigvals
+    return _eigvals(a, sort)
+
+
+def speigs(a, charge_sector, k, *args, **kwargs):
+    """``k`` eigenpairs of one charge sector by ARPACK (reference :4024); see :mod:`tenpy_amd.linalg._host_eig`."""
+    from ._host_eig import speigs as _speigs
+    return _speigs(a, charge_sector, k, *args, **kwargs)
+
+
+from . import _npc_cold  # noqa: E402   (needs Array and the functions above)
+_npc_cold.attach(__import__(__name__, fromlist=['Array']))
