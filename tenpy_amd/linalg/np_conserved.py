@@ -350,11 +350,7 @@ class Array:
     def from_func(cls, func, legcharges, dtype=None, qtotal=None, func_args=(), func_kwargs={}, shape_kw=None,
                   labels=None):
         """Fill every charge-allowed block with ``func(shape, ...)`` evaluated on the host, then upload."""
-        if dtype is None:
-            probe = func(*((2,),) + tuple(func_args), **func_kwargs) if shape_kw is None else \
-                func(*func_args, **{**func_kwargs, shape_kw: (2,)})
-            dtype = np.asarray(probe).dtype
-        res = cls(legcharges, dtype, qtotal, labels)
+        res = cls(legcharges, np.float64 if dtype is None else dtype, qtotal, labels)
         qdata = res._allowed_qdata()
         shapes = res._block_shapes(qdata)
         blocks = []
@@ -362,9 +358,11 @@ class Array:
             sh = tuple(int(s) for s in sh)
             blk = func(sh, *func_args, **func_kwargs) if shape_kw is None else \
                 func(*func_args, **{**func_kwargs, shape_kw: sh})
-            blocks.append(np.asarray(blk, dtype=res.dtype).reshape(-1))
+            blocks.append(np.asarray(blk).reshape(-1))
+        if dtype is None and len(blocks):            # the dtype is what `func` returns (reference :528-604)
+            res.dtype = _calc_dtype(*[b.dtype for b in blocks])
         if len(blocks):
-            res._set_blocks(qdata, arena=dev.to_device(np.concatenate(blocks)), qdata_sorted=True)
+            res._set_blocks(qdata, arena=dev.to_device(np.concatenate(blocks).astype(res.dtype, copy=False)), qdata_sorted=True)
         return res
 
     @classmethod
@@ -571,7 +569,7 @@ class Array:
             sort = [sort] * self.rank
         if bunch is False or bunch is True:
             bunch = [bunch] * self.rank
-        perms = [None] * self.rank
+        perms = [np.arange(n, dtype=np.intp) for n in self.shape]       # identity where nothing moves (reference :1405)
         res = self.copy(deep=False)
         res._qdata = self._qdata.copy()
         bunch_axes = []
@@ -668,38 +666,52 @@ class Array:
         # --- copy jobs: one per old block, ndim = old rank, iterating old axes in NEW order
         old_shapes = self._block_shapes()
         old_strides = _c_strides(old_shapes)
-        flat_src = [a for src in src_axes for a in src]
-        nd = len(flat_src)
+        # copy dims: one per source leg, except that a group of source legs that are neighbours in ascending order is
+        # contiguous in the old block AND in the slice of the fused block -> a single dim
+        dims = []           # (new axis, [source legs forming one dim])
+        for na, src in enumerate(src_axes):
+            if all(src[i + 1] == src[i] + 1 for i in range(len(src) - 1)):
+                dims.append((na, list(src)))
+            else:
+                dims.extend((na, [a]) for a in src)
+        nd = len(dims)
         if nd > COPY_MAXDIM:
             return self._combine_legs_via_transpose(combine_legs, new_axes, pipes, transp)
         new_strides = _c_strides(new_shapes)[new_index]  # (nold, res.rank)
         jobs = np.zeros((nold, 4 + 3 * COPY_MAXDIM), dtype=np.int64)
         jobs[:, 2] = nd
         dst_off = res._offsets[new_index].copy()
-        col = 0
-        for na, src in enumerate(src_axes):
+        for na in range(res.rank):
             dst_off += start[:, na] * new_strides[:, na]
-            # C-order strides inside the slice for the legs of this new axis
-            inner = np.ones(nold, dtype=np.int64)
-            for a in reversed(src):
-                pos = flat_src.index(a)
-                jobs[:, 4 + pos] = old_shapes[:, a]
-                jobs[:, 4 + COPY_MAXDIM + pos] = inner * new_strides[:, na]
-                jobs[:, 4 + 2 * COPY_MAXDIM + pos] = old_strides[:, a]
-                inner = inner * old_shapes[:, a]
-            col += len(src)
+        for pos in range(nd - 1, -1, -1):
+            na, legs_d = dims[pos]
+            # C-order stride inside the slice of new axis `na`: product of the sizes of the later source legs of that axis
+            later = [a for (na2, l2) in dims[pos + 1:] if na2 == na for a in l2]
+            inner = np.prod(old_shapes[:, later], axis=1) if later else np.ones(nold, dtype=np.int64)
+            jobs[:, 4 + pos] = np.prod(old_shapes[:, legs_d], axis=1)
+            jobs[:, 4 + COPY_MAXDIM + pos] = inner * new_strides[:, na]
+            jobs[:, 4 + 2 * COPY_MAXDIM + pos] = old_strides[:, legs_d[-1]]
         jobs[:, 0] = dst_off
         jobs[:, 1] = self._offsets
         sizes = np.prod(old_shapes, axis=1)
         _run_copy(self.dtype, jobs, int(np.max(sizes)), self._arena, res._arena)
         return res
 
-    def _combine_legs_via_transpose(self, combine_legs, new_axes, pipes, transp):  # pragma: no cover (rank > 6)
+    def _combine_legs_via_transpose(self, combine_legs, new_axes, pipes, transp):
+        """More than COPY_MAXDIM copy dims: bring the legs of every group next to each other first (``transp``: the final
+        leg order with each pipe expanded into its legs), then every new axis is a single copy dim."""
         tr = self.transpose(transp)
-        inv = np.argsort(transp)
-        cl = [[int(inv[a]) for a in c] for c in combine_legs]
-        merged = tr._merge_for_copy(cl)
-        raise NotImplementedError("combine_legs of more than %d legs at once" % COPY_MAXDIM)
+        pos, groups = 0, []
+        sizes = {na: len(cl) for na, cl in zip(new_axes, combine_legs)}
+        n_new = self.rank - sum(sizes.values()) + len(sizes)
+        for na in range(n_new):
+            w = sizes.get(na, 1)
+            if na in sizes:
+                groups.append(list(range(pos, pos + w)))
+            pos += w
+        if n_new > COPY_MAXDIM:
+            raise NotImplementedError("combine_legs with a result of rank > %d" % COPY_MAXDIM)
+        return tr.combine_legs(groups, new_axes=list(new_axes), pipes=list(pipes))
 
     def _combine_legs_make_pipes(self, combine_legs, pipes, qconj):
         npipes = len(combine_legs)
@@ -811,21 +823,22 @@ class Array:
                 new_qdata[:, new_of_old[a][0]] = self._qdata[old_idx, a]
         res._set_blocks(new_qdata, qdata_sorted=False)
         new_shapes = res._block_shapes()
-        if res.rank > COPY_MAXDIM:
-            raise NotImplementedError("split_legs to more than %d legs" % COPY_MAXDIM)
+        # copy dims: ONE per old axis -- the legs a pipe is split into subdivide a contiguous index range of the old
+        # block in C order and are neighbours in the new block, so they move as a single dim
+        if self.rank > COPY_MAXDIM:
+            raise NotImplementedError("split_legs of a tensor of rank > %d" % COPY_MAXDIM)
         old_shapes = self._block_shapes()[old_idx]
         old_strides = _c_strides(old_shapes)
+        new_strides = _c_strides(new_shapes)
         jobs = np.zeros((nnew, 4 + 3 * COPY_MAXDIM), dtype=np.int64)
-        jobs[:, 2] = res.rank
-        jobs[:, 4:4 + res.rank] = new_shapes
-        jobs[:, 4 + COPY_MAXDIM:4 + COPY_MAXDIM + res.rank] = _c_strides(new_shapes)
+        jobs[:, 2] = self.rank
         src_off = self._offsets[old_idx].copy()
         for a in range(self.rank):
             src_off += old_start[:, a] * old_strides[:, a]
-            inner = np.ones(nnew, dtype=np.int64)
-            for na in reversed(new_of_old[a]):
-                jobs[:, 4 + 2 * COPY_MAXDIM + na] = inner * old_strides[:, a]
-                inner = inner * new_shapes[:, na]
+            group = list(new_of_old[a])
+            jobs[:, 4 + a] = np.prod(new_shapes[:, group], axis=1)
+            jobs[:, 4 + COPY_MAXDIM + a] = new_strides[:, group[-1]]
+            jobs[:, 4 + 2 * COPY_MAXDIM + a] = old_strides[:, a]
         jobs[:, 0] = res._offsets
         jobs[:, 1] = src_off
         sizes = np.prod(new_shapes, axis=1)
@@ -922,19 +935,37 @@ class Array:
         self._skey = None
         if self.stored_blocks == 0:
             return self
-        if self.rank > COPY_MAXDIM:
-            raise NotImplementedError("transpose of rank > %d" % COPY_MAXDIM)
         new_shapes = old_shapes[:, axes_arr]
         sizes = np.prod(new_shapes, axis=1)
         # blocks whose memory order does not change need no copy; still repack everything into a new arena
         new_offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        # legs that stay neighbours in the same order move as one copy dim
+        runs = [[0]]
+        for i in range(1, self.rank):
+            if axes[i] == axes[i - 1] + 1:
+                runs[-1].append(i)
+            else:
+                runs.append([i])
+        nd = len(runs)
+        if nd > COPY_MAXDIM:        # tensors of rank > 6 only occur in set-up utilities (grouping sites, H conversions)
+            host = dev.to_host(self._arena)
+            out = np.empty(int(np.sum(sizes)), dtype=self.dtype)
+            for b in range(self.stored_blocks):
+                blk = host[self._offsets[b]:self._offsets[b] + sizes[b]].reshape(tuple(old_shapes[b]))
+                out[new_offs[b]:new_offs[b] + sizes[b]] = np.transpose(blk, axes).reshape(-1)
+            self._arena = dev.to_device(out)
+            self._offsets = new_offs
+            return self
+        new_str_full = _c_strides(new_shapes)
+        old_str_perm = old_strides[:, axes_arr]
         jobs = np.zeros((self.stored_blocks, 4 + 3 * COPY_MAXDIM), dtype=np.int64)
         jobs[:, 0] = new_offs
         jobs[:, 1] = self._offsets
-        jobs[:, 2] = self.rank
-        jobs[:, 4:4 + self.rank] = new_shapes
-        jobs[:, 4 + COPY_MAXDIM:4 + COPY_MAXDIM + self.rank] = _c_strides(new_shapes)
-        jobs[:, 4 + 2 * COPY_MAXDIM:4 + 2 * COPY_MAXDIM + self.rank] = old_strides[:, axes_arr]
+        jobs[:, 2] = nd
+        for d, run in enumerate(runs):
+            jobs[:, 4 + d] = np.prod(new_shapes[:, run], axis=1)
+            jobs[:, 4 + COPY_MAXDIM + d] = new_str_full[:, run[-1]]
+            jobs[:, 4 + 2 * COPY_MAXDIM + d] = old_str_perm[:, run[-1]]
         new_arena = dev.empty(int(np.sum(sizes)), self.dtype)
         _run_copy(self.dtype, jobs, int(np.max(sizes)), self._arena, new_arena)
         self._arena = new_arena
@@ -1201,10 +1232,12 @@ class Array:
     def iproject(self, mask, axes):
         """Keep only the indices selected by ``mask`` (bool or index array) on the given ``axes``
         (reference :1914).  Returns ``(map_qind, block_masks)`` lists per axis; ``self`` is modified."""
+        if not _is_iterable(axes):          # a single axis goes with a single mask (reference :1946)
+            mask = [mask]
         axes = self.get_leg_indices(_to_iterable(axes))
         mask = list(mask)
-        if len(mask) == 0 or not _is_iterable(mask[0]):       # a single mask, not a list of masks
-            mask = [mask]
+        if len(axes) == 0:
+            return [], []
         if len(axes) != len(mask):
             raise ValueError("len(axes) != len(mask)")
         masks = []
@@ -1212,7 +1245,7 @@ class Array:
             m = np.asarray(m)
             if m.dtype != np.bool_:
                 mm = np.zeros(self.shape[a], dtype=np.bool_)
-                mm[m] = True
+                np.put(mm, m, True)
                 m = mm
             if m.shape != (self.shape[a],):
                 raise ValueError("mask has wrong length")
