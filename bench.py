@@ -1,26 +1,37 @@
 #!/usr/bin/env python
-"""bench.py -- two-site DMRG sweep time on MI355X (BASELINE.json metric).
+"""bench.py -- two-site DMRG sweep time (+ energy / singular-value error) on MI355X: BASELINE.json's metric.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--chi CHI] [--L L]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config heis2048|xxz512|hubbard1024|tebd1024] [--chi CHI] [--L L]
 
-Workload (config["workload"]): spin-1/2 Heisenberg chain (XXZ, Jxx=Jz=1, hz=0, Sz conserved), L=100,
-two-site DMRG at bond dimension chi (default 2048, BASELINE.json's headline configuration; fits one
-GPU), Lanczos with N_min=N_max=8 (fixed work per bond, as tests/benchmark/dmrg_infinite.py:36 of the
-reference does), svd_min=1e-14 (the reference's default, so that the bond dimension really saturates at chi), no mixer.  A "step" is ONE FULL SWEEP = 2(L-2) = 196 two-site bond
-updates (effective-H build, 8-step Lanczos, block SVD + truncation, environment update).
+Default workload (``config["workload"]``): spin-1/2 Heisenberg chain (XXZ, Jxx=Jz=1, hz=0, Sz conserved), L=100, two-site
+DMRG at bond dimension chi=2048 (BASELINE.json's headline configuration; fits one GPU), Lanczos with N_min=N_max=8 (fixed
+work per bond, as the reference's tests/benchmark/dmrg_infinite.py:36 does), svd_min=1e-14, no mixer.  A "step" is ONE FULL
+SWEEP = 2(L-2) = 196 two-site bond updates (effective-H build, 8-step Lanczos, block SVD + truncation, environment update).
+The other BASELINE configurations are selected with ``--config`` (same JSON shape): ``xxz512`` (config 2), ``hubbard1024``
+(config 4: Fermi-Hubbard ladder 2x40, U(1)xU(1)), ``tebd1024`` (config 5: TFI L=64, parity, complex128 real-time TEBD of
+order 2; a step is one ``evolve_step`` over all bonds of a random chi=1024 state, i.e. at saturated bond dimension).
 
-The MPS is synthetic in the sense of the contract: there is no checkpoint to load, so the state is grown
-on the device from the Neel product state by an (untimed) chi ramp of single sweeps
-chi = 64, 128, ..., chi/2, followed by W warm-up sweeps at the target chi; then exactly K sweeps are
-timed between barrier + torch.cuda.synchronize() on both sides.
+The MPS is synthetic in the sense of the contract: there is no checkpoint to load, so the state is grown on the device from
+the Neel product state by an (untimed) chi ramp of single sweeps chi = 64, 64, 128, ..., chi/2, followed by W warm-up
+sweeps at the target chi; then exactly K sweeps are timed between barrier + torch.cuda.synchronize() on both sides.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU over RCCL): the Lanczos matvec is
-sharded over the ranks by rows of theta' (tenpy_amd/algorithms/sharded.py: row panels of both GEMM steps +
-one all-gather per matvec), the charge blocks of every SVD are distributed (one all-gather); environment update and
-the Lanczos vector kernels are replicated.  Total work is fixed -> "scaling": "strong"; the value is the max over ranks of the time per sweep.
+One JSON line on rank 0:
+* ``roofline`` describes the DOMINANT kernel family of the timed region, the batched block SVD (``tpa_svd_batch``): HIP
+  events on the launch stream around every call, algorithmic flops ``4 m^2 n + 8 m n^2 + 9 n^3`` and bytes
+  ``8 (mn + mk + kn + k)`` per charge block, against the fp64 MFMA peak and (``hbm_frac``) the HBM peak;
+  ``roofline_gemm`` is the same for the grouped MFMA GEMM (tensordot / Lanczos matvec / environment update).
+* parity at scale (N=1): ``sv_max_rel_err`` (block SVD of the centre-bond theta vs LAPACK through the numpy oracle,
+  max |dS| / S_max), ``matvec_max_rel_err``, ``E0_rel_err`` (8-step Lanczos energy of the centre bond vs the oracle's
+  Lanczos on the same operator) and the top-level ``energy_err`` = |E - E_ref| / |E_ref| against the energy the REFERENCE
+  (TeNPy with its compiled helper, run offline in the build container with the same protocol) reaches after the same
+  sweep (``profiles/r02_cpu_reference.json``); ``null`` when that file has no entry for this configuration / sweep.
+* ``cpu_baseline``: kind "reference (offline, 8 cores)" = TeNPy itself, measured in the build container
+  (``scripts/cpu_reference_baseline.py``; it cannot travel to the GPU box), with the numpy oracle timed live on this
+  host's cores on a bounded sample as the secondary field ``port``.
 
-One JSON line on rank 0; `roofline` is for the grouped MFMA GEMM (tensordot / Lanczos matvec kernel),
-`cpu_baseline` is the numpy oracle (oracle/npc_oracle.py) timed on the host cores on a bounded sample.
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU over RCCL): the Lanczos matvec is sharded over the
+ranks by rows of theta' (tenpy_amd/algorithms/sharded.py) and the charge blocks of every SVD are distributed (DESIGN.md
+section 5).  Total work is fixed -> "scaling": "strong"; the value is the max over ranks of the time per sweep.
 """
 import argparse
 import json
@@ -35,6 +46,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix peak (vendor figure); not in the microarch guide
 PEAK_HBM_GBS = 8000.0
+CPU_REF = os.path.join(ROOT, 'profiles', 'r02_cpu_reference.json')
 
 
 def parse():
@@ -42,12 +54,22 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--chi', type=int, default=int(os.environ.get('TPA_BENCH_CHI', 2048)))
-    ap.add_argument('--L', type=int, default=100)
+    ap.add_argument('--config', default=os.environ.get('TPA_BENCH_CONFIG', 'heis2048'),
+                    choices=['heis2048', 'xxz512', 'hubbard1024', 'tebd1024'])
+    ap.add_argument('--chi', type=int, default=int(os.environ.get('TPA_BENCH_CHI', 0)))
+    ap.add_argument('--L', type=int, default=0)
     ap.add_argument('--lanczos-N', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-bonds', type=int, default=2)
     return ap.parse_args()
+
+
+CONFIGS = {     # name: (default L, default chi, description)
+    'heis2048': (100, 2048, "spin-1/2 Heisenberg chain (XXZ Jxx=Jz=1, Sz conserved)"),
+    'xxz512': (100, 512, "spin-1/2 XXZ chain Jxx=Jz=1 (Sz conserved)"),
+    'hubbard1024': (80, 1024, "Fermi-Hubbard ladder 2x40, t=1, U=8, half filling, charges (N, 2Sz)"),
+    'tebd1024': (64, 1024, "TFI chain J=1, g=1.5 (parity conserved), real-time TEBD order 2, dt=0.05, complex128"),
+}
 
 
 def oracle_tensor(arr):
@@ -57,50 +79,160 @@ def oracle_tensor(arr):
     return orc.OTensor(legs, arr.qtotal, arr._qdata, arr._data)
 
 
-def cpu_baseline(eng, args, gpu_bond_s):
-    """Time the numpy oracle on `cpu_sample_bonds` centre-bond updates of the SAME state: 8 effective-H
-    matvecs (two block-sparse tensordots each) + the block SVD of theta.  Returns the cpu_baseline dict."""
-    from oracle import npc_oracle as orc
-    from tenpy_amd.algorithms.mps_common import TwoSiteH
-    L = eng.psi.L
-    n_b = max(1, args.cpu_sample_bonds)
-    bonds = [L // 2 - 1 + i for i in range(n_b)]
-    t_cpu, errs = 0., []
-    for i0 in bonds:
-        eff = TwoSiteH(eng.env, i0, factored=False)       # the fused form LHeff . theta . RHeff that the oracle restates
-        theta = eff.combine_theta(eng.psi.get_theta(i0, n=2))
-        fac = TwoSiteH(eng.env, i0)                       # what the timed sweeps ran (factored when W has scalar blocks)
-        want = fac.prepare_svd(fac.matvec(fac.combine_theta(eng.psi.get_theta(i0, n=2))))
-        LH, RH, th = oracle_tensor(eff.LHeff), oracle_tensor(eff.RHeff), oracle_tensor(theta)
-        t0 = time.time()
-        v = th
-        for _ in range(args.lanczos_N):
-            v = orc.matvec_two_site(LH, RH, v)
-            nv = orc.norm(v)
-            v = orc.scale(v, 1. / nv)
-        blocked, _ = orc.combine_legs(th, [[0], [1]], [th.legs[0].qconj, th.legs[1].qconj]) \
-            if not _legs_blocked(th) else (th, None)
-        orc.svd(blocked)
-        t_cpu += time.time() - t0
-        first = orc.matvec_two_site(LH, RH, th)
-        ref = first.to_dense()
-        errs.append(float(np.max(np.abs(want.to_ndarray() - ref)) / max(np.max(np.abs(ref)), 1e-300)))
-    per_bond = t_cpu / n_b
-    n_bonds = 2 * (L - 2)
-    return {"value": per_bond * n_bonds, "unit": "s/sweep", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d centre bond updates (%d Lanczos matvecs + block SVD each) with the numpy oracle on the "
-                      "same state, %.2f s CPU per bond, extrapolated x%d bonds; GPU same bonds %.4f s per bond; "
-                      "max |matvec_gpu - matvec_oracle| / max|.| = %.2e" % (n_b, args.lanczos_N, per_bond, n_bonds,
-                                                                            gpu_bond_s, max(errs)),
-            "matvec_max_rel_err": max(errs)}
-
-
 def _legs_blocked(t):
     return all(len({tuple(c) for c in l.charges.tolist()}) == len(l.charges) for l in t.legs)
 
 
+def parity_and_port(eng, args, gpu_bond_s):
+    """On `cpu_sample_bonds` centre bonds of the SAME state: run the numpy oracle (8 effective-H matvecs + block SVD; its
+    time is the `port` baseline) and compare the device results with it.  Returns (port dict, parity dict)."""
+    from oracle import npc_oracle as orc
+    from tenpy_amd.algorithms.mps_common import TwoSiteH
+    from tenpy_amd.linalg import np_conserved as npc
+    from tenpy_amd.linalg.krylov_based import LanczosGroundState
+    L = eng.psi.L
+    n_b = max(1, args.cpu_sample_bonds)
+    bonds = [L // 2 - 1 + i for i in range(n_b)]
+    t_cpu, mv_err, sv_err, e0_err = 0., [], [], []
+    for i0 in bonds:
+        eff = TwoSiteH(eng.env, i0, factored=False)       # the fused form LHeff . theta . RHeff that the oracle restates
+        theta = eff.combine_theta(eng.psi.get_theta(i0, n=2))
+        fac = TwoSiteH(eng.env, i0)                       # what the timed sweeps ran (factored when W has scalar blocks)
+        th_fac = fac.combine_theta(eng.psi.get_theta(i0, n=2))
+        want = fac.prepare_svd(fac.matvec(th_fac))
+        LH, RH, th = oracle_tensor(eff.LHeff), oracle_tensor(eff.RHeff), oracle_tensor(theta)
+        # --- device side of the comparison
+        U, S_dev, VH = npc.svd(fac.prepare_svd(th_fac), inner_labels=['vR', 'vL'])
+        E_dev, _, N_dev = LanczosGroundState(fac, th_fac, {'N_min': args.lanczos_N, 'N_max': args.lanczos_N}).run()
+        # --- oracle: timed part = N matvecs (+ the vector work of a Lanczos step) + block SVD
+        t0 = time.time()
+        E_orc, _, N_orc = orc.lanczos_gs(lambda v: orc.matvec_two_site(LH, RH, v), th, N_min=args.lanczos_N, N_max=args.lanczos_N)
+        blocked = th if _legs_blocked(th) else orc.combine_legs(th, [[0], [1]], [th.legs[0].qconj, th.legs[1].qconj])[0]
+        _, S_orc, _ = orc.svd(blocked)
+        t_cpu += time.time() - t0
+        first = orc.matvec_two_site(LH, RH, th).to_dense()
+        mv_err.append(float(np.max(np.abs(want.to_ndarray() - first)) / max(np.max(np.abs(first)), 1e-300)))
+        a, b = np.sort(np.asarray(S_dev))[::-1], np.sort(np.asarray(S_orc))[::-1]
+        n = min(len(a), len(b))
+        sv_err.append(float(np.max(np.abs(a[:n] - b[:n])) / b[0]))
+        e0_err.append(abs(E_dev - E_orc) / abs(E_orc))
+    per_bond = t_cpu / n_b
+    n_bonds = 2 * (L - 2)
+    port = {"value": per_bond * n_bonds, "unit": "s/sweep", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d centre bond updates (%d-step Lanczos + block SVD each) with the numpy oracle on the same state, "
+                      "%.2f s CPU per bond, extrapolated x%d bonds; GPU same bonds %.4f s per bond"
+                      % (n_b, args.lanczos_N, per_bond, n_bonds, gpu_bond_s)}
+    parity = {"sv_max_rel_err": max(sv_err), "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err),
+              "parity_sample": "centre bonds %r of the timed state: device block SVD vs LAPACK (oracle), factored device matvec "
+                               "vs oracle LHeff.theta.RHeff, %d-step Lanczos energy vs the oracle's Lanczos" % (bonds, args.lanczos_N)}
+    return port, parity
+
+
+def reference_entry(config_name, chi):
+    """Offline numbers of TeNPy itself for this configuration (profiles/r02_cpu_reference.json), or None."""
+    try:
+        with open(CPU_REF) as f:
+            ref = json.load(f)
+    except Exception:
+        return None, None
+    return ref.get('dmrg%d' % chi) if config_name in ('heis2048', 'xxz512') else None, ref
+
+
+def build_dmrg(args, world, name):
+    from tenpy_amd.algorithms.dmrg import TwoSiteDMRGEngine
+    from tenpy_amd.networks.mps import MPS
+    L, chi = args.L, args.chi
+    if name == 'hubbard1024':
+        from tenpy_amd.models.hubbard import hubbard_ladder_mpo, spinful_fermion_leg
+        H = hubbard_ladder_mpo(L // 2, 1., 8., 0.)
+        _, p = spinful_fermion_leg()
+        psi = MPS.from_product_state([p] * L, [1, 2] * (L // 2))
+    else:
+        from tenpy_amd.models.spin_chains import spin_half_leg, xxz_chain_mpo
+        H = xxz_chain_mpo(L, 1., 1., 0.)
+        _, p = spin_half_leg('Sz')
+        psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
+    eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': min(64, chi), 'svd_min': 1.e-14},
+                                     'lanczos_params': {'N_min': 2, 'N_max': 20}, 'shard_matvec': world > 1,
+                                     'profile': bool(os.environ.get('TPA_BENCH_PHASES'))})
+    # ---- untimed: grow the state (two quick sweeps at small chi, then double chi per sweep)
+    energies = []
+    c = min(64, chi)
+    for _ in range(2):
+        eng.sweep()
+        energies.append(eng.sweep_stats['E'][-1])
+    while c < chi:
+        c = min(2 * c, chi)
+        eng.trunc_params['chi_max'] = c
+        if c == chi:
+            break
+        eng.sweep()
+        energies.append(eng.sweep_stats['E'][-1])
+    eng.lanczos_params = {'N_min': args.lanczos_N, 'N_max': args.lanczos_N}
+    return eng, energies
+
+
+def build_tebd(args):
+    """Random right-canonical MPS at the full bond dimension (two parity sectors of chi/2 each, complex128) so that the
+    timed evolve_step runs at saturated chi from the first step, as BASELINE config 5 specifies."""
+    from tenpy_amd.algorithms.tebd import TEBDEngine
+    from tenpy_amd.models.spin_chains import spin_half_leg
+    from tenpy_amd.networks.mps import MPS
+    L, chi = args.L, args.chi
+    J, g = 1., 1.5
+    _, p = spin_half_leg('parity')
+    sx, sz, I2 = np.array([[0., 1.], [1., 0.]]), np.diag([-1., 1.]), np.eye(2)
+    h_bonds = [None]
+    for i in range(1, L):
+        gl = g if i - 1 == 0 else g / 2
+        gr = g if i == L - 1 else g / 2
+        h_bonds.append((-J * np.kron(sx, sx) - gl * np.kron(sz, I2) - gr * np.kron(I2, sz)).reshape(2, 2, 2, 2))
+    psi = random_right_canonical_mps(p, L, chi, np.complex128, seed=1)
+    return TEBDEngine(psi, h_bonds, {'dt': 0.05, 'compute_err': False, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
+
+
+def random_right_canonical_mps(p, L, chi, dtype, seed):
+    """Random MPS in right-canonical ('B') form whose bonds have min(chi, d**i, d**(L-i)) states spread evenly over the charge
+    sectors that the fusion rules allow: built from the right edge, site tensor = the isometric factor of an LQ
+    decomposition (device block QR) of a random (vL) x (p.vR) block matrix."""
+    from tenpy_amd.linalg import np_conserved as npc
+    from tenpy_amd.linalg.charges import LegCharge, LegPipe
+    from tenpy_amd.networks.mps import MPS
+    rng = np.random.default_rng(seed)
+    chinfo = p.chinfo
+    d = p.ind_len
+    cplx = np.dtype(dtype).kind == 'c'
+
+    def rnd(size):
+        x = rng.standard_normal(size)
+        return x + 1.j * rng.standard_normal(size) if cplx else x
+    vR = LegCharge.from_qflat(chinfo, [chinfo.make_valid()], qconj=-1)
+    Bs, Ss = [None] * L, [None] * (L + 1)
+    Ss[L] = np.ones(1)
+    for i in reversed(range(L)):
+        pipe = LegPipe([p, vR], qconj=-1)
+        n_q = pipe.get_block_sizes()
+        total = int(min(chi, d ** min(i, 30), int(np.sum(n_q))))
+        sizes = np.minimum(n_q, total // len(n_q))
+        for q in np.argsort(-n_q):                  # hand the remainder to the sectors that still have room
+            room = min(int(n_q[q] - sizes[q]), total - int(np.sum(sizes)))
+            sizes[q] += max(room, 0)
+        keep = sizes > 0
+        vL = LegCharge.from_qind(chinfo, np.concatenate([[0], np.cumsum(sizes[keep])]), pipe.charges[keep], qconj=+1)
+        M = npc.Array.from_func(rnd, [vL, pipe], dtype=dtype, qtotal=None, shape_kw='size', labels=['vL', '(p.vR)'])
+        _, Q = npc.lq(M, inner_labels=['vR', 'vL'])
+        Bs[i] = Q.split_legs(1)
+        vR = Bs[i].get_leg('vL').conj()
+        s = np.abs(rng.standard_normal(vR.ind_len)) + 0.1
+        Ss[i] = s / np.linalg.norm(s)
+    return MPS([p] * L, Bs, Ss, form='B')
+
+
 def main():
     args = parse()
+    L0, chi0, desc = CONFIGS[args.config]
+    args.L = args.L or L0
+    args.chi = args.chi or chi0
     import torch
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -117,100 +249,138 @@ def main():
         dist = None
         torch.cuda.set_device(0)
 
-    from tenpy_amd.algorithms.dmrg import TwoSiteDMRGEngine
     from tenpy_amd.linalg import np_conserved as npc
-    from tenpy_amd.models.spin_chains import spin_half_leg, xxz_chain_mpo
-    from tenpy_amd.networks.mps import MPS
-
     L, chi = args.L, args.chi
-    H = xxz_chain_mpo(L, 1., 1., 0.)
-    _, p = spin_half_leg('Sz')
-    psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
-    eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': min(64, chi), 'svd_min': 1.e-14},
-                                     'lanczos_params': {'N_min': 2, 'N_max': 20}, 'shard_matvec': world > 1,
-                                     'profile': bool(os.environ.get('TPA_BENCH_PHASES'))})
-    # ---- untimed: grow the state (two quick sweeps at small chi, then double chi per sweep)
+    is_tebd = args.config == 'tebd1024'
     t_prep = time.time()
-    c = min(64, chi)
-    eng.sweep()
-    eng.sweep()
-    while c < chi:
-        c = min(2 * c, chi)
-        eng.trunc_params['chi_max'] = c
-        if c == chi:
-            break
-        eng.sweep()
-    eng.lanczos_params = {'N_min': args.lanczos_N, 'N_max': args.lanczos_N}
+    if is_tebd:
+        eng, ramp_E = build_tebd(args), []
+        step = eng.evolve_step_order2
+    else:
+        eng, ramp_E = build_dmrg(args, world, args.config)
+        step = eng.sweep
+    sweep_E = list(ramp_E)
     for _ in range(args.warmup):
-        eng.sweep()
+        step()
+        if not is_tebd:
+            sweep_E.append(eng.sweep_stats['E'][-1])
     torch.cuda.synchronize()
     t_prep = time.time() - t_prep
 
-    eng.phase_time = {k: 0. for k in eng.phase_time}
-    # ---- timed region: exactly K sweeps
-    npc.gemm_timer.reset()
-    npc.gemm_timer.enabled = True
-    n0 = len(eng.update_stats['E_total'])
+    if not is_tebd:
+        eng.phase_time = {k: 0. for k in eng.phase_time}
+    # ---- timed region: exactly K steps
+    for tm in (npc.gemm_timer, npc.svd_timer):
+        tm.reset()
+        tm.enabled = True
+    n0 = 0 if is_tebd else len(eng.update_stats['E_total'])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(args.steps):
-        eng.sweep()
+        step()
+        if not is_tebd:
+            sweep_E.append(eng.sweep_stats['E'][-1])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.time() - t0
-    npc.gemm_timer.enabled = False
-    gemm_ms = npc.gemm_timer.collect()
+    for tm in (npc.gemm_timer, npc.svd_timer):
+        tm.enabled = False
+        tm.collect()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    s_per_sweep = elapsed / max(args.steps, 1)
-    E = eng.sweep_stats['E'][-1]
-    chi_reached = eng.sweep_stats['max_chi'][-1]
+    s_per_step = elapsed / max(args.steps, 1)
 
     if rank == 0:
-        gt = npc.gemm_timer
-        tflops = (gt.flops / (gemm_ms * 1e-3)) / 1e12 if gemm_ms > 0 else 0.
-        per_launch_ms = gemm_ms / max(gt.n_launch, 1)
-        traffic, traffic_note = None, None
-        try:     # L2-miss traffic of the matvec GEMM measured with rocprofv3 PMC passes (committed profile, not live)
-            with open(os.path.join(ROOT, 'profiles', 'r01_gemm_pmc_matvec_factored_chi2048.json')) as f:
-                pm = json.load(f)
-            if chi == 2048:
-                traffic, traffic_note = pm["traffic_bytes_per_launch"], pm["how"]
-        except Exception:
-            pass
-        roof = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                "kernel": "gemm_chain_kernel<f64, 64x64 | 128x128> (grouped chained MFMA GEMM: tensordot / Lanczos matvec / env update)",
-                "matvec_form": "factored: LP.theta (GEMM) -> W0 W1 blockwise (lincomb) -> .RP (GEMM); d=2 times fewer flops than LHeff.theta.RHeff",
-                "launches": gt.n_launch, "avg_launch_ms": per_launch_ms, "algorithmic_flops_per_launch": gt.flops / max(gt.n_launch, 1),
-                "algorithmic_bytes_per_launch": gt.bytes_min / max(gt.n_launch, 1),
-                "time_share_of_sweep": (gemm_ms * 1e-3) / max(elapsed, 1e-12)}
-        upd_t = eng.update_stats['time'][n0:]
-        mid = [t for i, t in zip(eng.update_stats['i0'][n0:], upd_t) if abs(i - L // 2) <= 1]
-        gpu_bond_s = float(np.mean(mid)) if mid else s_per_sweep / (2 * (L - 2))
-        out = {"metric": "DMRG sweep time (s), Heisenberg L=%d chi=%d" % (L, chi), "value": s_per_sweep, "unit": "s/sweep",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * s_per_sweep,
-               "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-               "data": "synthetic (state grown on-device from the Neel product state by an untimed chi ramp; no dataset/checkpoint)",
-               "config": {"workload": "two-site DMRG sweep, spin-1/2 Heisenberg chain (XXZ Jxx=Jz=1, Sz conserved), L=%d, "
-                                      "chi_max=%d (reached %d), Lanczos N=%d per bond, svd_min=1e-14, no mixer, combine=True interface (theta fused for the SVD; matvec applied in factored form); 1 step = 1 sweep = %d bond updates"
-                                      % (L, chi, chi_reached, args.lanczos_N, 2 * (L - 2)),
-                          "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge blocks distributed (LPT + all-gather), env update replicated" % world},
-               "E": E, "chi_reached": chi_reached, "prep_s": t_prep, "roofline": roof}
-        if os.environ.get('TPA_BENCH_PHASES'):   # diagnostic run only: the phase timers synchronise the device
-            out["phases_s"] = {k: round(v / max(args.steps, 1), 4) for k, v in eng.phase_time.items()}
-            out["svd_stats"] = dict(npc.svd_stats)
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the other ranks would idle at the barrier)
-            try:
-                out["cpu_baseline"] = cpu_baseline(eng, args, gpu_bond_s)
-            except Exception as e:  # the baseline must never kill the bench line
-                out["cpu_baseline"] = {"value": None, "unit": "s/sweep", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
+        def roof(tm, kernel, extra):
+            sec = tm.ms * 1e-3
+            tflops = tm.flops / sec / 1e12 if sec > 0 else 0.
+            gbs = tm.bytes_min / sec / 1e9 if sec > 0 else 0.
+            r = {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                 "hbm_achieved_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "kernel": kernel, "launches": tm.n_launch,
+                 "avg_launch_ms": tm.ms / max(tm.n_launch, 1), "algorithmic_flops_per_launch": tm.flops / max(tm.n_launch, 1),
+                 "algorithmic_bytes_per_launch": tm.bytes_min / max(tm.n_launch, 1),
+                 "time_share_of_timed_region": sec / max(elapsed, 1e-12)}
+            r.update(extra)
+            return r
+        roof_svd = roof(npc.svd_timer, "tpa_svd_batch: rank-revealing pivoted QR (qrp_panel / qrp_update) + one-sided block Jacobi "
+                                       "(svd_round_fused) + Q application, all charge blocks of one npc.svd per call",
+                        {"traffic_note": "HBM traffic is not measured live; PMC passes of the same call are in profiles/ (r02_*pmc*) when present",
+                         "flop_model": "4 m^2 n + 8 m n^2 + 9 n^3 per block (m >= n), x4 for complex128 (SURVEY 8(d))"})
+        roof_gemm = roof(npc.gemm_timer, "gemm_chain_kernel<f64 | c128> (grouped chained MFMA GEMM: tensordot / Lanczos matvec / env update)",
+                         {"flop_model": "sum over GEMM links of c m k n, c = 2 real / 8 complex"})
+        n_upd = (L - 1) if is_tebd else 2 * (L - 2)
+        unit = "s/step" if is_tebd else "s/sweep"
+        what = "TEBD evolve_step time (s), TFI" if is_tebd else \
+            "DMRG sweep time (s) + GS energy err, " + ("Heisenberg" if args.config == 'heis2048' else args.config)
+        out = {"metric": "%s L=%d chi=%d" % (what, L, chi),
+               "value": s_per_step, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * s_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+               "dtype": "c128" if is_tebd else "f64",
+               "data": "synthetic (random right-canonical MPS at full chi)" if is_tebd else
+                       "synthetic (state grown on-device from the Neel product state by an untimed chi ramp; no dataset/checkpoint)",
+               "config": {"workload": "%s, L=%d, chi_max=%d; %s; 1 step = %d bond updates"
+                          % (desc, L, chi, ("order-2 Suzuki-Trotter step, svd_min=1e-12" if is_tebd else
+                                            "two-site DMRG sweep, Lanczos N=%d per bond, svd_min=1e-14, no mixer, combine=True "
+                                            "interface (theta fused for the SVD)" % args.lanczos_N), n_upd),
+                          "name": args.config,
+                          "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge "
+                                                                    "blocks distributed (LPT + all-gather), env update replicated" % world},
+               "prep_s": t_prep, "roofline": roof_svd, "roofline_gemm": roof_gemm, "energy_err": None}
+        if not is_tebd:
+            out["E"] = eng.sweep_stats['E'][-1]
+            out["chi_reached"] = eng.sweep_stats['max_chi'][-1]
+            out["E_sweeps"] = sweep_E
+            ref, ref_all = reference_entry(args.config, chi)
+            if ref is not None and L == 100 and args.lanczos_N == 8:
+                # the reference ran the same protocol; its sweep list starts with the same ramp
+                ref_E = [e['E'] for e in ref['sweeps']]
+                idx = min(len(sweep_E), len(ref_E)) - 1
+                out["energy_err"] = abs(sweep_E[idx] - ref_E[idx]) / abs(ref_E[idx])
+                out["energy_err_note"] = ("|E - E_ref| / |E_ref| after sweep %d of the common protocol (ramp + %d sweeps at chi=%d); "
+                                          "E_ref = %.13f from TeNPy (compiled helper) run offline, profiles/r02_cpu_reference.json"
+                                          % (idx + 1, idx + 1 - len(ramp_E), chi, ref_E[idx]))
+            else:
+                out["energy_err_note"] = "no offline TeNPy run of this configuration in profiles/r02_cpu_reference.json"
+            if os.environ.get('TPA_BENCH_PHASES'):   # diagnostic run only: the phase timers synchronise the device
+                out["phases_s"] = {k: round(v / max(args.steps, 1), 4) for k, v in eng.phase_time.items()}
+                out["svd_stats"] = dict(npc.svd_stats)
+            if world == 1:
+                upd_t = eng.update_stats['time'][n0:]
+                mid = [t for i, t in zip(eng.update_stats['i0'][n0:], upd_t) if abs(i - L // 2) <= 1]
+                gpu_bond_s = float(np.mean(mid)) if mid else s_per_step / n_upd
+                base = None
+                if ref_all is not None and args.config in ('heis2048', 'xxz512'):
+                    envi = ref_all.get('environment', {})
+                    if ref is not None:
+                        base = {"value": ref['s_per_sweep_best'], "unit": unit, "cores": envi.get('cores'), "kind": "reference",
+                                "where": "offline: build container, %s host cores" % envi.get('cores'),
+                                "sample": "TeNPy %s with its compiled _npc_helper (OpenBLAS), set_level(3): best FULL sweep at "
+                                          "chi=%d of the same protocol (%s)" % (envi.get('tenpy'), chi, os.path.basename(CPU_REF))}
+                    elif chi == 2048 and 'bond2048' in ref_all:
+                        b = ref_all['bond2048']
+                        base = {"value": b['s_per_sweep_extrapolated'], "unit": unit, "cores": envi.get('cores'), "kind": "reference",
+                                "where": "offline: build container, %s host cores" % envi.get('cores'),
+                                "sample": "TeNPy %s, compiled helper: %.2f s per centre-bond update at chi=2048 (operands with the "
+                                          "block structure of the real state) x 196 (%s)"
+                                          % (envi.get('tenpy'), b['s_per_bond_best'], os.path.basename(CPU_REF))}
+                if not args.no_cpu_baseline:
+                    try:
+                        port, parity = parity_and_port(eng, args, gpu_bond_s)
+                        out.update(parity)
+                    except Exception as e:  # the baseline must never kill the bench line
+                        port = {"value": None, "unit": unit, "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+                    if base is None:
+                        base = port             # no offline TeNPy number for this configuration: the live oracle is the baseline
+                    else:
+                        base["port"] = port
+                if base is not None:
+                    out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1804,6 +1804,29 @@ class KernelTimer:
 
 
 gemm_timer = KernelTimer()
+
+
+class _Work:
+    """What KernelTimer.end accumulates (algorithmic flops / bytes of one device call)."""
+    __slots__ = ('flops', 'bytes_min')
+
+    def __init__(self, flops, bytes_min):
+        self.flops, self.bytes_min = flops, bytes_min
+
+
+# same for every `tpa_svd_batch` call (the dominant kernel family of a DMRG sweep).  Algorithmic work as SURVEY 8(d) defines
+# it for an m x n block with k = min(m, n): flops = 4 m^2 n + 8 m n^2 + 9 n^3 for m >= n (gesdd with vectors; x4 complex),
+# bytes_min = itemsize (m n + m k + k n + k).
+svd_timer = KernelTimer()
+
+
+def svd_work(ms, ns, itemsize, cplx):
+    big, small = np.maximum(ms, ns).astype(np.float64), np.minimum(ms, ns).astype(np.float64)
+    flops = np.sum(4. * big * big * small + 8. * big * small * small + 9. * small ** 3) * (4. if cplx else 1.)
+    nbytes = itemsize * np.sum(big * small * 3. + small)
+    return _Work(float(flops), float(nbytes))
+
+
 _tile_shapes = {}
 
 
@@ -2351,7 +2374,9 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
         if np.any(np.isnan(S_host)):
             raise ValueError("NaN in S: " + str(np.sum(np.isnan(S_host))))
     else:
+        ev = svd_timer.begin()
         S_host = _svd_batch_robust(L, code, jobs, nblk, a._arena, U_arena, S_dev, V_arena, sweeps)
+        svd_timer.end(ev, svd_work(ms, ns, a.dtype.itemsize, a.dtype.kind == 'c') if ev is not None else None)
     svd_stats['calls'] += 1
     svd_stats['sweeps'] += sweeps.value
     svd_stats['max_block'] = max(svd_stats['max_block'], int(np.max(ks)))

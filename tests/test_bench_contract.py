@@ -40,7 +40,11 @@ def test_bench_json_contract(monkeypatch):
     c = out['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
-    assert c['kind'] in ('reference', 'port') and c['value'] > 0 and c['matvec_max_rel_err'] < 1e-10
+    assert c['kind'] in ('reference', 'port') and c['value'] > 0
+    # parity at scale rides on the same line ("report parity at scale in the bench line")
+    assert out['matvec_max_rel_err'] < 1e-10 and out['sv_max_rel_err'] < 1e-10 and out['E0_rel_err'] < 1e-10
+    assert 'energy_err' in out and 'roofline_gemm' in out
+    assert 'svd' in r['kernel'] and r['launches'] > 0
     assert abs(out['E'] - (-5.142090632841)) < 1e-6          # XXZ Jz=1, L=12 ground state energy (exact: -5.1420906328)
 
 
