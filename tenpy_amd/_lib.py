@@ -69,6 +69,16 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise BackendError("tenpy_amd: %s not built; run `python -m tenpy_amd._build`" % path)
         _build.build()
+    elif build_if_missing and os.path.exists(_build.HIPCC) and os.path.isdir(_build.CSRC):
+        # no-op unless a source under csrc/ is newer than its object: a stale .so is never loaded silently.  One process
+        # at a time (N ranks of a torchrun launch all come through here).
+        import fcntl
+        with open(os.path.join(_build.OUT_DIR, '.build.lock'), 'w') as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                _build.build()
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGS.items():
         f = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure

@@ -194,6 +194,7 @@ def Array_itranspose(self, axes=None):
 
 
 def Array_iadd_prefactor_other(self, prefactor, other):
+    other = other._transpose_same_labels(self._labels)
     if self.rank != other.rank:
         raise ValueError("different rank!")
     for sl, ol in zip(self.legs, other.legs):

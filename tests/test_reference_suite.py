@@ -25,10 +25,10 @@ ROOT = os.path.dirname(HERE)
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'tests')), reason="reference tree not available")
 
 
-def run_reference_tests(args, timeout=3000):
+def run_reference_tests(args, timeout=3000, plugin='refsuite_plugin'):
     env = dict(os.environ)
     env['PYTHONPATH'] = os.pathsep.join([HERE, ROOT, REF, env.get('PYTHONPATH', '')])
-    cmd = [sys.executable, '-m', 'pytest', '-p', 'refsuite_plugin', '-p', 'no:cacheprovider', '-q', '-x'] + list(args)
+    cmd = [sys.executable, '-m', 'pytest', '-p', plugin, '-p', 'no:cacheprovider', '-q', '-x'] + list(args)
     res = subprocess.run(cmd, cwd=os.path.join(REF, 'tests'), env=env, capture_output=True, text=True, timeout=timeout)
     tail = (res.stdout[-3000:] + "\n" + res.stderr[-2000:])
     assert res.returncode == 0, "reference tests failed on the mirror:\n" + tail
@@ -46,6 +46,16 @@ FAST = [
 @pytest.mark.parametrize("args", FAST, ids=lambda a: a[0])
 def test_reference_linalg_tests_on_mirror(args):
     out = run_reference_tests(args)
+    assert ' passed' in out and ' failed' not in out
+
+
+def test_reference_tests_through_use_cython_hook():
+    """The fine-grained boundary (SURVEY 8(b) "what a replacement must export"): the reference keeps its own np_conserved and
+    finds ``tenpy_amd/_npc_helper.py`` through ``tools/optimization.py:262 use_cython`` -- all 16 decorated names, docstring
+    check included (the plugin asserts that the workers really are ours).  Here ``test_expm`` stays in: with its own
+    ``np_conserved`` the reference's ``expm`` is scipy's."""
+    out = run_reference_tests(['test_charges.py', 'test_np_conserved.py', 'test_krylov_based.py', 'test_sparse.py'],
+                              plugin='refsuite_helper_plugin')
     assert ' passed' in out and ' failed' not in out
 
 
