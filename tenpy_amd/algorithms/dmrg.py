@@ -1,14 +1,15 @@
-"""DMRG engines -- the callers around the hot path, mirroring ``tenpy/algorithms/dmrg.py``.
+"""Minimal two-site DMRG driver for boxes WITHOUT TeNPy (the GPU test box: ``bench.py``, ``smoke()``, the ``-m gpu`` tests).
 
-Call sequence of the reference: ``Sweep.sweep`` (mps_common.py:345) -> ``prepare_update_local`` (:498) ->
-``update_local`` (dmrg.py:529: ``diag`` :672 = Lanczos or exact diagonalisation, ``mixed_svd`` :876 / :996, ``set_B``) ->
-``update_env`` (:569); main loop ``run`` / ``run_iteration`` / ``is_converged`` / ``stopping_criterion``.  Options keep the
-reference's names (``trunc_params``, ``lanczos_params``, ``chi_list``, ``max_sweeps``, ``min_sweeps``, ``max_E_err``,
-``max_S_err``, ``N_sweeps_check``, ``P_tol_to_trunc``, ``E_tol_to_trunc``, ``diag_method``, ``max_N_for_ED``, ``mixer``,
-``mixer_params``, ``chi_list_reactivates_mixer``, ``start_env``, ``update_env``, ``orthogonal_to``).  ``TwoSiteDMRGEngine``: finite and
-infinite MPS, density-matrix mixer or subspace expansion, checkpoint / resume, multi-GPU sharding of the matvec and the SVD.
-``SingleSiteDMRGEngine``: finite MPS, subspace expansion.  Not here: ``explicit_plus_hc`` MPOs, segment boundary conditions.
+Where TeNPy is installed, use TeNPy's own engines on the device mirror instead -- ``tenpy_amd.install.install()`` and then
+``tenpy.algorithms.dmrg.TwoSiteDMRGEngine`` etc. run unchanged (mixers, single-site DMRG, infinite systems, excited states:
+all of it is the reference's code, ``tests/test_reference_suite.py``).  This file only issues the npc calls of one bond update
+in the reference's order (``prepare_update_local`` -> ``update_local`` (Lanczos, ``svd_theta``, ``set_B``) ->
+``update_env``) for finite chains without a mixer, which is exactly BASELINE.json's timed workload.
+
+Options (names as in the reference): ``trunc_params``, ``lanczos_params``, ``chi_list`` (dict sweep -> chi_max);
+``shard_matvec`` (multi-GPU, ``algorithms/sharded.py``), ``profile`` (per-phase timers; synchronises the device).
 """
+import pickle
 import time
 
 import numpy as np
@@ -17,331 +18,128 @@ from ..linalg import np_conserved as npc
 from ..linalg.krylov_based import LanczosGroundState
 from ..linalg.truncation import svd_theta
 from ..networks.mpo import MPOEnvironment
-from .mps_common import DensityMatrixMixer, OneSiteH, SubspaceExpansion, TwoSiteH, full_diag_effH
+from .mps_common import TwoSiteH
 
-__all__ = ['TwoSiteDMRGEngine', 'SingleSiteDMRGEngine', 'run']
+__all__ = ['TwoSiteDMRGEngine']
 
 
 class TwoSiteDMRGEngine:
-    def __init__(self, psi, model_H, options, resume_data=None, orthogonal_to=None):
-        """``orthogonal_to``: list of MPS to orthogonalise against (excited states; reference ``Sweep.init_env`` :190,
-        ``_wrap_ortho_eff_H`` :524): the effective Hamiltonian becomes ``P H P`` with the projected states."""
-        self.psi = psi
-        self.H = model_H
+    def __init__(self, psi, model_H, options, resume_data=None):
+        if not psi.finite:
+            raise ValueError("the stand-alone driver handles finite chains; run TeNPy's engines on the mirror for the rest")
+        self.psi, self.H = psi, model_H
         self.options = options = dict(options)
         self.trunc_params = dict(options.get('trunc_params', {}))
         self.lanczos_params = dict(options.get('lanczos_params', {}))
-        self.chi_list = options.get('chi_list', None)
-        self.combine = options.get('combine', True)
+        self.chi_list = options.get('chi_list')
         self.env = MPOEnvironment(psi, model_H)
-        from ..networks.mps import MPSEnvironment
-        self.ortho_to_envs = [MPSEnvironment(psi, o) for o in (orthogonal_to or [])]
         self.sweeps = 0
-        self.update_stats = {k: [] for k in ['i0', 'E_total', 'N_lanczos', 'time', 'err', 'chi', 'flops', 'bytes']}
-        self.sweep_stats = {k: [] for k in ['sweep', 'E', 'S', 'time', 'max_trunc_err', 'max_chi', 'N_updates']}
-        self.E_trunc_list = []
-        self._entropy_approx = [None] * psi.L     # entropy of the approximate Schmidt values, left of a given site
-        self._meas_E_trunc = False
-        self._in_iteration = False
-        self.n_optimize = 2
-        self.finite = psi.finite
-        self.N_sweeps_check = options.get('N_sweeps_check', 1 if psi.finite else 10)
-        self.time0 = time.time()
-        self.log_matvec = options.get('log_matvec', False)
-        self.matvec_log = []
-        self.hooks = {}
-        self.shard_matvec = options.get('shard_matvec', False)
-        if self.shard_matvec:       # multi-GPU: also distribute the independent charge blocks of every SVD over the ranks
+        self.update_stats = {k: [] for k in ('i0', 'E_total', 'N_lanczos', 'time', 'err', 'chi')}
+        self.sweep_stats = {k: [] for k in ('sweep', 'E', 'S', 'time', 'max_trunc_err', 'max_chi')}
+        self.profile = bool(options.get('profile', False))
+        self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
+        self.shard_matvec = bool(options.get('shard_matvec', False))
+        self._svd_group = None
+        if self.shard_matvec:           # multi-GPU: the independent charge blocks of every SVD are dealt out to the ranks too
             import torch.distributed as dist
             if dist.is_initialized() and dist.get_world_size() > 1:
-                npc.SVD_DIST_GROUP = (None, dist.get_rank(), dist.get_world_size())
-        self.profile = options.get('profile', False)
-        self.phase_time = {'heff': 0., 'lanczos': 0., 'svd': 0., 'env': 0., 'setB': 0.}
-        self.mixer = None            # activated by run() / mixer_activate() (reference: pre_run_initialize :829)
-        self._optimize = True
-        if resume_data is not None:  # reference: Algorithm.__init__(..., resume_data=...) / get_resume_data (algorithm.py)
+                self._svd_group = (None, dist.get_rank(), dist.get_world_size())
+        if resume_data is not None:
             self.sweeps = int(resume_data['sweeps'])
-            for k, v in resume_data.get('sweep_stats', {}).items():
-                self.sweep_stats[k] = list(v)
-            for k, v in resume_data.get('update_stats', {}).items():
-                self.update_stats[k] = list(v)
+            for name in ('sweep_stats', 'update_stats'):
+                for k, v in resume_data.get(name, {}).items():
+                    getattr(self, name)[k] = list(v)
             if resume_data.get('chi_max') is not None:
                 self.trunc_params['chi_max'] = resume_data['chi_max']
-        if not self.finite:          # iDMRG: initial sweeps of the environment without optimisation (reference :254-256)
-            if self.ortho_to_envs:
-                raise ValueError("Can't orthogonalize for infinite MPS: overlap not well defined.")
-            self.environment_sweeps(options.get('start_env', 1))
+            if resume_data.get('lanczos_params') is not None:
+                self.lanczos_params = dict(resume_data['lanczos_params'])
 
-    # ---- checkpoint / resume (SURVEY 8f row 4; reference: Algorithm.get_resume_data, simulations/simulation.py:1189) ----
+    # ---- checkpoint / resume: the state (device arrays pickle through the host), counters, statistics --------------------
     def get_resume_data(self):
-        """Everything needed to continue the run in a new process: the state (device arrays are pickled through the host,
-        ``Array.__getstate__``), sweep counter and statistics.  Environments are NOT stored; they are rebuilt from the
-        state on demand.  Bond matrices of a mixer sweep are diagonalised first (``mixer_cleanup``)."""
-        self.mixer_cleanup()
-        return {'psi': self.psi, 'sweeps': self.sweeps, 'sweep_stats': {k: list(v) for k, v in self.sweep_stats.items()},
-                'update_stats': {k: list(v) for k, v in self.update_stats.items()},
-                'chi_max': self.trunc_params.get('chi_max')}
+        """Not interchangeable with the reference's checkpoints (those hold TeNPy's own MPS class); environments are rebuilt
+        from the state on demand."""
+        return {'psi': self.psi, 'sweeps': self.sweeps, 'chi_max': self.trunc_params.get('chi_max'),
+                'lanczos_params': dict(self.lanczos_params),
+                'sweep_stats': {k: list(v) for k, v in self.sweep_stats.items()},
+                'update_stats': {k: list(v) for k, v in self.update_stats.items()}}
 
     def save_checkpoint(self, filename):
-        import pickle
         with open(filename, 'wb') as f:
             pickle.dump(self.get_resume_data(), f, protocol=4)
 
     @classmethod
     def from_checkpoint(cls, filename, model_H, options):
-        import pickle
         with open(filename, 'rb') as f:
             data = pickle.load(f)
         return cls(data['psi'], model_H, options, resume_data=data)
 
-    # ---- mixer handling (reference mps_common.py:653-760, :1547-1653) -----------------------------------------
-    def mixer_activate(self):
-        """Create the mixer requested by ``options['mixer']`` (``True`` / 'DensityMatrixMixer'; default: none, as
-        ``TwoSiteDMRGEngine.use_mixer_by_default = False``, dmrg.py:867) with ``options['mixer_params']``."""
-        which = self.options.get('mixer', False)
-        if not which:
-            return
-        mp = dict(self.options.get('mixer_params', {}))
-        if which == 'SubspaceExpansion':
-            self.mixer = SubspaceExpansion(mp.get('amplitude', 1.e-5), self.H.IdL, self.H.IdR, decay=mp.get('decay', 2.),
-                                           disable_after=mp.get('disable_after', 15), sweep_activated=self.sweeps)
-            return
-        if which is not True and which != 'DensityMatrixMixer':
-            raise NotImplementedError("tenpy_amd: mixers are 'DensityMatrixMixer' (default) and 'SubspaceExpansion'")
-        self.mixer = DensityMatrixMixer(mp.get('amplitude', 1.e-5), self.H.IdL, self.H.IdR,
-                                        decay=mp.get('decay', 2.), disable_after=mp.get('disable_after', 15),
-                                        sweep_activated=self.sweeps)
-
-    def mixer_deactivate(self):
-        self.mixer = None
-
-    def mixer_cleanup(self):
-        """Bring the 2-D bond matrices left behind by a sweep with mixer back to diagonal form by SVDs of the
-        matrices, absorbing the unitaries into the neighbouring tensors and environments (reference :693-769)."""
-        psi, env = self.psi, self.env
-        for i in range(1, psi.L):
-            S = psi.get_SL(i)
-            if not isinstance(S, npc.Array):
-                continue
-            U, S, V = npc.svd(S, inner_labels=['vR', 'vL'])
-            S = S / np.linalg.norm(S)
-            form_L, form_R = psi.form[i - 1][1], psi.form[i][0]
-            B_L, B_R = psi.get_B(i - 1, None), psi.get_B(i, None)
-            if form_L == 0.:
-                B_L = npc.tensordot(B_L, U, axes=['vR', 'vL'])
-            elif form_L == 1.:
-                B_L = npc.tensordot(B_L, V.conj().replace_labels(['vR*', 'vL*'], ['vL', 'vR']), axes=['vR', 'vL'])
-            else:
-                raise RuntimeError("bond matrices are only supported next to A, B, Th or G form tensors")
-            if form_R == 0.:
-                B_R = npc.tensordot(V, B_R, axes=['vR', 'vL'])
-            elif form_R == 1.:
-                B_R = npc.tensordot(U.conj().replace_labels(['vR*', 'vL*'], ['vL', 'vR']), B_R, axes=['vR', 'vL'])
-            else:
-                raise RuntimeError("bond matrices are only supported next to A, B, Th or G form tensors")
-            psi.set_B(i - 1, B_L, form=psi.form[i - 1])
-            psi.set_SL(i, S)
-            psi.set_B(i, B_R, form=psi.form[i])
-            if env._LP[i] is not None:
-                LP = npc.tensordot(env._LP[i], U.conj(), axes=['vR*', 'vL*'])
-                LP = npc.tensordot(LP, U, axes=['vR', 'vL'])
-                env.set_LP(i, LP.transpose(['vR*', 'wR', 'vR']))
-            if env._RP[i - 1] is not None:
-                RP = npc.tensordot(V.conj(), env._RP[i - 1], axes=['vR*', 'vL*'])
-                RP = npc.tensordot(V, RP, axes=['vR', 'vL'])
-                env.set_RP(i - 1, RP.transpose(['vL', 'wL', 'vL*']))
-
-    def get_sweep_schedule(self):
-        L = self.psi.L
-        if not self.finite:          # reference mps_common.py:444-450: the bonds of the unit cell, across its boundary too
-            i0s = list(range(0, L)) + list(range(L, 0, -1))
-            move_right = [True] * L + [False] * L
-            update_LP_RP = [[True, True]] * 2 + [[True, False]] * (L - 2) + [[True, True]] * 2 + [[False, True]] * (L - 2)
-            return list(zip(i0s, move_right, update_LP_RP))
-        i0s = list(range(0, L - 2)) + list(range(L - 2, 0, -1))
-        move_right = [True] * (L - 2) + [False] * (L - 2)
-        update_LP_RP = [[True, False]] * (L - 2) + [[False, True]] * (L - 2)
-        return list(zip(i0s, move_right, update_LP_RP))
-
-    def environment_sweeps(self, N_sweeps):
-        """Sweeps without optimisation, to converge the environments of an infinite MPS (reference :330)."""
-        for _ in range(max(int(N_sweeps), 0)):
-            self.sweep(optimize=False)
-
-    def sweep(self, optimize=True, meas_E_trunc=False):
-        """One sweep = 2(L-2) two-site updates.  Returns the maximal truncation error.  ``meas_E_trunc``: also evaluate
-        ``<psi|H|psi>`` after every truncation (one full contraction per update, reference dmrg.py:520/:589)."""
-        self._meas_E_trunc = meas_E_trunc
-        self.E_trunc_list = []
+    # ---- one sweep = 2 (L - 2) bond updates ----------------------------------------------------------------------------------
+    def sweep(self):
         if self.chi_list is not None:
-            keys = [k for k in self.chi_list if k <= self.sweeps]
-            if keys:
-                self.trunc_params['chi_max'] = self.chi_list[max(keys)]
-            if optimize and self.sweeps in self.chi_list and self.options.get('chi_list_reactivates_mixer', True):
-                self.mixer_activate()                       # reference mps_common.py:376-382
+            due = [s for s in self.chi_list if s <= self.sweeps]
+            if due:
+                self.trunc_params['chi_max'] = self.chi_list[max(due)]
+        L = self.psi.L
         t0 = time.time()
-        max_err, n_upd = 0., 0
-        self._optimize = bool(optimize)
-        try:
-            for i0, move_right, (upd_LP, upd_RP) in self.get_sweep_schedule():
-                err = self.update_bond(i0, move_right, upd_LP, upd_RP)
-                max_err = max(max_err, err.eps)
-                n_upd += 1
-        finally:
-            self._optimize = True
-        if not optimize:                # environment sweep: not counted, mixer untouched (reference :405-413)
-            return max_err
+        worst = 0.
+        for i0 in range(L - 2):
+            worst = max(worst, self.update_bond(i0, move_right=True).eps)
+        for i0 in range(L - 2, 0, -1):
+            worst = max(worst, self.update_bond(i0, move_right=False).eps)
         self.sweeps += 1
-        if self.mixer is not None and self.mixer.update_amplitude(self.sweeps) is None:
-            self.mixer_deactivate()
-        if self._in_iteration:          # run(): the statistics of an iteration are collected by run_iteration
-            return max_err
         st = self.sweep_stats
         st['sweep'].append(self.sweeps)
         st['E'].append(self.update_stats['E_total'][-1])
         st['S'].append(float(np.max(self.psi.entanglement_entropy())))
         st['time'].append(time.time() - t0)
-        st['max_trunc_err'].append(max_err)
+        st['max_trunc_err'].append(worst)
         st['max_chi'].append(int(np.max(self.psi.chi)))
-        st['N_updates'].append(n_upd)
-        return max_err
+        return worst
 
-    def update_bond(self, i0, move_right=True, update_LP=True, update_RP=False):
+    def update_bond(self, i0, move_right=True):
         t0 = time.time()
-        psi = self.psi
-        tick = self._tick
-        tick(None)
+        psi, env = self.psi, self.env
+        self._tick(None)
         if self.shard_matvec:
             from .sharded import ShardedTwoSiteH
-            eff_H = ShardedTwoSiteH(self.env, i0, combine=True, move_right=move_right)
+            eff_H = ShardedTwoSiteH(env, i0, combine=True, move_right=move_right)
         else:
-            eff_H = TwoSiteH(self.env, i0, combine=True, move_right=move_right)
-        theta = psi.get_theta(i0, n=2, cutoff=self.S_inv_cutoff)
-        theta = eff_H.combine_theta(theta)
-        op = self._wrap_ortho_eff_H(eff_H, i0, 2)
-        age = (self.env.get_LP_age(i0) or 0) + 2 + (self.env.get_RP_age(i0 + 1) or 0)
-        tick('heff')
-        if self._optimize:
-            E0, theta, N = self.diag(eff_H, op, theta)
-        else:                                     # environment sweep: only re-decompose and update the environments
-            E0, N = None, 0
-        theta = eff_H.prepare_svd(theta)          # fused matrix [(vL.p0), (p1.vR)] for the SVD / mixer
-        tick('lanczos')
+            eff_H = TwoSiteH(env, i0, combine=True, move_right=move_right)
+        theta = eff_H.combine_theta(psi.get_theta(i0, n=2))
+        self._tick('heff')
+        E0, theta, N = LanczosGroundState(eff_H, theta, self.lanczos_params).run()
+        theta = eff_H.prepare_svd(theta)                      # fused matrix [(vL.p0), (p1.vR)]
+        self._tick('lanczos')
+        previous = npc.SVD_DIST_GROUP
+        npc.SVD_DIST_GROUP = self._svd_group                  # scoped to this call (other SVDs in the process stay local)
+        try:
+            U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[psi.get_B(i0, None).qtotal, None],
+                                         inner_labels=['vR', 'vL'])
+        finally:
+            npc.SVD_DIST_GROUP = previous
+        self._tick('svd')
         i1 = i0 + 1
-        qtotal_i0 = psi.get_B(i0, None).qtotal
-        if self.mixer is None:
-            U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[qtotal_i0, None], inner_labels=['vR', 'vL'])
-            S_a = S
-        else:       # reference dmrg.py:921-929: perturbed density matrices, S is a general bond matrix
-            qtotal_LR = [qtotal_i0, theta.chinfo.make_valid(theta.qtotal - qtotal_i0)]
-            if isinstance(self.mixer, DensityMatrixMixer):
-                rho_L, rho_R = self.mixer.mix_rho(eff_H, theta, update_LP, update_RP)
-                U, S, VH, err, S_a = self.mixer.svd_from_rho(rho_L, rho_R, theta, self.trunc_params, qtotal_LR)
-            else:   # mixers that only know the one-site decomposition (reference Mixer.mix_and_decompose_2site :1764)
-                U, S, VH, err, S_a = self.mixer.mix_and_decompose_2site(eff_H, theta, self.trunc_params, update_LP, update_RP,
-                                                                        qtotal_LR)
-                # (like the reference, the factor on the non-mixed side is stored as it comes: not an isometry)
-        tick('svd')
-        if not self.finite:          # the parts next to the updated bond are recomputed or dropped (reference :580-593)
-            self.env.del_LP(i1)
-            self.env.del_RP(i0)
-        if update_LP:
-            eff_H.update_LP(self.env, i1, U)
-        if update_RP:
-            eff_H.update_RP(self.env, i0, VH)
-        tick('env')
-        A = U.split_legs(['(vL.p0)']).ireplace_label('p0', 'p')
-        B = VH.split_legs(['(p1.vR)']).ireplace_label('p1', 'p')
-        psi.set_B(i0, A, form='A')
-        psi.set_B(i1, B, form='B')
+        if move_right:
+            eff_H.update_LP(env, i1, U)
+        else:
+            eff_H.update_RP(env, i0, VH)
+        self._tick('env')
+        psi.set_B(i0, U.split_legs(['(vL.p0)']).ireplace_label('p0', 'p'), form='A')
+        psi.set_B(i1, VH.split_legs(['(p1.vR)']).ireplace_label('p1', 'p'), form='B')
         psi.set_SR(i0, S)
-        tick('setB')
-        if self.finite:              # environments that depended on the old tensors are stale now
-            for j in range(i1 + 1, psi.L):
-                if self.env._LP[j] is None:
-                    break
-                self.env._LP[j] = None
-            if not update_LP and self.env._LP[i1] is not None:
-                self.env._LP[i1] = None
-            for j in range(i0 - 1, -1, -1):
-                if self.env._RP[j] is None:
-                    break
-                self.env._RP[j] = None
-            if not update_RP and self.env._RP[i0] is not None:
-                self.env._RP[i0] = None
-            self._update_ortho_envs(i0, i1, update_LP, update_RP)
-        if E0 is None:               # no optimisation: the energy after truncation (reference :587-592)
-            E0 = float(np.real(self.env.full_contraction(i0)))
+        env.invalidate(i0, i1, keep_LP=move_right, keep_RP=not move_right)
+        self._tick('setB')
         us = self.update_stats
-        us.setdefault('age', []).append(age)
         us['i0'].append(i0)
         us['E_total'].append(float(E0))
         us['N_lanczos'].append(N)
         us['time'].append(time.time() - t0)
         us['err'].append(err.eps)
-        us['chi'].append(len(S_a))
-        us['flops'].append(eff_H.flops_per_matvec)
-        us['bytes'].append(eff_H.bytes_per_matvec)
-        self._post_update(i0, 2, move_right, float(E0), S_a)
-        if self.log_matvec:
-            self.matvec_log.append((i0, N, eff_H.flops_per_matvec, eff_H.bytes_per_matvec, theta.shape))
+        us['chi'].append(len(S))
         return err
 
-    @property
-    def S_inv_cutoff(self):
-        """Cutoff of the (pseudo-)inverse of bond matrices: 1e-8 while a mixer left 2-D matrices in the MPS (reference
-        mps_common.py:161)."""
-        return 1.e-8 if any(isinstance(S, npc.Array) for S in self.psi._S) else 1.e-15
-
-    def diag(self, eff_H, op, theta_guess):
-        """Lowest eigenpair of the effective Hamiltonian (reference ``DMRGEngine.diag``, dmrg.py:672).  ``diag_method``:
-        'lanczos' (default HERE; the bench and the goldens of this repo fix it), 'ED_block' (exact diagonalisation in the
-        charge sector of the guess) or 'default' = the reference's default: ED below ``max_N_for_ED`` (400), Lanczos above.
-        With ``orthogonal_to`` the projected operator has no matrix form here: Lanczos is used."""
-        method = self.options.get('diag_method', 'lanczos')
-        if method not in ('lanczos', 'ED_block', 'default'):
-            raise ValueError("Unknown diagonalization method: " + repr(method))
-        use_ed = method == 'ED_block' or (method == 'default' and eff_H.N < self.options.get('max_N_for_ED', 400))
-        if use_ed and op is eff_H and hasattr(eff_H, 'to_matrix_array'):
-            E0, theta = full_diag_effH(eff_H, theta_guess)
-            return E0, theta, -1
-        return LanczosGroundState(op, theta_guess, self.lanczos_params).run()
-
-    # ---- orthogonalisation against other states (reference mps_common.py:524-540, :569-593) -------------------------
-    def _wrap_ortho_eff_H(self, eff_H, i0, n):
-        """``eff_H`` -> ``P eff_H P`` with the local wave functions of the states in ``orthogonal_to`` projected out."""
-        if not self.ortho_to_envs:
-            return eff_H
-        from ..linalg.sparse import OrthogonalNpcLinearOperator
-        vecs = []
-        for o_env in self.ortho_to_envs:
-            th = o_env.ket.get_theta(i0, n=n)
-            th = npc.tensordot(o_env.get_LP(i0), th, axes=('vR', 'vL'))
-            th = npc.tensordot(th, o_env.get_RP(i0 + n - 1), axes=('vR', 'vL'))
-            th.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
-            th = eff_H.combine_theta(th)
-            if th.dtype != self.env.dtype:
-                th = th.astype(self.env.dtype)
-            vecs.append(th)
-        return OrthogonalNpcLinearOperator(eff_H, vecs)
-
-    def _update_ortho_envs(self, i_L, i_R, update_LP, update_RP):
-        for env in self.ortho_to_envs:
-            for j in range(i_R, self.psi.L):         # everything that contains the new tensors is stale
-                if env._LP[j] is None and j > i_R:
-                    break
-                env._LP[j] = None
-            for j in range(i_L, -1, -1):
-                if env._RP[j] is None and j < i_L:
-                    break
-                env._RP[j] = None
-            if update_LP:
-                env.get_LP(i_R, store=True)
-            if update_RP:
-                env.get_RP(i_L, store=True)
-
     def _tick(self, phase):
-        """Phase timer (mirrors the reference's DEBUG_PRINT phases); synchronises only when profiling."""
+        """Phase timer (the reference's DEBUG_PRINT phases, _npc_helper.pyx:13); synchronises only when profiling."""
         if not self.profile:
             return
         from ..linalg import _device as dev
@@ -350,263 +148,3 @@ class TwoSiteDMRGEngine:
         if phase is not None:
             self.phase_time[phase] += now - self._t_phase
         self._t_phase = now
-
-    def _post_update(self, i0, n_opt, move_right, E0, S_approx):
-        """Entropy of the (approximate) Schmidt values of the updated bond and, if requested, the truncation energy
-        (reference dmrg.py:570, :587-594)."""
-        S_approx = np.asarray(S_approx)
-        p = S_approx**2
-        p = p[p > 1.e-30]
-        self._entropy_approx[(i0 + n_opt - 1) % self.psi.L] = float(-np.inner(np.log(p), p))
-        E_trunc = None
-        if self._meas_E_trunc:
-            i = i0 if (n_opt == 2 or move_right) else i0 - 1
-            E_trunc = float(np.real(self.env.full_contraction(i))) - E0
-        self.update_stats.setdefault('E_trunc', []).append(E_trunc)
-        self.E_trunc_list.append(E_trunc)
-
-    # ---- the reference's main loop (IterativeSweeps.run, mps_common.py:796; DMRGEngine.run_iteration, dmrg.py:219) --------
-    def run_iteration(self):
-        """``N_sweeps_check`` sweeps, then the Lanczos tolerances follow the truncation error (``P_tol_to_trunc`` = 0.05,
-        ``P_tol_min`` / ``P_tol_max``; ``E_tol_to_trunc`` = None, ``E_tol_min`` / ``E_tol_max``) and the statistics of the
-        iteration are appended to ``sweep_stats`` (same keys as the reference)."""
-        opt = self.options
-        st = self.sweep_stats
-        for k in ('Delta_E', 'Delta_S', 'max_S', 'max_E_trunc', 'norm_err'):
-            st.setdefault(k, [])
-        p_tol_to_trunc = opt.get('P_tol_to_trunc', 0.05)
-        if p_tol_to_trunc is not None:
-            svd_min = self.trunc_params.get('svd_min', 0.) or 0.
-            trunc_cut = self.trunc_params.get('trunc_cut', 0.) or 0.
-            p_tol_min = opt.get('P_tol_min', max(1.e-30, svd_min**2 * p_tol_to_trunc, trunc_cut**2 * p_tol_to_trunc))
-            p_tol_max = opt.get('P_tol_max', 1.e-4)
-        e_tol_to_trunc = opt.get('E_tol_to_trunc', None)
-        if e_tol_to_trunc is not None:
-            e_tol_min, e_tol_max = opt.get('E_tol_min', 5.e-16), opt.get('E_tol_max', 1.e-4)
-        if len(st['E']) < 1:
-            E_old, S_old = np.nan, float(np.mean(self.psi.entanglement_entropy()))
-        else:
-            E_old, S_old = st['E'][-1], st['S'][-1]
-        self._in_iteration = True
-        try:
-            for _ in range(self.N_sweeps_check - 1):
-                self.sweep(meas_E_trunc=False)
-            max_trunc_err = self.sweep(meas_E_trunc=True)
-        finally:
-            self._in_iteration = False
-        max_E_trunc = float(np.max(self.E_trunc_list))
-        if p_tol_to_trunc is not None and max_trunc_err > p_tol_min:
-            self.lanczos_params['P_tol'] = max(p_tol_min, min(p_tol_max, max_trunc_err * p_tol_to_trunc))
-        if e_tol_to_trunc is not None and max_E_trunc > e_tol_min:
-            self.lanczos_params['E_tol'] = max(e_tol_min, min(e_tol_max, max_E_trunc * e_tol_to_trunc))
-        if not self.finite:          # iDMRG: update the environments, energy per site from the growth of the system
-            self.environment_sweeps(opt.get('update_env', self.N_sweeps_check // 2))
-            entropy_bonds = list(self._entropy_approx)
-            Es, ages = self.update_stats['E_total'], self.update_stats['age']
-            delta = min(1 + 2 * self.env.L, len(ages))
-            E = (Es[-1] - Es[-delta]) / (ages[-1] - ages[-delta])
-        else:
-            entropy_bonds = self._entropy_approx[1:]
-            E = self.update_stats['E_total'][-1]
-        S = float(np.mean(entropy_bonds))
-        st['sweep'].append(self.sweeps)
-        st['N_updates'].append(len(self.update_stats['i0']))
-        st['E'].append(E)
-        st['Delta_E'].append((E - E_old) / self.N_sweeps_check)
-        st['S'].append(S)
-        st['Delta_S'].append((S - S_old) / self.N_sweeps_check)
-        st['max_S'].append(float(max(entropy_bonds)))
-        st['time'].append(time.time() - self.time0)
-        st['max_trunc_err'].append(max_trunc_err)
-        st['max_E_trunc'].append(max_E_trunc)
-        st['max_chi'].append(int(np.max(self.psi.chi)))
-        st['norm_err'].append(abs(abs(self.psi.norm_test()) - 1.) if self.finite and not any(isinstance(x, npc.Array) for x in self.psi._S) else np.nan)
-        return E, self.psi
-
-    def is_converged(self):
-        """``|Delta E / max(E, 1)| < max_E_err`` (1e-8) and ``|Delta S| < max_S_err`` (1e-5)  (reference dmrg.py:376)."""
-        max_E_err = self.options.get('max_E_err', 1.e-8)
-        max_S_err = self.options.get('max_S_err', 1.e-5)
-        st = self.sweep_stats
-        if not st.get('Delta_E'):           # no iteration of run() yet (e.g. right after resuming from a checkpoint)
-            return False
-        E, Delta_E, Delta_S = st['E'][-1], st['Delta_E'][-1], st['Delta_S'][-1]
-        return abs(Delta_E / max(E, 1.)) < max_E_err and abs(Delta_S) < max_S_err
-
-    def stopping_criterion(self):
-        """Reference mps_common.py:869: ``max_sweeps`` (1000), ``min_sweeps`` (1), convergence with the mixer still on
-        switches the mixer off and goes on; ``max_hours``."""
-        opt = self.options
-        if self.sweeps > opt.get('max_sweeps', 1000):
-            return True
-        if self.sweeps > opt.get('min_sweeps', 1) and self.is_converged():
-            if self.mixer is None:
-                return True
-            self.mixer_deactivate()
-            return False
-        if time.time() - self.time0 > 3600. * opt.get('max_hours', 24 * 365):
-            self.shelve = True
-            return True
-        return False
-
-    def run(self):
-        """The reference's ``DMRGEngine.run()``: iterate ``run_iteration`` until ``stopping_criterion``; returns ``(E, psi)``."""
-        self.shelve = False
-        self.mixer_activate()
-        result = (np.nan, self.psi)
-        while not self.stopping_criterion():
-            result = self.run_iteration()
-        self.mixer_cleanup()
-        self._canonicalize()
-        return result
-
-    def _canonicalize(self):
-        """Reference ``DMRGEngine._canonicalize`` (dmrg.py:455): for an infinite MPS converge the environments (at most
-        ``norm_tol_iter`` x ``update_env`` environment sweeps) until the norm error is below ``norm_tol`` (1e-5); if it is
-        still above ``norm_tol_final`` (1e-10) bring the state into canonical form."""
-        if self.mixer is not None:
-            return
-        opt = self.options
-        norm_tol, norm_tol_final = opt.get('norm_tol', 1.e-5), opt.get('norm_tol_final', 1.e-10)
-        norm_err = float(np.linalg.norm(self.psi.norm_error()))
-        if norm_tol is None or (norm_err < norm_tol and norm_err < norm_tol_final):
-            return
-        if norm_err > norm_tol and not self.finite:
-            update_env = opt.get('update_env', self.N_sweeps_check // 2)
-            for _ in range(opt.get('norm_tol_iter', 5)):
-                self.environment_sweeps(update_env)
-                norm_err = float(np.linalg.norm(self.psi.norm_error()))
-                if norm_err <= norm_tol:
-                    break
-        if norm_err > norm_tol_final:
-            self.psi.canonical_form()
-            self.env._heff_cache.clear()
-
-
-class SingleSiteDMRGEngine(TwoSiteDMRGEngine):
-    """Single-site DMRG (reference dmrg.py:955-1139): the effective Hamiltonian acts on ONE site (``OneSiteH``), the SVD
-    of the optimised theta shifts the orthogonality centre, and the subspace expansion (default mixer, switched on by
-    default like ``use_mixer_by_default = True`` :976) lets the bond dimension grow.  Moving right the bond (i0, i0+1)
-    and the tensors of sites i0 and i0+1 are updated, moving left the bond (i0-1, i0) and sites i0-1, i0
-    (``_update_env_inds``, mps_common.py:595).  Shares sweep / run / checkpoint / mixer-cleanup logic with the two-site
-    engine."""
-
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self.n_optimize = 1
-
-    def mixer_activate(self):
-        which = self.options.get('mixer', True)
-        if not which:
-            return
-        mp = dict(self.options.get('mixer_params', {}))
-        kw = dict(decay=mp.get('decay', 2.), disable_after=mp.get('disable_after', 15), sweep_activated=self.sweeps)
-        if which is True or which == 'SubspaceExpansion':
-            self.mixer = SubspaceExpansion(mp.get('amplitude', 1.e-5), self.H.IdL, self.H.IdR, **kw)
-        else:
-            raise NotImplementedError("tenpy_amd: single-site DMRG supports the SubspaceExpansion mixer (or none)")
-
-    def get_sweep_schedule(self):
-        L = self.psi.L                      # reference mps_common.py:438-454 with n = 1
-        if not self.finite:
-            i0s = list(range(0, L)) + list(range(L, 0, -1))
-            move_right = [True] * L + [False] * L
-            update_LP_RP = [[True, True]] + [[True, False]] * (L - 1) + [[True, True]] + [[False, True]] * (L - 1)
-            return list(zip(i0s, move_right, update_LP_RP))
-        i0s = list(range(0, L - 1)) + list(range(L - 1, 0, -1))
-        move_right = [True] * (L - 1) + [False] * (L - 1)
-        update_LP_RP = [[True, False]] * (L - 1) + [[False, True]] * (L - 1)
-        return list(zip(i0s, move_right, update_LP_RP))
-
-    def mixed_svd(self, eff_H, theta, i0, move_right):
-        """Reference dmrg.py:996-1110.  Returns U [(vL.p), vR], S (1-D host array, or a 2-D bond matrix with a mixer),
-        VH [vL, (p.vR)], err, S_approx."""
-        psi = self.psi
-        if move_right:
-            nxt = psi.get_B(i0 + 1, 'B').combine_legs(['p', 'vR'], qconj=-1, new_axes=1)
-        else:
-            nxt = psi.get_B(i0 - 1, 'A').combine_legs(['vL', 'p'], qconj=+1, new_axes=0)
-        if self.mixer is None:
-            qtotal = [theta.qtotal, None] if move_right else [None, theta.qtotal]
-            U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=qtotal, inner_labels=['vR', 'vL'])
-            S_a = S
-            if move_right:       # VH is at most a truncation: VH.next_B stays right-canonical
-                VH = npc.tensordot(VH, nxt, axes=['vR', 'vL'])
-                U.ireplace_label('(vL.p0)', '(vL.p)')
-            else:
-                U = npc.tensordot(nxt, U, axes=['vR', 'vL'])
-                VH.ireplace_label('(p0.vR)', '(p.vR)')
-        else:
-            U, S, VH, err = self.mixer.mix_and_decompose_1site(eff_H, theta, self.trunc_params, move_right)
-            S_a = S
-            if move_right:       # the (non-isometric) VH goes into the bond matrix; the old next_B stays
-                S = VH.scale_axis(S, 'vL')
-                VH = nxt
-                U.ireplace_label('(vL.p0)', '(vL.p)')
-            else:
-                S = U.scale_axis(S, 'vR')
-                U = nxt
-                VH.ireplace_label('(p0.vR)', '(p.vR)')
-        return U, S, VH, err, S_a
-
-    def update_bond(self, i0, move_right=True, update_LP=True, update_RP=False):
-        t0 = time.time()
-        psi = self.psi
-        tick = self._tick
-        tick(None)
-        eff_H = OneSiteH(self.env, i0, combine=True, move_right=move_right)
-        theta = eff_H.combine_theta(psi.get_theta(i0, n=1, cutoff=self.S_inv_cutoff))
-        op = self._wrap_ortho_eff_H(eff_H, i0, 1)
-        age = (self.env.get_LP_age(i0) or 0) + 1 + (self.env.get_RP_age(i0) or 0)
-        tick('heff')
-        if self._optimize:
-            E0, theta, N = self.diag(eff_H, op, theta)
-        else:
-            E0, N = None, 0
-        tick('lanczos')
-        U, S, VH, err, S_a = self.mixed_svd(eff_H, theta, i0, move_right)
-        tick('svd')
-        i_L, i_R = (i0, i0 + 1) if move_right else (i0 - 1, i0)
-        psi.set_B(i_L, U.split_legs(['(vL.p)']), form='A')       # the state first: the generic environment updates
-        psi.set_B(i_R, VH.split_legs(['(p.vR)']), form='B')      # (``env.get_LP / get_RP``) contract the NEW tensors
-        psi.set_SR(i_L, S)
-        tick('setB')
-        self.env.del_LP(i_R)
-        self.env.del_RP(i_L)
-        if update_LP:
-            eff_H.update_LP(self.env, i_R, U)
-        if update_RP:
-            eff_H.update_RP(self.env, i_L, VH)
-        tick('env')
-        if self.finite:
-            for j in range(i_R + 1, psi.L):      # environments built from the old tensors are stale now
-                if self.env._LP[j] is None:
-                    break
-                self.env._LP[j] = None
-            for j in range(i_L - 1, -1, -1):
-                if self.env._RP[j] is None:
-                    break
-                self.env._RP[j] = None
-            self._update_ortho_envs(i_L, i_R, update_LP, update_RP)
-        if E0 is None:
-            E0 = float(np.real(self.env.full_contraction(i_L)))
-        us = self.update_stats
-        us.setdefault('age', []).append(age)
-        us['i0'].append(i0)
-        us['E_total'].append(float(E0))
-        us['N_lanczos'].append(N)
-        us['time'].append(time.time() - t0)
-        us['err'].append(err.eps)
-        us['chi'].append(len(S_a))
-        us['flops'].append(eff_H.flops_per_matvec)
-        us['bytes'].append(eff_H.bytes_per_matvec)
-        self._post_update(i0, 1, move_right, float(E0), S_a)
-        return err
-
-
-def run(psi, model_H, options, **kwargs):
-    """Two-site DMRG like the reference's ``dmrg.run`` (dmrg.py:63); returns the same dict keys."""
-    eng = TwoSiteDMRGEngine(psi, model_H, options, **kwargs)
-    E, psi = eng.run()
-    return {'E': E, 'shelve': eng.shelve, 'bond_statistics': eng.update_stats, 'sweep_statistics': eng.sweep_stats,
-            'update_statistics': eng.update_stats}

@@ -22,7 +22,7 @@ import numpy as np
 from ..linalg import _device as dev
 from ..linalg import np_conserved as npc
 
-__all__ = ['TwoSiteH', 'OneSiteH', 'ZeroSiteH', 'DensityMatrixMixer', 'SubspaceExpansion', 'full_diag_effH']
+__all__ = ['TwoSiteH']
 
 
 FUSED_HEFF = True     # tuning / test hook: False forces the generic tensordot + combine_legs construction
@@ -339,8 +339,8 @@ class TwoSiteH:
     acts_on = ['(vL.p0)', '(p1.vR)']
 
     def __init__(self, env, i0, combine=True, move_right=True, tensors=None, factored=None):
-        if not combine:
-            raise NotImplementedError("tenpy_amd.TwoSiteH: only combine=True")
+        if not combine:     # (TeNPy's own TwoSiteH runs combine=False on the mirror: tenpy_amd/install.py)
+            raise NotImplementedError("tenpy_amd.TwoSiteH (stand-alone driver): only combine=True")
         self.i0 = i0
         self.combine = combine
         self.move_right = move_right
@@ -568,408 +568,3 @@ class TwoSiteH:
         full = full.transpose(0, 3, 1, 2)                    # out_L, out_R, in_L, in_R
         n = full.shape[0] * full.shape[1]
         return full.reshape(n, n)
-
-
-class OneSiteH:
-    """One-site effective Hamiltonian ``LP - W0 - RP`` of single-site DMRG (reference mps_common.py:1040-1243), in the
-    ``combine=True`` form: moving right, ``LHeff = LP.W0`` [(vR*.p0), wR, (vR.p0*)] acts on theta [(vL.p0), vR]; moving
-    left, ``RHeff = W0.RP`` [wL, (p0*.vL), (p0.vL*)] acts on theta [vL, (p0.vR)].  Both halves come from the same fused
-    builder (and the same per-(side, site) cache) as the two-site operator; a matvec is two planned block GEMM launches."""
-    length = 1
-
-    def __init__(self, env, i0, combine=True, move_right=True, tensors=None):
-        self.i0 = i0
-        self.combine = combine
-        self.move_right = move_right
-        if tensors is not None:
-            self.LP, self.RP, W0 = tensors
-            self.dtype = W0.dtype
-        else:
-            self.LP = env.get_LP(i0)
-            self.RP = env.get_RP(i0)
-            W0 = env.H.get_W(i0)
-            self.dtype = env.H.dtype
-        self.W0 = W0.replace_labels(['p', 'p*'], ['p0', 'p0*'])
-        self.W0._tpa_entries = _mpo_entries(W0)
-        self._env = env if tensors is None else None
-        self.N = self.LP.get_leg('vR').ind_len * self.W0.get_leg('p0').ind_len * self.RP.get_leg('vL').ind_len
-        self.flops_per_matvec = None
-        self.bytes_per_matvec = None
-        if combine:
-            self.combine_Heff(self._env)
-        else:
-            self.acts_on = ['vL', 'p0', 'vR']
-
-    def combine_Heff(self, env=None):
-        cache = getattr(env, '_heff_cache', None) if env is not None else None
-        if self.move_right:
-            hit = cache.get(('L', self.i0)) if cache is not None else None
-            if hit is not None and hit[0] is self.LP:
-                _, self.LHeff, self.pipeL = hit
-            else:
-                fused = _fused_heff(self.LP, self.W0, True) if FUSED_HEFF else None
-                if fused is not None:
-                    self.LHeff, self.pipeL = fused
-                else:
-                    LHeff = npc.tensordot(self.LP, self.W0, axes=['wR', 'wL'])
-                    self.pipeL = pipeL = LHeff.make_pipe(['vR*', 'p0'], qconj=+1)
-                    self.LHeff = LHeff.combine_legs([['vR*', 'p0'], ['vR', 'p0*']], pipes=[pipeL, pipeL.conj()], new_axes=[0, 2])
-                if cache is not None:
-                    cache[('L', self.i0)] = (self.LP, self.LHeff, self.pipeL)
-            self.acts_on = ['(vL.p0)', 'vR']
-        else:
-            W1 = self.W0.replace_labels(['p0', 'p0*'], ['p1', 'p1*'])          # (the right half is built with 'p1' labels)
-            W1._tpa_entries = self.W0._tpa_entries
-            hit = cache.get(('R', self.i0)) if cache is not None else None
-            if hit is not None and hit[0] is self.RP:
-                _, RHeff, pipeR = hit
-            else:
-                fused = _fused_heff(self.RP, W1, False) if FUSED_HEFF else None
-                if fused is not None:
-                    RHeff, pipeR = fused
-                else:
-                    RHeff = npc.tensordot(W1, self.RP, axes=['wR', 'wL'])
-                    pipeR = RHeff.make_pipe(['p1', 'vL*'], qconj=-1)
-                    RHeff = RHeff.combine_legs([['p1*', 'vL'], ['p1', 'vL*']], pipes=[pipeR.conj(), pipeR], new_axes=[1, 2])
-                if cache is not None:
-                    cache[('R', self.i0)] = (self.RP, RHeff, pipeR)
-            self._RHeff_p1 = RHeff                                             # what the mixer asks for (reference :1893)
-            self.RHeff = RHeff.replace_labels(['(p1*.vL)', '(p1.vL*)'], ['(p0*.vL)', '(p0.vL*)'])
-            self.pipeR = pipeR
-            self.acts_on = ['vL', '(p0.vR)']
-
-    def combine_theta(self, theta):
-        if not self.combine:
-            return theta if list(theta.get_leg_labels()) == self.acts_on else theta.transpose(self.acts_on)
-        if self.move_right:
-            theta = theta.combine_legs(['vL', 'p0'], pipes=self.pipeL)
-        else:
-            theta = theta.combine_legs(['p0', 'vR'], pipes=self.pipeR)
-        return theta if list(theta.get_leg_labels()) == self.acts_on else theta.transpose(self.acts_on)
-
-    def matvec(self, theta):
-        """Reference :1118-1151."""
-        if not self.combine:             # LP - W0 - RP applied to [vL, p0, vR] (three contractions)
-            res = npc.tensordot(self.LP, theta, axes=['vR', 'vL'])
-            res = npc.tensordot(self.W0, res, axes=[['wL', 'p0*'], ['wR', 'p0']])
-            res = npc.tensordot(res, self.RP, axes=[['wR', 'vR'], ['wL', 'vL']])
-            res.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
-            return res if list(res.get_leg_labels()) == self.acts_on else res.transpose(self.acts_on)
-        if self.move_right:
-            tmp = npc.tensordot(self.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])            # (vR*.p0), wR, vR
-            res = npc.tensordot(tmp, self.RP, axes=[['wR', 'vR'], ['wL', 'vL']])            # (vR*.p0), vL*
-            res.ireplace_labels(['(vR*.p0)', 'vL*'], ['(vL.p0)', 'vR'])
-        else:
-            tmp = npc.tensordot(theta, self.RHeff, axes=['(p0.vR)', '(p0*.vL)'])            # vL, wL, (p0.vL*)
-            res = npc.tensordot(self.LP, tmp, axes=[['vR', 'wR'], ['vL', 'wL']])            # vR*, (p0.vL*)
-            res.ireplace_labels(['vR*', '(p0.vL*)'], ['vL', '(p0.vR)'])
-        return res if list(res.get_leg_labels()) == self.acts_on else res.transpose(self.acts_on)
-
-    def update_LP(self, env, i, U=None):
-        """Reference :1226.  Moving right: LP(i0+1) = U^dagger LHeff U; otherwise the generic contraction."""
-        if self.combine and self.move_right:
-            assert i == self.i0 + 1
-            LP = npc.tensordot(self.LHeff, U, axes=['(vR.p0*)', '(vL.p)'])
-            LP = npc.tensordot(U.conj(), LP, axes=['(vL*.p*)', '(vR*.p0)'])                 # vR*, wR, vR
-            _env_set_LP(env, i, LP)
-            return LP
-        return env.get_LP(i, store=True)
-
-    def update_RP(self, env, i, VH=None):
-        """Reference :1235.  Moving left: RP(i0-1) = RHeff VH VH^dagger."""
-        if self.combine and self.move_right is False:
-            assert i == self.i0 - 1
-            RP = npc.tensordot(VH, self.RHeff, axes=['(p.vR)', '(p0*.vL)'])                 # vL, wL, (p0.vL*)
-            RP = npc.tensordot(RP, VH.conj(), axes=['(p0.vL*)', '(p*.vR*)'])                # vL, wL, vL*
-            _env_set_RP(env, i, RP)
-            return RP
-        return env.get_RP(i, store=True)
-
-    def to_matrix_array(self):
-        """Device matrix of the one-site effective Hamiltonian (reference ``OneSiteH.to_matrix`` :1195)."""
-        if self.move_right:
-            contr = npc.tensordot(self.LHeff, self.RP, axes=['wR', 'wL'])
-            return contr.combine_legs([['(vR*.p0)', 'vL*'], ['(vR.p0*)', 'vL']], qconj=[+1, -1])
-        contr = npc.tensordot(self.LP, self.RHeff, axes=['wR', 'wL'])
-        return contr.combine_legs([['vR*', '(p0.vL*)'], ['vR', '(p0*.vL)']], qconj=[+1, -1])
-
-    def to_matrix(self):
-        """Dense effective Hamiltonian on the host (tests only), rows/columns in the order of ``acts_on``."""
-        if self.move_right:
-            full = np.tensordot(self.LHeff.to_ndarray(), self.RP.transpose(['wL', 'vL*', 'vL']).to_ndarray(), axes=([1], [0]))
-        else:
-            full = np.tensordot(self.LP.transpose(['vR*', 'wR', 'vR']).to_ndarray(),
-                                self.RHeff.transpose(['wL', '(p0.vL*)', '(p0*.vL)']).to_ndarray(), axes=([1], [0]))
-        full = full.transpose(0, 2, 1, 3)        # out_L, out_R, in_L, in_R
-        n = full.shape[0] * full.shape[1]
-        return full.reshape(n, n)
-
-
-class ZeroSiteH:
-    """Zero-site effective Hamiltonian ``LP - RP`` on the bond left of site ``i0`` (reference mps_common.py:1440-1530):
-    acts on a bond matrix [vL, vR]; used by the backward time step of single-site TDVP."""
-    length = 0
-    acts_on = ['vL', 'vR']
-
-    def __init__(self, env, i0):
-        self.i0 = i0
-        self.LP = env.get_LP(i0)
-        self.RP = env.get_RP(i0 - 1)
-        self.dtype = env.H.dtype
-        self.N = self.LP.get_leg('vR').ind_len * self.RP.get_leg('vL').ind_len
-
-    def matvec(self, theta):
-        res = npc.tensordot(self.LP, theta, axes=['vR', 'vL'])
-        res = npc.tensordot(res, self.RP, axes=[['wR', 'vR'], ['wL', 'vL']])
-        res.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
-        return res if list(res.get_leg_labels()) == self.acts_on else res.transpose(self.acts_on)
-
-
-class DensityMatrixMixer:
-    """Density-matrix perturbation ("mixer") of two-site DMRG -- the npc call sequence of the reference's
-    ``DensityMatrixMixer.mix_rho`` / ``svd_from_rho`` (mps_common.py:1972-2079): four tensordots with the
-    effective Hamiltonian halves, ``iscale_axis`` on the MPO leg and two block ``eigh``.
-
-    ``IdL`` / ``IdR`` are the MPO indices on the bond (i0, i0+1) meaning "only identities to the left / right"
-    (``_mix_LR``, :1846).  Returns a general (non-diagonal) bond matrix ``S`` like the reference.
-    """
-
-    def __init__(self, amplitude=1.e-5, IdL=0, IdR=-1, explicit_plus_hc=False, decay=2., disable_after=15,
-                 sweep_activated=0, eigh_via_svd=True):
-        assert amplitude <= 1.
-        self.eigh_via_svd = eigh_via_svd
-        self.amplitude = amplitude
-        self.IdL, self.IdR = IdL, IdR
-        self.explicit_plus_hc = explicit_plus_hc
-        self.decay, self.disable_after, self.sweep_activated = decay, disable_after, sweep_activated
-
-    def update_amplitude(self, sweeps):
-        """Divide the amplitude by ``decay`` after a sweep; returns ``None`` when the mixer should be switched off
-        (``disable_after`` sweeps after activation or amplitude below machine precision; reference :1626-1653)."""
-        off = self.disable_after is not None and sweeps >= self.sweep_activated + self.disable_after
-        if self.amplitude is not None and self.decay is not None:
-            self.amplitude /= self.decay
-            if self.amplitude <= np.finfo('float').eps:
-                off = True
-        return None if off else self
-
-    def _mix_LR(self, chi_MPO):
-        mix_L = np.full((chi_MPO,), self.amplitude)
-        mix_R = np.full((chi_MPO,), self.amplitude)
-        one = 1. if not self.explicit_plus_hc else 0.5
-        if self.IdL is not None:
-            mix_L[self.IdL] = one
-            mix_R[self.IdL] = 0.
-        if self.IdR is not None:
-            mix_L[self.IdR] = 0.
-            mix_R[self.IdR] = one
-        return mix_L, mix_R
-
-    def mix_rho(self, eff_H, theta, mix_left, mix_right):
-        """``rho_L`` [(vL.p0), (vL*.p0*)] and ``rho_R`` [(p1.vR), (p1*.vR*)], perturbed with H where requested."""
-        chi_MPO = eff_H.LHeff.get_leg('wR').ind_len
-        mix_L, mix_R = self._mix_LR(chi_MPO)
-        if mix_left:
-            rho_L = npc.tensordot(eff_H.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])
-            rho_L.ireplace_label('(vR*.p0)', '(vL.p0)')
-            rho_c = rho_L.conj()
-            rho_L.iscale_axis(mix_L, 'wR')
-            rho_L = npc.tensordot(rho_L, rho_c, axes=[['wR', '(p1.vR)'], ['wR*', '(p1*.vR*)']])
-            if self.explicit_plus_hc:
-                rho_L = rho_L + rho_L.conj().itranspose()
-            if self.IdL is None:
-                rho_L = rho_L + npc.tensordot(theta, theta.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
-        else:
-            rho_L = npc.tensordot(theta, theta.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
-        if mix_right:
-            # RHeff is stored as [wL, (p1*.vL), (p1.vL*)] (matvec-friendly order)
-            rho_R = npc.tensordot(theta, eff_H.RHeff, axes=['(p1.vR)', '(p1*.vL)'])
-            rho_R.ireplace_label('(p1.vL*)', '(p1.vR)')
-            rho_c = rho_R.conj()
-            rho_R.iscale_axis(mix_R, 'wL')
-            rho_R = npc.tensordot(rho_c, rho_R, axes=[['wL*', '(vL*.p0*)'], ['wL', '(vL.p0)']])
-            if self.explicit_plus_hc:
-                rho_R = rho_R + rho_R.conj().itranspose()
-            if self.IdR is None:
-                rho_R = rho_R + npc.tensordot(theta.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
-        else:
-            rho_R = npc.tensordot(theta.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
-        return rho_L, rho_R
-
-    def _eigh_psd(self, rho):
-        """Eigenvalues and eigenvectors (as columns) of a positive semi-definite density matrix.
-
-        ``npc.eigh`` (reference :2047 / :2055) runs an un-preconditioned Jacobi iteration on the shifted matrix: ~22 sweeps
-        over ALL rows.  The density matrices of the mixer are theta theta^dagger plus a small perturbation: rank <= chi
-        of d chi and strongly graded, i.e. exactly what the rank-revealing path of the block SVD is made for -- and for a
-        PSD matrix the SVD ``rho = U S U^dagger`` IS the eigendecomposition (S = eigenvalues, U = eigenvectors).
-        Eigenvalues below 1e-15 ||rho|| come back as exact zeros with zero vectors; they are masked out by the caller
-        (with ``npc.eigh`` they are rounding noise that the truncation discards as well)."""
-        if not self.eigh_via_svd:
-            return npc.eigh(rho)
-        U, S, _ = npc.svd(rho, inner_labels=[None, None], inner_qconj=rho.legs[0].qconj)   # -> U.legs[1] == legs[0].conj()
-        # ascending order inside every block, as LAPACK's / the reference's eigh returns it (the order of the new bond
-        # basis inside a charge sector is a gauge choice, but a deterministic one of the reference: keep it)
-        val = np.array(S, dtype=np.float64)
-        sl = U.legs[1].slices
-        for q in range(len(sl) - 1):
-            val[sl[q]:sl[q + 1]] = val[sl[q]:sl[q + 1]][::-1]
-        return val, _reverse_columns(U)
-
-    def svd_from_rho(self, rho_L, rho_R, theta, trunc_params, qtotal_LR=None):
-        """Diagonalise rho_L / rho_R and rewrite theta = U S VH with isometric U, VH and a bond MATRIX S."""
-        from ..linalg.truncation import truncate
-        chinfo = theta.chinfo
-        qL, qR = (None, None) if qtotal_LR is None else qtotal_LR
-        if qL is None and qR is None:
-            qL, qR = chinfo.make_valid(), theta.qtotal
-        elif qL is None:
-            qL = chinfo.make_valid(theta.qtotal - qR)
-        elif qR is None:
-            qR = chinfo.make_valid(theta.qtotal - qL)
-        rho_L = rho_L.transpose(['(vL.p0)', '(vL*.p0*)'])
-        rho_R = rho_R.transpose(['(p1.vR)', '(p1*.vR*)'])
-        val_L, U = self._eigh_psd(rho_L)
-        U.iset_leg_labels(['(vL.p0)', 'vR'])
-        val_L[val_L < 0.] = 0.
-        val_L /= np.sum(val_L)
-        S_a = np.sqrt(val_L)
-        keep_L, _, err_L = truncate(S_a, trunc_params)
-        keep_L = keep_L & (val_L > 0.)          # (exact zeros of the rank-revealing path carry zero vectors)
-        U.iproject(keep_L, axes='vR')
-        U = U.gauge_total_charge(1, qL)
-        val_R, Vc = self._eigh_psd(rho_R)
-        Vc.iset_leg_labels(['(p1.vR)', 'vL'])
-        VH = Vc.itranspose(['vL', '(p1.vR)'])
-        val_R[val_R < 0.] = 0.
-        val_R /= np.sum(val_R)
-        keep_R, _, err_R = truncate(np.sqrt(val_R), trunc_params)
-        keep_R = keep_R & (val_R > 0.)
-        VH.iproject(keep_R, axes='vL')
-        VH = VH.gauge_total_charge(0, qR)
-        S = npc.tensordot(U.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
-        S = npc.tensordot(S, VH.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
-        S.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
-        S.iscale_prefactor(1. / S.norm())
-        return U, S, VH, err_L + err_R, S_a[keep_L]
-
-
-class SubspaceExpansion:
-    """Direct subspace expansion (Hubig et al. 2015) -- the default mixer of single-site DMRG; the npc call sequence of
-    the reference's ``SubspaceExpansion.mix_and_decompose_1site`` (mps_common.py:2082-2201): theta is stacked with
-    ``amplitude**0.5 * (H_eff half) theta`` along the MPO leg (one ``scale_axis`` + one tensordot), the stacked
-    matrix goes through ``svd_theta``, and the MPO leg of the non-isometric factor is projected back onto the identity
-    index with ``take_slice``.  MPOs with ``explicit_plus_hc`` (the stacking branch :2152-2167) are not supported."""
-    can_decompose_1site = True
-
-    def __init__(self, amplitude=1.e-5, IdL=0, IdR=-1, explicit_plus_hc=False, decay=2., disable_after=15, sweep_activated=0):
-        assert amplitude <= 1.
-        if explicit_plus_hc or IdL is None or IdR is None:
-            raise NotImplementedError("tenpy_amd.SubspaceExpansion: needs IdL / IdR and an MPO without explicit_plus_hc")
-        self.amplitude = amplitude
-        self.IdL, self.IdR = IdL, IdR
-        self.explicit_plus_hc = explicit_plus_hc
-        self.decay, self.disable_after, self.sweep_activated = decay, disable_after, sweep_activated
-
-    update_amplitude = DensityMatrixMixer.update_amplitude
-
-    def _mix_LR(self, chi_MPO):
-        amp = np.sqrt(self.amplitude)            # sqrt: `amplitude` then means the same as for the density-matrix mixer
-        mix_L, mix_R = np.full((chi_MPO,), amp), np.full((chi_MPO,), amp)
-        mix_L[self.IdL], mix_R[self.IdL] = 1., 0.
-        mix_L[self.IdR], mix_R[self.IdR] = 0., 1.
-        return mix_L, mix_R
-
-    def mix_and_decompose_1site(self, eff_H, theta, trunc_params, move_right):
-        from ..linalg.truncation import svd_theta
-        if move_right:
-            LHeff = eff_H.LHeff
-            chi_MPO = LHeff.get_leg('wR').ind_len
-            mix_L, _ = self._mix_LR(chi_MPO)
-            th = npc.tensordot(LHeff.scale_axis(mix_L, 'wR'), theta, axes=['(vR.p0*)', '(vL.p0)'])   # (vR*.p0), wR, vR
-            th.ireplace_label('(vR*.p0)', '(vL.p0)')
-            th = th.combine_legs(['wR', 'vR'], qconj=-1)
-            U, S, VH, err, _ = svd_theta(th, trunc_params, qtotal_LR=[theta.qtotal, None], inner_labels=['vR', 'vL'])
-            VH = VH.split_legs('(wR.vR)')
-            VH = VH.take_slice(self.IdL % chi_MPO, 'wR')      # back to the original theta = U S VH (up to truncation)
-        else:
-            RHeff = eff_H._RHeff_p1 if getattr(eff_H, 'length', 2) == 1 else eff_H.RHeff
-            chi_MPO = RHeff.get_leg('wL').ind_len
-            _, mix_R = self._mix_LR(chi_MPO)
-            th = npc.tensordot(theta, RHeff.scale_axis(mix_R, 'wL'), axes=['(p0.vR)', '(p1*.vL)'])   # vL, wL, (p1.vL*)
-            th.ireplace_label('(p1.vL*)', '(p0.vR)')
-            th = th.combine_legs(['vL', 'wL'], qconj=+1)
-            U, S, VH, err, _ = svd_theta(th, trunc_params, qtotal_LR=[None, theta.qtotal], inner_labels=['vR', 'vL'])
-            U = U.split_legs('(vL.wL)')
-            U = U.take_slice(self.IdR % chi_MPO, 'wL')
-        return U, S, VH, err
-
-    def mix_and_decompose_2site(self, eff_H, theta, trunc_params, mix_left, mix_right, qtotal_LR=None):
-        """Two-site theta [(vL.p0), (p1.vR)] decomposed with the one-site expansion on the side(s) to be mixed (reference
-        ``Mixer.mix_and_decompose_2site`` :1764-1822): only the tensor on a mixed side is an isometry, the other factor
-        goes into the bond matrix / stays non-canonical exactly like in the reference."""
-        if mix_left and mix_right:
-            qtotal_L, qtotal_R = (None, None) if qtotal_LR is None else qtotal_LR
-            if qtotal_L is None and qtotal_R is None:
-                qtotal_L, qtotal_R = theta.chinfo.make_valid(), theta.qtotal
-            elif qtotal_L is None:
-                qtotal_L = theta.chinfo.make_valid(theta.qtotal - qtotal_R)
-            elif qtotal_R is None:
-                qtotal_R = theta.chinfo.make_valid(theta.qtotal - qtotal_L)
-            U, _, _, err_L = self.mix_and_decompose_1site(eff_H, theta.replace_label('(p1.vR)', 'vR'), trunc_params, True)
-            U = U.gauge_total_charge(1, qtotal_L)
-            th_R = theta.replace_labels(['(vL.p0)', '(p1.vR)'], ['vL', '(p0.vR)'])
-            _, S_approx, VH, err_R = self.mix_and_decompose_1site(eff_H, th_R, trunc_params, False)
-            VH = VH.gauge_total_charge(0, qtotal_R)
-            VH.ireplace_label('(p0.vR)', '(p1.vR)')
-            S = npc.tensordot(U.conj(), theta, axes=['(vL*.p0*)', '(vL.p0)'])
-            S = npc.tensordot(S, VH.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
-            S.ireplace_labels(['vR*', 'vL*'], ['vL', 'vR'])
-            _, sv, _ = npc.svd(S)
-            S = S / np.linalg.norm(sv)
-            return U, S, VH, err_L + err_R, S_approx
-        if mix_left:
-            U, S, VH, err = self.mix_and_decompose_1site(eff_H, theta.replace_label('(p1.vR)', 'vR'), trunc_params, True)
-            VH.ireplace_label('vR', '(p1.vR)')          # VH is not isometric
-            return U, S, VH, err, S
-        if mix_right:
-            th_R = theta.replace_labels(['(vL.p0)', '(p1.vR)'], ['vL', '(p0.vR)'])
-            U, S, VH, err = self.mix_and_decompose_1site(eff_H, th_R, trunc_params, False)
-            U.ireplace_label('vL', '(vL.p0)')           # U is not isometric
-            VH.ireplace_label('(p0.vR)', '(p1.vR)')
-            return U, S, VH, err, S
-        raise ValueError("Expected mix_left=True and/or mix_right=True.")
-
-
-def full_diag_effH(effH, theta_guess):
-    """Exact diagonalisation of a small effective Hamiltonian in the charge sector of ``theta_guess`` -- the
-    ``diag_method='ED_block'`` of the reference (``full_diag_effH(..., keep_sector=True)``, dmrg.py:1177), which its default
-    ``diag_method='default'`` uses below ``max_N_for_ED`` = 400.  Device version: contract H_eff to a matrix (one block GEMM
-    + one packing copy), project both legs onto the sector (gather kernel), block ``eigh`` (Jacobi), and read the lowest
-    eigenvector off with ``take_slice``.  Returns ``(E0, theta)`` with theta in the form ``effH.acts_on``."""
-    factored = bool(getattr(effH, 'factored', False))
-    if factored:                         # the factored two-site operator acts on [vL, p0, p1, vR]: fuse for the matrix form
-        theta_guess = effH.prepare_svd(theta_guess)
-    acts_on = list(theta_guess.get_leg_labels())
-    fullH = effH.to_matrix_array()
-    pipe = fullH.legs[0]
-    th = theta_guess.combine_legs([acts_on], pipes=[pipe])
-    qi = pipe.get_qindex_of_charges(th.qtotal)
-    sl = pipe.get_slice(qi)
-    mask = np.zeros(pipe.ind_len, dtype=bool)
-    mask[sl] = True
-    block = fullH.copy(deep=False)
-    block.iproject([mask, mask], axes=[0, 1])
-    if block.stored_blocks == 0:         # H vanishes in this sector: nothing to diagonalise (reference :1199)
-        return 0., theta_guess
-    E, V = npc.eigh(block)
-    i0 = int(np.argmin(E))
-    vec = V.take_slice(i0, 1)            # leg: the projected pipe (one sector)
-    theta = npc.Array([pipe], np.result_type(fullH.dtype, theta_guess.dtype), th.qtotal, list(th._labels))
-    if vec.stored_blocks:
-        src = vec if vec.dtype == theta.dtype else vec.astype(theta.dtype)
-        theta._set_blocks(np.array([[qi]], dtype=np.intp), arena=src._repack()._arena, qdata_sorted=True)
-    theta = theta.split_legs([0])
-    if list(theta.get_leg_labels()) != acts_on:
-        theta = theta.transpose(acts_on)
-    return float(E[i0]), (effH.combine_theta(theta) if factored else theta)

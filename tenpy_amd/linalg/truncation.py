@@ -208,72 +208,66 @@ def _qr_theta_Y0(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, ex
 
 def decompose_theta_qr_based(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase,
                              use_eig_based_svd, trunc_params, compute_err, return_both_T):
-    """theta [(vL.p0), (p1.vR)] ~= renormalization * T_Lc . diag(S) . T_Rc via two QRs and the SVD of the bond
-    matrix (reference truncation.py:533-711; same arguments, same returned tuple
-    ``(T_Lc, S, T_Rc, form, trunc_err, renormalization)``)."""
-    if compute_err:
-        return_both_T = True
-    Y0 = _qr_theta_Y0(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase)
-    if move_right:
-        theta_i1 = npc.tensordot(Y0.conj(), theta, ['(vL*.p0*)', '(vL.p0)']).ireplace_label('vR*', 'vL')
-        theta_i1.itranspose(['(p1.vR)', 'vL'])
-        B_R, _ = npc.qr(theta_i1, inner_labels=['vL', 'vR'], inner_qconj=-1)
-        B_R.itranspose(['vL', '(p1.vR)'])
-        theta_i0 = npc.tensordot(theta, B_R.conj(), ['(p1.vR)', '(p1*.vR*)']).ireplace_label('vL*', 'vR')
-        A_L, Xi = npc.qr(theta_i0, inner_labels=['vR', 'vL'])
-    else:
-        theta_i0 = npc.tensordot(theta, Y0.conj(), ['(p1.vR)', '(p1*.vR*)']).ireplace_label('vL*', 'vR')
-        A_L, _ = npc.qr(theta_i0, inner_labels=['vR', 'vL'])
-        theta_i1 = npc.tensordot(A_L.conj(), theta, ['(vL*.p0*)', '(vL.p0)']).ireplace_label('vR*', 'vL')
-        theta_i1.itranspose(['(p1.vR)', 'vL'])
-        B_R, Xi = npc.qr(theta_i1, inner_labels=['vL', 'vR'], inner_qconj=-1)
-        B_R.itranspose(['vL', '(p1.vR)'])
-        Xi.itranspose(['vL', 'vR'])
-    if use_eig_based_svd:
-        U, S, Vd, _, renormalization = _eig_based_svd(Xi, need_U=move_right, need_Vd=(not move_right),
+    """``theta`` [(vL.p0), (p1.vR)] ~= renormalization * T_Lc . diag(S) . T_Rc without an SVD of theta itself: two block
+    QRs give isometries A (left) and B (right) around a small bond matrix ``Xi``, which alone is decomposed (block SVD,
+    or ``_eig_based_svd``).  Same arguments and returned tuple ``(T_Lc, S, T_Rc, form, trunc_err, renormalization)`` as the
+    reference (truncation.py:533-711); everything is block GEMM / block QR on the device."""
+    want_both = bool(return_both_T or compute_err)
+
+    def onto_right(mat, iso):        # mat . iso^dagger : [(vL.p0), (p1.vR)] -> [(vL.p0), vR]
+        return npc.tensordot(mat, iso.conj(), ['(p1.vR)', '(p1*.vR*)']).ireplace_label('vL*', 'vR')
+
+    def onto_left(iso, mat):         # iso^dagger . mat : [(vL.p0), (p1.vR)] -> [vL, (p1.vR)]
+        return npc.tensordot(iso.conj(), mat, ['(vL*.p0*)', '(vL.p0)']).ireplace_label('vR*', 'vL')
+
+    def left_isometry(mat):          # [(vL.p0), vR] = A . R
+        return npc.qr(mat, inner_labels=['vR', 'vL'])
+
+    def right_isometry(mat):         # [vL, (p1.vR)] = R . B   (QR of the transpose)
+        q, r = npc.qr(mat.itranspose(['(p1.vR)', 'vL']), inner_labels=['vL', 'vR'], inner_qconj=-1)
+        return q.itranspose(['vL', '(p1.vR)']), r.itranspose(['vL', 'vR'])
+
+    guess = _qr_theta_Y0(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase)
+    if move_right:                   # guess spans the left space: first B from it, then A from theta . B^dagger
+        B_R, _ = right_isometry(onto_left(guess, theta))
+        A_L, Xi = left_isometry(onto_right(theta, B_R))
+    else:                            # guess spans the right space
+        A_L, _ = left_isometry(onto_right(theta, guess))
+        B_R, Xi = right_isometry(onto_left(A_L, theta))
+    if use_eig_based_svd:            # only the factor on the side we move to comes out of the eigen-decomposition
+        U, S, Vd, _, renormalization = _eig_based_svd(Xi, need_U=move_right, need_Vd=not move_right,
                                                       inner_labels=['vR', 'vL'], trunc_params=trunc_params)
     else:
         U, S, Vd, _, renormalization = svd_theta(Xi, trunc_params)
+
+    def left_factor():               # -> (tensor, canonical form)
+        if U is not None:
+            return npc.tensordot(A_L, U, ['vR', 'vL']), 'A'
+        t = npc.tensordot(npc.tensordot(A_L, Xi, ['vR', 'vL']), Vd.conj(), ['vR', 'vR*']).ireplace_label('vL*', 'vR')
+        return t.iscale_prefactor(1. / npc.norm(t)), 'Th'
+
+    def right_factor():
+        if Vd is not None:
+            return npc.tensordot(Vd, B_R, ['vR', 'vL']), 'B'
+        t = npc.tensordot(U.conj(), npc.tensordot(Xi, B_R, ['vR', 'vL']), ['vL*', 'vL']).ireplace_label('vR*', 'vL')
+        return t.iscale_prefactor(1. / npc.norm(t)), 'Th'
+
     T_Lc = T_Rc = None
     form = ['A', 'B']
-    if move_right:
-        T_Lc = npc.tensordot(A_L, U, ['vR', 'vL'])
-        if return_both_T:
-            if use_eig_based_svd:
-                T_Rc = npc.tensordot(Xi, B_R, ['vR', 'vL'])
-                T_Rc = npc.tensordot(U.conj(), T_Rc, ['vL*', 'vL']).ireplace_label('vR*', 'vL')
-                T_Rc.iscale_prefactor(1. / npc.norm(T_Rc))
-                form[1] = 'Th'
-            else:
-                T_Rc = npc.tensordot(Vd, B_R, ['vR', 'vL'])
-    else:
-        T_Rc = npc.tensordot(Vd, B_R, ['vR', 'vL'])
-        if return_both_T:
-            if use_eig_based_svd:
-                T_Lc = npc.tensordot(A_L, Xi, ['vR', 'vL'])
-                T_Lc = npc.tensordot(T_Lc, Vd.conj(), ['vR', 'vR*']).ireplace_label('vL*', 'vR')
-                T_Lc.iscale_prefactor(1. / npc.norm(T_Lc))
-                form[0] = 'Th'
-            else:
-                T_Lc = npc.tensordot(A_L, U, ['vR', 'vL'])
-    if compute_err:
-        if use_eig_based_svd:
-            approx = npc.tensordot(T_Lc, T_Rc, ['vR', 'vL'])
-        else:
-            approx = npc.tensordot(T_Lc.scale_axis(S, axis='vR'), T_Rc, ['vR', 'vL'])
-        N_theta = npc.norm(theta)
-        diff = theta * (1. / N_theta)
-        diff.iadd_prefactor_other(-renormalization / N_theta, approx)
-        eps = npc.norm(diff)**2
+    if move_right or want_both:
+        T_Lc, form[0] = left_factor()
+    if (not move_right) or want_both:
+        T_Rc, form[1] = right_factor()
+    trunc_err = TruncationError(np.nan, np.nan)
+    if compute_err:                  # || theta / |theta|  -  renormalization / |theta| * T_Lc S T_Rc ||^2
+        weighted = T_Lc if 'Th' in form else T_Lc.scale_axis(S, axis='vR')
+        scale = 1. / npc.norm(theta)
+        residual = theta * scale
+        residual.iadd_prefactor_other(-renormalization * scale, npc.tensordot(weighted, T_Rc, ['vR', 'vL']))
+        eps = npc.norm(residual)**2
         trunc_err = TruncationError(eps, 1. - 2. * eps)
-    else:
-        trunc_err = TruncationError(np.nan, np.nan)
-    if move_right:
+    if T_Lc is not None:
         T_Lc.ireplace_label('(vL.p0)', '(vL.p)')
-        if return_both_T:
-            T_Rc.ireplace_label('(p1.vR)', '(p.vR)')
-    else:
+    if T_Rc is not None:
         T_Rc.ireplace_label('(p1.vR)', '(p.vR)')
-        if return_both_T:
-            T_Lc.ireplace_label('(vL.p0)', '(vL.p)')
     return T_Lc, S, T_Rc, form, trunc_err, renormalization

@@ -13,13 +13,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running")
 
 
-# GPU variants written after this round's GPU budget was spent (never run on the MI355X by the author): collected LAST,
-# so that with ``-x`` a surprise in them cannot hide the validated part of the suite.  
-_LATE_FILES = ('test_dmrg_single_golden.py', 'test_svd_rule.py', 'test_tebd_orders_and_imaginary_time', 'test_dmrg_ortho_golden.py', 'test_tdvp_golden.py', 'test_idmrg_golden.py', 'test_tebd_infinite_benchmark_model', 'test_mps_golden.py', 'test_tebd_run_GS', 'test_nocharge_golden.py', 'test_npc_random.py', 'test_mpo_evolution_golden.py', 'test_hubbard_single_site_dmrg_and_tdvp', 'test_resume_single_site_and_infinite')
-
-
 def pytest_collection_modifyitems(config, items):
-    items.sort(key=lambda it: any(f in it.nodeid for f in _LATE_FILES))
     try:
         import torch
         have_gpu = torch.cuda.is_available()

@@ -342,42 +342,6 @@ def gen_qr_theta():
     save('qr_theta.pkl', out)
 
 
-def gen_mixer():
-    """DensityMatrixMixer.mix_rho / svd_from_rho of the reference on a dumped bond (LP, RP, W0, W1, theta)."""
-    from tenpy.algorithms import dmrg, mps_common
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 10
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.3, 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
-        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-        eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': True, 'mixer_params': {'amplitude': 1.e-2, 'decay': 1., 'disable_after': 100},
-                                              'trunc_params': {'chi_max': 12, 'svd_min': 1e-10}, 'combine': True})
-        eng.sweep()
-        eng.sweep()
-        i0 = L // 2 - 1
-        eng.i0 = i0
-        eng.move_right = True
-        eng.make_eff_H()
-        theta = eng.eff_H.combine_theta(psi.get_theta(i0, n=2))
-        theta = theta + 1e-2 * rand_array(theta.legs, qtotal=theta.qtotal, labels=theta.get_leg_labels())
-        H = M.H_MPO
-        for amplitude in (1e-2, 0.3):
-            mixer = mps_common.DensityMatrixMixer({'amplitude': amplitude, 'decay': 1., 'disable_after': 100}, 0)
-            for ml, mr in ((True, True), (True, False), (False, True)):
-                rho_L, rho_R = mixer.mix_rho(eng, theta, i0, ml, mr)
-                qLR = [psi.get_B(i0, None).qtotal, None]
-                U, S, VH, err, S_a = mixer.svd_from_rho(eng, rho_L.copy(deep=True), rho_R.copy(deep=True), theta, qLR)
-                out.append(dict(LP=dump_array(eng.env.get_LP(i0)), RP=dump_array(eng.env.get_RP(i0 + 1)),
-                                W0=dump_array(H.get_W(i0)), W1=dump_array(H.get_W(i0 + 1)), theta=dump_array(theta),
-                                IdL=H.get_IdL(i0 + 1), IdR=H.get_IdR(i0), amplitude=amplitude, mix_left=ml, mix_right=mr,
-                                rho_L=dump_array(rho_L), rho_R=dump_array(rho_R), S=dump_array(S), S_a=np.array(S_a),
-                                qtotal_L=np.array(qLR[0]), eps=float(err.eps), U=dump_array(U), VH=dump_array(VH), chi_max=12))
-    save('mixer.pkl', out)
-
-
 def gen_hubbard():
     """BASELINE config 4 in small: Fermi-Hubbard 2 x 4 ladder, charges (N, 2Sz), two-site DMRG chi=64."""
     from tenpy.algorithms import dmrg
@@ -401,114 +365,6 @@ def gen_hubbard():
                             S_ent=np.array(psi.entanglement_entropy()), D_mpo=max(M.H_MPO.chi)))
             print(out[-1]['name'], Es[-1], chis[-1], 'MPO D', max(M.H_MPO.chi))
     save('hubbard.pkl', out)
-
-
-def gen_dmrg_mixer():
-    """Two-site DMRG WITH the density-matrix mixer (mixer on for the first sweeps, then decays / is disabled), then
-    mixer_cleanup: energies of every update, truncation errors, final Schmidt spectra."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for (L, Jz, hz, chi, amp, decay, dis, n_sweeps) in ((12, 1.3, 0., 16, 1.e-3, 2., 4, 7), (10, 0.7, 0.2, 12, 1.e-2, 1.5, 3, 6)):
-            M = XXZChain({'L': L, 'Jxx': 1., 'Jz': Jz, 'hz': hz, 'bc_MPS': 'finite', 'sort_charge': True})
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-            eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': True, 'mixer_params': {'amplitude': amp, 'decay': decay, 'disable_after': dis},
-                                                  'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6}})
-            # svd_min = 1e-6 on purpose: the mixed density matrices are rank deficient while the bond dimension is
-            # still growing; with svd_min = 1e-10 eigenvalues that are pure rounding noise (1e-17 -> S = 3e-9) decide
-            # which "state" is kept and the trajectory is not reproducible across LAPACK builds
-            eng.mixer_activate()
-            Es, mixer_on = [], []
-            for s in range(n_sweeps):
-                mixer_on.append(eng.mixer is not None)
-                eng.sweep()
-                Es.append(float(eng.update_stats['E_total'][-1]))
-            eng.mixer_cleanup()
-            out.append(dict(L=L, Jxx=1., Jz=Jz, hz=hz, chi=chi, amplitude=amp, decay=decay, disable_after=dis, n_sweeps=n_sweeps,
-                            E_sweeps=Es, mixer_on=mixer_on, E_updates=[float(e) for e in eng.update_stats['E_total']],
-                            err_updates=[float(e.eps) for e in eng.update_stats['err']],
-                            S=[np.array(psi.get_SL(i)) for i in range(1, L)], S_ent=np.array(psi.entanglement_entropy()),
-                            E_mpo=float(np.real(M.H_MPO.expectation_value(psi))), svd_min=1.e-6))
-            print('dmrg_mixer', L, Es, mixer_on)
-    save('dmrg_mixer.pkl', out)
-
-
-def gen_dmrg_single():
-    """Single-site DMRG (OneSiteH, combine=True): (a) from a product state with the SubspaceExpansion mixer,
-    (b) two two-site sweeps first, then single-site sweeps without any mixer.  Energies of every update, truncation
-    errors, mixer schedule, final Schmidt spectra after mixer_cleanup."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for (L, Jz, hz, chi, amp, decay, dis, n_sweeps, pre2) in ((12, 1.3, 0., 16, 1.e-3, 2., 4, 7, 0), (10, 0.7, 0.2, 12, 1.e-2, 1.5, 3, 6, 0),
-                                                                  (12, 1.0, 0., 14, None, None, None, 3, 2)):
-            M = XXZChain({'L': L, 'Jxx': 1., 'Jz': Jz, 'hz': hz, 'bc_MPS': 'finite', 'sort_charge': True})
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-            E_pre = []
-            if pre2:
-                e2 = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
-                                                     'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}})
-                for s in range(pre2):
-                    e2.sweep()
-                    E_pre.append(float(e2.update_stats['E_total'][-1]))
-            opts = {'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6 if amp else 1.e-10}}
-            if amp:
-                opts.update(mixer=True, mixer_params={'amplitude': amp, 'decay': decay, 'disable_after': dis})
-            else:
-                opts.update(mixer=None)
-            eng = dmrg.SingleSiteDMRGEngine(psi, M, opts)
-            eng.mixer_activate()
-            Es, mixer_on = [], []
-            for s in range(n_sweeps):
-                mixer_on.append(eng.mixer is not None)
-                eng.sweep()
-                Es.append(float(eng.update_stats['E_total'][-1]))
-            eng.mixer_cleanup()
-            out.append(dict(L=L, Jxx=1., Jz=Jz, hz=hz, chi=chi, amplitude=amp, decay=decay, disable_after=dis, n_sweeps=n_sweeps,
-                            pre_two_site_sweeps=pre2, E_pre=E_pre, E_sweeps=Es, mixer_on=mixer_on,
-                            i0_updates=[int(i) for i in eng.update_stats['i0']],
-                            E_updates=[float(e) for e in eng.update_stats['E_total']],
-                            err_updates=[float(e.eps) for e in eng.update_stats['err']],
-                            chi_final=[int(c) for c in psi.chi],
-                            S=[np.array(psi.get_SL(i)) for i in range(1, L)], S_ent=np.array(psi.entanglement_entropy()),
-                            E_mpo=float(np.real(M.H_MPO.expectation_value(psi))), svd_min=opts['trunc_params']['svd_min']))
-            print('dmrg_single', L, Es, mixer_on, psi.chi)
-    save('dmrg_single.pkl', out)
-
-
-def gen_dmrg_two_site_subspace():
-    """Two-site DMRG with mixer='SubspaceExpansion' (Mixer.mix_and_decompose_2site falling back to the one-site
-    decomposition)."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for (L, Jz, hz, chi, amp, decay, dis, n_sweeps) in ((12, 1.3, 0., 16, 1.e-3, 2., 3, 5), ):
-            M = XXZChain({'L': L, 'Jxx': 1., 'Jz': Jz, 'hz': hz, 'bc_MPS': 'finite', 'sort_charge': True})
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-            eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': 'SubspaceExpansion', 'mixer_params': {'amplitude': amp, 'decay': decay, 'disable_after': dis},
-                                                  'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6}})
-            eng.mixer_activate()
-            Es, mixer_on = [], []
-            for s in range(n_sweeps):
-                mixer_on.append(eng.mixer is not None)
-                eng.sweep()
-                Es.append(float(eng.update_stats['E_total'][-1]))
-            eng.mixer_cleanup()
-            out.append(dict(L=L, Jxx=1., Jz=Jz, hz=hz, chi=chi, amplitude=amp, decay=decay, disable_after=dis, n_sweeps=n_sweeps,
-                            E_sweeps=Es, mixer_on=mixer_on, E_updates=[float(e) for e in eng.update_stats['E_total']],
-                            err_updates=[float(e.eps) for e in eng.update_stats['err']],
-                            S=[np.array(psi.get_SL(i)) for i in range(1, L)], svd_min=1.e-6))
-            print('dmrg_two_site_subspace', L, Es, mixer_on)
-    save('dmrg_two_site_subspace.pkl', out)
 
 
 def gen_krylov2():
@@ -601,542 +457,9 @@ def gen_api2():
     save('api2.pkl', out)
 
 
-def gen_tebd2():
-    """TEBD with the other Suzuki-Trotter orders (1, 4, '4_opt'; 3 merged steps per evolve call) and imaginary time."""
-    from tenpy.algorithms import tebd
-    from tenpy.models.tf_ising import TFIChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 8
-        M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': 'parity', 'sort_charge': True})
-        h_bond = [None if h is None else h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond]
-        labels = list(M.lat.mps_sites()[0].state_labels.items())
-        for order, type_evo in ((1, 'real'), (2, 'real'), (4, 'real'), ('4_opt', 'real'), (2, 'imag'), (4, 'imag')):
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
-            eng = tebd.TEBDEngine(psi, M, {'order': order, 'dt': 0.05, 'N_steps': 3, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}})
-            eng.calc_U(order, 0.05, type_evo=type_evo)
-            S_t, chi_t, errs = [], [], []
-            for rep in range(4):
-                err = eng.evolve(3, 0.05)
-                S_t.append(np.array(psi.entanglement_entropy()))
-                chi_t.append(int(max(psi.chi)))
-                errs.append(float(err.eps))
-            out.append(dict(order=order, type_evo=type_evo, L=L, dt=0.05, chi=12, N_steps=3, S_t=np.array(S_t), chi_t=chi_t, err_t=errs,
-                            evolved_time=complex(eng.evolved_time), decomposition=list(tebd.TEBDEngine.suzuki_trotter_decomposition(order, 3)),
-                            time_steps=list(tebd.TEBDEngine.suzuki_trotter_time_steps(order)),
-                            S_mid=np.array(psi.get_SL(L // 2)), h_bond=h_bond, state_labels=labels, conserve='parity'))
-            print('tebd2', order, type_evo, chi_t, S_t[-1][L // 2 - 1])
-    save('tebd2.pkl', out)
-
-
-def gen_dmrg_ortho():
-    """Excited state by DMRG with ``orthogonal_to=[ground state]`` (two-site and single-site engines)."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L, chi = 10, 24
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.2, 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
-        psi0 = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-        e0 = dmrg.TwoSiteDMRGEngine(psi0, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}})
-        E0s = []
-        for s_ in range(5):
-            e0.sweep()
-            E0s.append(float(e0.update_stats['E_total'][-1]))
-        for engine, n_sw in (('two', 6), ('single', 6)):
-            psi1 = MPS.from_product_state(M.lat.mps_sites(), ['down', 'up'] * (L // 2), bc='finite')
-            cls = dmrg.TwoSiteDMRGEngine if engine == 'two' else dmrg.SingleSiteDMRGEngine
-            opts = {'combine': True, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-6 if engine == 'single' else 1.e-10}}
-            if engine == 'single':
-                opts.update(mixer=True, mixer_params={'amplitude': 1.e-3, 'decay': 2., 'disable_after': 3})
-            else:
-                opts.update(mixer=None)
-            e1 = cls(psi1, M, opts, orthogonal_to=[psi0])
-            e1.mixer_activate()
-            Es = []
-            for s_ in range(n_sw):
-                e1.sweep()
-                Es.append(float(e1.update_stats['E_total'][-1]))
-            e1.mixer_cleanup()
-            out.append(dict(engine=engine, L=L, Jxx=1., Jz=1.2, hz=0., chi=chi, E0_sweeps=E0s, E1_sweeps=Es,
-                            E1_updates=[float(e) for e in e1.update_stats['E_total']], overlap=complex(psi0.overlap(psi1)),
-                            E1_mpo=float(np.real(M.H_MPO.expectation_value(psi1))), svd_min=opts['trunc_params']['svd_min']))
-            print('dmrg_ortho', engine, E0s[-1], Es, abs(psi0.overlap(psi1)))
-    save('dmrg_ortho.pkl', out)
-
-
-def gen_dmrg_default_diag():
-    """Two-site DMRG with the reference's DEFAULT diagonalisation (ED below max_N_for_ED=400, Lanczos above) and with
-    'ED_block' everywhere (small chi)."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for (L, chi, method, engine) in ((14, 24, 'default', 'two'), (10, 8, 'ED_block', 'two'), (12, 12, 'ED_block', 'single')):
-            M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.8, 'hz': 0.1, 'bc_MPS': 'finite', 'sort_charge': True})
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-            opts = {'combine': True, 'diag_method': method, 'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10 if engine == 'two' else 1.e-6}}
-            if engine == 'two':
-                opts['mixer'] = None
-                eng = dmrg.TwoSiteDMRGEngine(psi, M, opts)
-            else:
-                opts.update(mixer=True, mixer_params={'amplitude': 1.e-3, 'decay': 2., 'disable_after': 3})
-                eng = dmrg.SingleSiteDMRGEngine(psi, M, opts)
-            eng.mixer_activate()
-            Es = []
-            for s_ in range(5):
-                eng.sweep()
-                Es.append(float(eng.update_stats['E_total'][-1]))
-            eng.mixer_cleanup()
-            out.append(dict(L=L, Jxx=1., Jz=0.8, hz=0.1, chi=chi, diag_method=method, engine=engine, E_sweeps=Es,
-                            E_updates=[float(e) for e in eng.update_stats['E_total']], N_lanczos=[int(n) for n in eng.update_stats['N_lanczos']],
-                            svd_min=opts['trunc_params']['svd_min'], S=[np.array(psi.get_SL(i)) for i in range(1, L)]))
-            print('dmrg_default_diag', L, chi, method, engine, Es[-1], sorted(set(out[-1]['N_lanczos']))[:5])
-    save('dmrg_default_diag.pkl', out)
-
-
-def gen_dmrg_run():
-    """The reference's ``DMRGEngine.run()`` main loop with its default options (examples/d_dmrg.py parameters: TFI chain,
-    chi_max=30, svd_min=1e-10, max_E_err=1e-10, no mixer, combine, DEFAULT diag_method and Lanczos tolerances that follow
-    the truncation error), and an XXZ run with the mixer on by default parameters."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.tf_ising import TFIChain
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for case in ('tfi_d_dmrg', 'xxz_mixer'):
-            if case == 'tfi_d_dmrg':
-                L = 16
-                M = TFIChain({'L': L, 'J': 1., 'g': 1., 'bc_MPS': 'finite', 'conserve': None})
-                psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
-                opts = {'mixer': None, 'max_E_err': 1.e-10, 'trunc_params': {'chi_max': 30, 'svd_min': 1.e-10}, 'combine': True}
-                extra = dict(L=L, J=1., g=1., conserve=None)
-            else:
-                L = 12
-                M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
-                psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-                opts = {'mixer': True, 'mixer_params': {'amplitude': 1.e-4, 'decay': 2., 'disable_after': 4}, 'max_E_err': 1.e-9,
-                        'trunc_params': {'chi_max': 20, 'svd_min': 1.e-6}, 'combine': True, 'max_N_for_ED': 0}
-                extra = dict(L=L, Jxx=1., Jz=1., hz=0., conserve='Sz')
-            import copy
-            opts_plain = copy.deepcopy(opts)
-            eng = dmrg.TwoSiteDMRGEngine(psi, M, opts)
-            E, _ = eng.run()
-            st = eng.sweep_stats
-            rec = dict(case=case, E=float(E), sweeps=int(eng.sweeps), P_tol_final=float(eng.lanczos_params['P_tol']),
-                       N_lanczos=[int(n) for n in eng.update_stats['N_lanczos']], E_updates=[float(e) for e in eng.update_stats['E_total']],
-                       E_trunc=[None if e is None else float(e) for e in eng.update_stats['E_trunc']],
-                       sweep_stats={k: [float(x) for x in st[k]] for k in ('sweep', 'N_updates', 'E', 'Delta_E', 'S', 'Delta_S', 'max_S',
-                                                                              'max_trunc_err', 'max_E_trunc', 'max_chi')},
-                       options=opts_plain)
-            rec.update(extra)
-            out.append(rec)
-            print('dmrg_run', case, E, eng.sweeps, eng.lanczos_params['P_tol'])
-    save('dmrg_run.pkl', out)
-
-
-def gen_tdvp():
-    """Real-time TDVP after a quench from the Neel state (XXZ, Sz conserved): two-site engine growing the bond dimension,
-    then the single-site engine continuing on the same state."""
-    from tenpy.algorithms import tdvp
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 8
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.7, 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
-        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-        opts = {'dt': 0.05, 'N_steps': 2, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 2, 'N_max': 20}}
-        eng = tdvp.TwoSiteTDVPEngine(psi, M, dict(opts))
-        recs = []
-        for rep in range(4):
-            eng.run()
-            recs.append(dict(engine='two', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
-                             Sz=np.array(psi.expectation_value('Sz')), norm=float(psi.norm), t=float(eng.evolved_time),
-                             trunc_err=float(eng.trunc_err.eps)))
-        eng1 = tdvp.SingleSiteTDVPEngine(psi, M, dict(opts))
-        for rep in range(4):
-            eng1.run()
-            recs.append(dict(engine='single', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
-                             Sz=np.array(psi.expectation_value('Sz')), norm=float(psi.norm), t=float(eng1.evolved_time),
-                             trunc_err=float(eng1.trunc_err.eps)))
-        out.append(dict(L=L, Jxx=1., Jz=0.7, hz=0., options=opts, steps=recs,
-                        E=float(np.real(M.H_MPO.expectation_value(psi)))))
-        print('tdvp', [r['chi'] for r in recs][-1], recs[-1]['S'], recs[-1]['norm'])
-    save('tdvp.pkl', out)
-
-
-def gen_idmrg():
-    """Infinite DMRG (two-site, Lanczos always): XXZ chain with a 2-site unit cell and TFI with parity, through the
-    reference's run() loop (N_sweeps_check, environment sweeps, energy per site from the growth of the system)."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.tf_ising import TFIChain
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    import copy
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for case in ('xxz', 'tfi', 'xxz_mixer'):
-            if case.startswith('xxz'):
-                L = 2
-                M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.5, 'hz': 0., 'bc_MPS': 'infinite', 'sort_charge': True})
-                psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
-                extra = dict(L=L, Jxx=1., Jz=1.5, hz=0., conserve='Sz')
-            else:
-                L = 2
-                M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'infinite', 'conserve': 'parity', 'sort_charge': True})
-                psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'up'], bc='infinite')
-                extra = dict(L=L, J=1., g=1.5, conserve='parity')
-            opts = {'mixer': None, 'combine': True, 'max_N_for_ED': 0, 'max_E_err': 1.e-10, 'max_sweeps': 40, 'N_sweeps_check': 5,
-                    'trunc_params': {'chi_max': 16, 'svd_min': 1.e-10}}
-            if case == 'xxz_mixer':
-                opts.update(mixer=True, mixer_params={'amplitude': 1.e-4, 'decay': 1.5, 'disable_after': 6})
-                opts['trunc_params']['svd_min'] = 1.e-6
-            opts_plain = copy.deepcopy(opts)
-            eng = dmrg.TwoSiteDMRGEngine(psi, M, opts)
-            E, _ = eng.run()
-            st = eng.sweep_stats
-            rec = dict(case=case, E=float(E), sweeps=int(eng.sweeps), options=opts_plain,
-                       E_updates=[float(e) for e in eng.update_stats['E_total']], age=[int(a) for a in eng.update_stats['age']],
-                       i0=[int(i) for i in eng.update_stats['i0']],
-                       sweep_stats={k: [float(x) for x in st[k]] for k in ('sweep', 'N_updates', 'E', 'Delta_E', 'S', 'Delta_S', 'max_S',
-                                                                              'max_trunc_err', 'max_E_trunc', 'max_chi')},
-                       S=[np.array(psi.get_SL(i)) for i in range(L)], chi=[int(c) for c in psi.chi])
-            rec.update(extra)
-            out.append(rec)
-            print('idmrg', case, E, eng.sweeps, psi.chi)
-    save('idmrg.pkl', out)
-
-
-def gen_idmrg_bench():
-    """The reference's iDMRG benchmark (tests/benchmark/dmrg_infinite.py) in small: spin-2 chain with D=0.3, Sz conserved,
-    Lanczos N_min=N_max=10, optimisation sweeps alternating with environment sweeps."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.spins import SpinChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L, chi = 4, 14
-        M = SpinChain(dict(L=L, S=2., D=0.3, bc_MPS='infinite', conserve='Sz', sort_charge=True))
-        psi = MPS.from_product_state(M.lat.mps_sites(), (['up', 'down'] * L)[:L], bc='infinite')
-        eng = dmrg.TwoSiteDMRGEngine(psi, M, {'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 10, 'N_max': 10},
-                                              'max_N_for_ED': 0, 'combine': True})
-        eng.diag_method = 'lanczos'
-        for i in range(6):
-            eng.sweep(meas_E_trunc=False)
-            eng.sweep(optimize=False, meas_E_trunc=False)
-        Es, ages = eng.update_stats['E_total'], eng.update_stats['age']
-        out.append(dict(L=L, chi=chi, S=2., D=0.3, E_updates=[float(e) for e in Es], age=[int(a) for a in ages],
-                        i0=[int(i) for i in eng.update_stats['i0']], chi_final=[int(c) for c in psi.chi],
-                        S_ent=np.array(psi.entanglement_entropy()), state_labels=list(M.lat.mps_sites()[0].state_labels.items())))
-        print('idmrg_bench', psi.chi, (Es[-1] - Es[-9]) / (ages[-1] - ages[-9]))
-    save('idmrg_bench.pkl', out)
-
-
-def gen_tebd_infinite():
-    """The reference's TEBD benchmark (tests/benchmark/tebd_infinite.py) in small: infinite spin-2 chain, order 2."""
-    from tenpy.algorithms import tebd
-    from tenpy.models.spins import SpinChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L, chi = 2, 12
-        M = SpinChain(dict(L=L, S=2., D=0.3, bc_MPS='infinite', conserve='Sz', sort_charge=True))
-        psi = MPS.from_product_state(M.lat.mps_sites(), (['up', 'down'] * L)[:L], bc='infinite')
-        eng = tebd.TEBDEngine(psi, M, {'trunc_params': {'chi_max': chi, 'svd_min': 1.e-10}, 'order': 2, 'N_steps': 2, 'dt': 0.05})
-        S_t, chi_t = [], []
-        for rep in range(5):
-            eng.run()
-            S_t.append(np.array(psi.entanglement_entropy()))
-            chi_t.append([int(c) for c in psi.chi])
-        out.append(dict(L=L, chi=chi, S_t=np.array(S_t), chi_t=chi_t, trunc_err=float(eng.trunc_err.eps), t=float(eng.evolved_time),
-                        h_bond=[h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond],
-                        S0=np.array(psi.get_SL(0)), S1=np.array(psi.get_SL(1))))
-        print('tebd_infinite', chi_t[-1], S_t[-1])
-    save('tebd_infinite.pkl', out)
-
-
-def gen_canonical_form():
-    """MPS.canonical_form of a finite MPS made of random (non-canonical) tensors and of a slightly perturbed canonical one."""
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    r4 = np.random.RandomState(99)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 6
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
-        for cplx in (False, True):
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite', dtype=np.complex128 if cplx else np.float64)
-            from tenpy.algorithms import tebd
-            eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.1, 'N_steps': 4, 'trunc_params': {'chi_max': 8, 'svd_min': 1.e-10}})
-            eng.run()
-            # perturb every tensor: the form labels stay 'B' but the state is no longer canonical
-            Bs_in = []
-            for i in range(L):
-                B = psi.get_B(i, 'B')
-                noise = npc.Array.from_func(lambda size: 0.05 * (r4.standard_normal(size) + (1.j * r4.standard_normal(size) if cplx else 0.)),
-                                            B.legs, dtype=B.dtype, qtotal=B.qtotal, shape_kw='size')
-                noise.iset_leg_labels(B.get_leg_labels())
-                Bn = B + noise
-                psi.set_B(i, Bn, form='B')
-                Bs_in.append(dump_array(Bn.transpose(['vL', 'p', 'vR'])))
-            S_in = [np.array(psi.get_SL(i)) for i in range(L)] + [np.array(psi.get_SR(L - 1))]
-            for renorm in (True, False):
-                p2 = psi.copy()
-                p2.canonical_form(renormalize=renorm)
-                out.append(dict(L=L, cplx=cplx, renormalize=renorm, B_in=Bs_in, S_in=S_in, norm=float(p2.norm),
-                                S_out=[np.array(p2.get_SL(i)) for i in range(L)] + [np.array(p2.get_SR(L - 1))], S_ent=np.array(p2.entanglement_entropy()),
-                                overlap=complex(p2.overlap(psi)), chi=[int(c) for c in p2.chi]))
-            print('canonical_form', cplx, out[-1]['norm'], out[-1]['chi'])
-    save('canonical_form.pkl', out)
-
-
-def gen_canonical_form_infinite():
-    """canonical_form of an infinite MPS that is slightly out of canonical form (after real-time iTEBD with truncation
-    and an extra perturbation of the tensors)."""
-    from tenpy.algorithms import tebd
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    r5 = np.random.RandomState(123)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 2
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.5, 'hz': 0., 'bc_MPS': 'infinite', 'sort_charge': True})
-        for cplx in (False, True):
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
-            eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.1, 'N_steps': 6, 'trunc_params': {'chi_max': 8, 'svd_min': 1.e-10}})
-            if cplx:
-                eng.run()
-            else:
-                eng.calc_U(2, 0.1, type_evo='imag')
-                eng.evolve(6, 0.1)
-            Bs_in = []
-            for i in range(L):
-                B = psi.get_B(i, 'B')
-                noise = npc.Array.from_func(lambda size: 0.03 * (r5.standard_normal(size) + (1.j * r5.standard_normal(size) if cplx else 0.)),
-                                            B.legs, dtype=B.dtype, qtotal=B.qtotal, shape_kw='size')
-                noise.iset_leg_labels(B.get_leg_labels())
-                Bn = B + noise
-                psi.set_B(i, Bn, form='B')
-                Bs_in.append(dump_array(Bn.transpose(['vL', 'p', 'vR'])))
-            S_in = [np.array(psi.get_SL(i)) for i in range(L)]
-            err_in = np.array(psi.norm_test())
-            psi_before = psi.copy()
-            psi.canonical_form()
-            import warnings as _w
-            ov_self = complex(psi.overlap(psi, understood_infinite=True))
-            other = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
-            ov_prod = complex(psi.overlap(other, understood_infinite=True))
-            out.append(dict(L=L, cplx=cplx, ov_self=ov_self, ov_prod=ov_prod, norm=float(psi.norm), B_in=Bs_in, S_in=S_in, err_in=err_in, err_out=np.array(psi.norm_test()),
-                            S_out=[np.array(psi.get_SL(i)) for i in range(L)], S_ent=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
-                            Sz=np.array(psi.expectation_value('Sz'))))
-            print('canonical_form_infinite', cplx, np.linalg.norm(err_in), np.linalg.norm(out[-1]['err_out']), out[-1]['chi'], out[-1]['S_ent'])
-    save('canonical_form_infinite.pkl', out)
-
-
-def gen_tebd_gs():
-    """TEBDEngine.run_GS (imaginary time, decreasing steps) for a finite chain (update_imag sweeps) and an infinite one."""
-    from tenpy.algorithms import tebd
-    from tenpy.models.tf_ising import TFIChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for bc in ('finite', 'infinite'):
-            L = 8 if bc == 'finite' else 2
-            M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': bc, 'conserve': 'parity', 'sort_charge': True})
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc=bc)
-            opts = {'order': 2, 'delta_tau_list': [0.1, 0.01, 0.001], 'N_steps': 10, 'max_error_E': 1.e-9, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}}
-            eng = tebd.TEBDEngine(psi, M, dict(opts))
-            eng.run_GS()
-            out.append(dict(bc=bc, L=L, options=opts, E_bonds=np.array(M.bond_energies(psi)), S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi],
-                            beta=float(-np.imag(eng.evolved_time)), h_bond=[None if h is None else h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond],
-                            state_labels=list(M.lat.mps_sites()[0].state_labels.items())))
-            print('tebd_gs', bc, np.mean(out[-1]['E_bonds']), out[-1]['beta'], out[-1]['chi'])
-    save('tebd_gs.pkl', out)
-
-
-def gen_nocharge():
-    """The newer engines WITHOUT charge conservation (TFI chain, conserve=None: one block per tensor) and with Z2 parity:
-    single-site DMRG with subspace expansion, TDVP (two-site then single-site), iDMRG with the default run loop."""
-    from tenpy.algorithms import dmrg, tdvp
-    from tenpy.models.tf_ising import TFIChain
-    from tenpy.networks.mps import MPS
-    import copy
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        for conserve in (None, 'parity'):
-            L = 8
-            M = TFIChain({'L': L, 'J': 1., 'g': 1.3, 'bc_MPS': 'finite', 'conserve': conserve, 'sort_charge': True})
-            labels = list(M.lat.mps_sites()[0].state_labels.items())
-            # single-site DMRG
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
-            eng = dmrg.SingleSiteDMRGEngine(psi, M, {'combine': True, 'max_N_for_ED': 0, 'mixer': True,
-                                                     'mixer_params': {'amplitude': 1.e-3, 'decay': 2., 'disable_after': 3},
-                                                     'trunc_params': {'chi_max': 10, 'svd_min': 1.e-6}})
-            eng.mixer_activate()
-            Es = []
-            for s_ in range(5):
-                eng.sweep()
-                Es.append(float(eng.update_stats['E_total'][-1]))
-            eng.mixer_cleanup()
-            rec = dict(conserve=conserve, L=L, J=1., g=1.3, state_labels=labels, single_E_sweeps=Es,
-                       single_E_updates=[float(e) for e in eng.update_stats['E_total']], single_S=np.array(psi.entanglement_entropy()))
-            # TDVP from the all-up product state
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
-            topts = {'dt': 0.05, 'N_steps': 2, 'trunc_params': {'chi_max': 10, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 2, 'N_max': 20}}
-            e2 = tdvp.TwoSiteTDVPEngine(psi, M, copy.deepcopy(topts))
-            steps = []
-            for rep in range(3):
-                e2.run()
-                steps.append(dict(engine='two', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], sz=np.array(psi.expectation_value('Sigmaz'))))
-            e1 = tdvp.SingleSiteTDVPEngine(psi, M, copy.deepcopy(topts))
-            for rep in range(2):
-                e1.run()
-                steps.append(dict(engine='single', S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], sz=np.array(psi.expectation_value('Sigmaz'))))
-            rec.update(tdvp_options=topts, tdvp_steps=steps)
-            # iDMRG
-            Mi = TFIChain({'L': 2, 'J': 1., 'g': 1.3, 'bc_MPS': 'infinite', 'conserve': conserve, 'sort_charge': True})
-            psi = MPS.from_product_state(Mi.lat.mps_sites(), ['up'] * 2, bc='infinite')
-            iopts = {'mixer': None, 'max_E_err': 1.e-10, 'max_sweeps': 30, 'N_sweeps_check': 5, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}}
-            ei = dmrg.TwoSiteDMRGEngine(psi, Mi, dict(copy.deepcopy(iopts), combine=True, max_N_for_ED=0))
-            E, _ = ei.run()
-            rec.update(idmrg_options=iopts, idmrg_E=float(E), idmrg_sweeps=int(ei.sweeps), idmrg_E_updates=[float(e) for e in ei.update_stats['E_total']],
-                       idmrg_S=[np.array(psi.get_SL(i)) for i in range(2)])
-            out.append(rec)
-            print('nocharge', conserve, Es[-1], steps[-1]['chi'], E, ei.sweeps)
-    save('nocharge.pkl', out)
-
-
-def gen_correlations():
-    """Correlation functions of a DMRG ground state (XXZ chain): Sz-Sz, S+ S-, and the state itself (B tensors) so that the
-    device code is checked on identical input."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 8
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.6, 'hz': 0.05, 'bc_MPS': 'finite', 'sort_charge': True})
-        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-        dmrg.run(psi, M, {'mixer': None, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-10}, 'max_sweeps': 6})
-        site = M.lat.mps_sites()[0]
-        out.append(dict(L=L, B=[dump_array(psi.get_B(i, 'B').transpose(['vL', 'p', 'vR'])) for i in range(L)],
-                        S=[np.array(psi.get_SL(i)) for i in range(L)] + [np.array(psi.get_SR(L - 1))],
-                        SzSz=np.array(psi.correlation_function('Sz', 'Sz')), SpSm=np.array(psi.correlation_function('Sp', 'Sm')),
-                        SzSz_sub=np.array(psi.correlation_function('Sz', 'Sz', sites1=[1, 4], sites2=[0, 4, 7])),
-                        Sz=site.Sz.to_ndarray(), Sp=site.Sp.to_ndarray(), Sm=site.Sm.to_ndarray(), exp_Sz=np.array(psi.expectation_value('Sz'))))
-        print('correlations', out[-1]['SzSz'][0, :3])
-    save('correlations.pkl', out)
-
-
-def gen_mpo_evolution():
-    """ExpMPOEvolution (W_II, orders 1 and 2, SVD compression) after a quench from the Neel state, plus the W_II tensors."""
-    from tenpy.algorithms import mpo_evolution
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 6
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 0.8, 'hz': 0.1, 'bc_MPS': 'finite', 'sort_charge': True})
-        for order in (1, 2):
-            psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
-            opts = {'dt': 0.05, 'N_steps': 2, 'order': order, 'approximation': 'II', 'compression_method': 'SVD',
-                    'trunc_params': {'chi_max': 10, 'svd_min': 1.e-10}}
-            eng = mpo_evolution.ExpMPOEvolution(psi, M, dict(opts))
-            steps = []
-            for rep in range(4):
-                eng.run()
-                steps.append(dict(S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], Sz=np.array(psi.expectation_value('Sz')),
-                                  norm=float(psi.norm)))
-            U = M.H_MPO.make_U_II(-0.05j)
-            out.append(dict(L=L, Jxx=1., Jz=0.8, hz=0.1, order=order, options=opts, steps=steps, trunc_err=float(eng.trunc_err.eps),
-                            W_II=[U.get_W(i).transpose(['wL', 'wR', 'p', 'p*']).to_ndarray() for i in range(L)]))
-            print('mpo_evolution', order, steps[-1]['chi'], steps[-1]['S'][L // 2 - 1], steps[-1]['norm'])
-    save('mpo_evolution.pkl', out)
-
-
-def gen_idmrg_single():
-    """Single-site infinite DMRG with the subspace expansion (reference defaults for the run loop)."""
-    from tenpy.algorithms import dmrg
-    from tenpy.models.xxz_chain import XXZChain
-    from tenpy.networks.mps import MPS
-    import copy
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        L = 2
-        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1.5, 'hz': 0., 'bc_MPS': 'infinite', 'sort_charge': True})
-        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'], bc='infinite')
-        opts = {'mixer': True, 'mixer_params': {'amplitude': 1.e-3, 'decay': 1.5, 'disable_after': 8}, 'combine': True, 'max_N_for_ED': 0,
-                'max_E_err': 1.e-9, 'max_sweeps': 40, 'N_sweeps_check': 5, 'trunc_params': {'chi_max': 12, 'svd_min': 1.e-6}}
-        opts_plain = copy.deepcopy(opts)
-        eng = dmrg.SingleSiteDMRGEngine(psi, M, opts)
-        E, _ = eng.run()
-        st = eng.sweep_stats
-        out.append(dict(E=float(E), sweeps=int(eng.sweeps), options=opts_plain, E_updates=[float(e) for e in eng.update_stats['E_total']],
-                        age=[int(a) for a in eng.update_stats['age']], i0=[int(i) for i in eng.update_stats['i0']],
-                        sweep_stats={k: [float(x) for x in st[k]] for k in ('sweep', 'E', 'Delta_E', 'S', 'max_chi')},
-                        S=[np.array(psi.get_SL(i)) for i in range(L)], chi=[int(c) for c in psi.chi], L=L, Jxx=1., Jz=1.5, hz=0.))
-        print('idmrg_single', E, eng.sweeps, psi.chi)
-    save('idmrg_single.pkl', out)
-
-
-def gen_hubbard2():
-    """Fermi-Hubbard 2 x 3 ladder (two U(1) charges, fermionic MPO with D = 10): single-site DMRG with subspace expansion and
-    two-site TDVP after a quench."""
-    from tenpy.algorithms import dmrg, tdvp
-    from tenpy.models.hubbard import FermiHubbardModel
-    from tenpy.networks.mps import MPS
-    out = []
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        Lx = 3
-        M = FermiHubbardModel({'lattice': 'Ladder', 'L': Lx, 't': 1., 'U': 8., 'mu': 0., 'cons_N': 'N', 'cons_Sz': 'Sz',
-                               'bc_MPS': 'finite', 'sort_charge': True})
-        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * Lx, bc='finite')
-        eng = dmrg.SingleSiteDMRGEngine(psi, M, {'combine': True, 'max_N_for_ED': 0, 'mixer': True,
-                                                 'mixer_params': {'amplitude': 1.e-2, 'decay': 2., 'disable_after': 4},
-                                                 'trunc_params': {'chi_max': 24, 'svd_min': 1.e-6}})
-        eng.mixer_activate()
-        Es = []
-        for s_ in range(7):
-            eng.sweep()
-            Es.append(float(eng.update_stats['E_total'][-1]))
-        eng.mixer_cleanup()
-        rec = dict(Lx=Lx, t=1., U=8., mu=0., single_E_sweeps=Es, single_S=np.array(psi.entanglement_entropy()), single_chi=[int(c) for c in psi.chi])
-        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * Lx, bc='finite')
-        topts = {'dt': 0.02, 'N_steps': 2, 'trunc_params': {'chi_max': 20, 'svd_min': 1.e-10}, 'lanczos_params': {'N_min': 2, 'N_max': 20}}
-        e2 = tdvp.TwoSiteTDVPEngine(psi, M, dict(topts))
-        steps = []
-        for rep in range(3):
-            e2.run()
-            steps.append(dict(S=np.array(psi.entanglement_entropy()), chi=[int(c) for c in psi.chi], n=np.array(psi.expectation_value('Ntot'))))
-        rec.update(tdvp_options=topts, tdvp_steps=steps)
-        out.append(rec)
-        print('hubbard2', Es[-1], rec['single_chi'], steps[-1]['chi'])
-    save('hubbard2.pkl', out)
-
-
-GENERATORS = dict(hubbard2=gen_hubbard2, idmrg_single=gen_idmrg_single, mpo_evolution=gen_mpo_evolution, correlations=gen_correlations, nocharge=gen_nocharge, tebd_gs=gen_tebd_gs, canonical_form_infinite=gen_canonical_form_infinite, canonical_form=gen_canonical_form, tebd_infinite=gen_tebd_infinite, idmrg_bench=gen_idmrg_bench, idmrg=gen_idmrg, tdvp=gen_tdvp, dmrg_run=gen_dmrg_run, dmrg_default_diag=gen_dmrg_default_diag, dmrg_ortho=gen_dmrg_ortho, tebd2=gen_tebd2, api2=gen_api2, krylov2=gen_krylov2, dmrg_two_site_subspace=gen_dmrg_two_site_subspace, dmrg_single=gen_dmrg_single, dmrg_mixer=gen_dmrg_mixer, hubbard=gen_hubbard, mixer=gen_mixer, charges=gen_charges, tensordot=gen_tensordot, reshape=gen_reshape, linalg=gen_linalg,
-                  truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd, qr_theta=gen_qr_theta)
+GENERATORS = dict(api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
+                  reshape=gen_reshape, linalg=gen_linalg, truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd,
+                  qr_theta=gen_qr_theta)
 
 if __name__ == '__main__':
     print("reference:", tenpy.__version__, tenpy.__file__)

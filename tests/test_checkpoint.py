@@ -54,51 +54,3 @@ def test_resume_continues_the_run(backend, tmp_path):
     np.testing.assert_allclose(res.update_stats['E_total'], ref.update_stats['E_total'], rtol=1e-11, atol=1e-11)
     for i in range(1, res.psi.L):
         np.testing.assert_allclose(res.psi.get_SL(i), ref.psi.get_SL(i), rtol=0, atol=1e-10)
-
-
-def test_resume_single_site_and_infinite(backend, tmp_path):
-    """Checkpoint / resume of the single-site engine (2-D bond matrices are diagonalised by the checkpoint) and of an
-    infinite run: the resumed runs end at the energy of the uninterrupted ones."""
-    from tenpy_amd.algorithms.dmrg import SingleSiteDMRGEngine
-    o1 = dict(OPTS, mixer=True, mixer_params={'amplitude': 1.e-3, 'decay': 2., 'disable_after': 2},
-              trunc_params={'chi_max': 12, 'svd_min': 1.e-6})
-    psi, H = _fresh(8)
-    ref = SingleSiteDMRGEngine(psi, H, o1)
-    ref.mixer_activate()
-    for _ in range(6):
-        ref.sweep()
-    psi2, H2 = _fresh(8)
-    eng = SingleSiteDMRGEngine(psi2, H2, o1)
-    eng.mixer_activate()
-    for _ in range(3):
-        eng.sweep()
-    fn = os.path.join(str(tmp_path), 'ckpt1.pkl')
-    eng.save_checkpoint(fn)
-    res = SingleSiteDMRGEngine.from_checkpoint(fn, H2, o1)
-    assert res.sweeps == 3
-    for _ in range(3):
-        res.sweep()
-    assert abs(res.sweep_stats['E'][-1] - ref.sweep_stats['E'][-1]) < 1e-8
-    # infinite two-site run
-    Hi = xxz_chain_mpo(2, 1., 1.5, 0., bc='infinite')
-    _, p = spin_half_leg('Sz')
-    oi = {'trunc_params': {'chi_max': 10, 'svd_min': 1.e-8}, 'lanczos_params': {}}
-    pa = MPS.from_product_state([p] * 2, [1, 0], bc='infinite')
-    ea = TwoSiteDMRGEngine(pa, Hi, oi)
-    for _ in range(12):
-        ea.sweep()
-    pb = MPS.from_product_state([p] * 2, [1, 0], bc='infinite')
-    eb = TwoSiteDMRGEngine(pb, Hi, oi)
-    for _ in range(6):
-        eb.sweep()
-    fn = os.path.join(str(tmp_path), 'ckpt2.pkl')
-    eb.save_checkpoint(fn)
-    ec = TwoSiteDMRGEngine.from_checkpoint(fn, Hi, oi)
-    assert not ec.psi.finite and ec.sweeps == 6
-    for _ in range(8):
-        ec.sweep()
-
-    def e_site(e):
-        Es, ages = e.update_stats['E_total'], e.update_stats['age']
-        return (Es[-1] - Es[-5]) / (ages[-1] - ages[-5])
-    assert abs(e_site(ec) - e_site(ea)) < 1e-6

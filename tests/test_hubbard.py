@@ -72,34 +72,3 @@ def test_hubbard_ladder_vs_reference(backend, name):
         assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= tol * abs(rec['E_sweeps'][s]), (s, eng.sweep_stats['E'][-1], rec['E_sweeps'][s])
     assert eng.sweep_stats['max_chi'][-1] == rec['chi_sweeps'][-1]
     np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_ent'], rtol=0, atol=1e-6)
-
-
-def test_hubbard_single_site_dmrg_and_tdvp(backend):
-    """Two U(1) charges + fermionic MPO (D = 10) through the single-site engine with subspace expansion and through
-    two-site TDVP, vs the reference's FermiHubbardModel runs (tests/golden/make_golden.py:gen_hubbard2).  (The two MPOs
-    differ by a gauge of the virtual index: the mixer trajectories are not identical, converged values are.)"""
-    from tenpy_amd.algorithms.dmrg import SingleSiteDMRGEngine
-    from tenpy_amd.algorithms.tdvp import TwoSiteTDVPEngine
-    rec = golden('hubbard2.pkl')[0]
-    Lx = rec['Lx']
-    H = hubbard_ladder_mpo(Lx, rec['t'], rec['U'], rec['mu'])
-    _, p = spinful_fermion_leg()
-    psi = MPS.from_product_state([p] * (2 * Lx), [1, 2] * Lx)
-    eng = SingleSiteDMRGEngine(psi, H, {'mixer': True, 'mixer_params': {'amplitude': 1.e-2, 'decay': 2., 'disable_after': 4},
-                                        'trunc_params': {'chi_max': 24, 'svd_min': 1.e-6}})
-    eng.mixer_activate()
-    for s in range(len(rec['single_E_sweeps'])):
-        eng.sweep()
-    eng.mixer_cleanup()
-    assert abs(eng.sweep_stats['E'][-1] - rec['single_E_sweeps'][-1]) < 1e-7
-    assert list(psi.chi) == rec['single_chi']
-    np.testing.assert_allclose(psi.entanglement_entropy(), rec['single_S'], rtol=0, atol=1e-5)
-    # TDVP: no mixer, the evolution is gauge independent
-    psi = MPS.from_product_state([p] * (2 * Lx), [1, 2] * Lx)
-    e2 = TwoSiteTDVPEngine(psi, H, dict(rec['tdvp_options']))
-    n_op = np.diag(hubbard_ops()['Ntot'])
-    for step in rec['tdvp_steps']:
-        e2.run()
-        assert list(psi.chi) == step['chi']
-        np.testing.assert_allclose(psi.entanglement_entropy(), step['S'], rtol=0, atol=1e-9)
-        np.testing.assert_allclose(psi.expectation_value(np.diag(n_op)), step['n'], rtol=0, atol=1e-9)

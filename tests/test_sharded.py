@@ -59,11 +59,15 @@ def _worker(rank, world, port, ret):
         # block SVD distributed over the ranks (LPT by block cost + one all-gather) == the local SVD, bit for bit
         from tenpy_amd.linalg import np_conserved as npc
         th2 = ref_H.prepare_svd(ref_H.combine_theta(psi.get_theta(i0, n=2)))
-        assert npc.SVD_DIST_GROUP is not None and npc.SVD_DIST_GROUP[2] == world
-        Ud, Sd, Vd = npc.svd(th2, inner_labels=['vR', 'vL'])
-        grp, npc.SVD_DIST_GROUP = npc.SVD_DIST_GROUP, None
+        # (the engine distributes the SVD only inside its own bond updates: the module switch is back to None afterwards, so
+        # a later SVD on one rank alone -- diagnostics, post-processing -- cannot dead-lock)
+        assert npc.SVD_DIST_GROUP is None and eng._svd_group is not None and eng._svd_group[2] == world
+        npc.SVD_DIST_GROUP = eng._svd_group
+        try:
+            Ud, Sd, Vd = npc.svd(th2, inner_labels=['vR', 'vL'])
+        finally:
+            npc.SVD_DIST_GROUP = None
         Ul, Sl, Vl = npc.svd(th2, inner_labels=['vR', 'vL'])
-        npc.SVD_DIST_GROUP = grp
         np.testing.assert_array_equal(Sd, Sl)
         np.testing.assert_array_equal(Ud.to_ndarray(), Ul.to_ndarray())
         np.testing.assert_array_equal(Vd.to_ndarray(), Vl.to_ndarray())
