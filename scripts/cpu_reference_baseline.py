@@ -67,7 +67,7 @@ def dmrg_protocol(L, chi, n_sweeps_at_chi, label):
         t0 = time.time()
         eng.sweep()
         log.append({"chi_max": int(eng.trunc_params['chi_max']), "lanczos": tag, "s": time.time() - t0,
-                    "E": float(eng.sweep_stats['E'][-1]), "max_chi": int(max(psi.chi))})
+                    "E": float(eng.update_stats['E_total'][-1]), "max_chi": int(max(psi.chi))})
         print(label, log[-1], flush=True)
     c = min(64, chi)
     sweep('N<=20')
@@ -115,7 +115,7 @@ def sweep512(L=100, chi=512, n_timed=3):
     return {"workload": "TwoSiteDMRGEngine.sweep(), XXZChain L=%d (Sz), chi_max=%d (reached %d), combine=True, no mixer, "
                         "Lanczos N=8, svd_min=1e-14" % (L, chi, max(psi.chi)),
             "s_per_sweep_best": min(times), "s_per_sweep_all": times, "prep_s": prep,
-            "E": float(eng.sweep_stats['E'][-1]), "bond_updates_per_sweep": 2 * (L - 2)}
+            "E": float(eng.update_stats['E_total'][-1]), "bond_updates_per_sweep": 2 * (L - 2)}
 
 
 def synthetic_bond(chi_sectors, seed):

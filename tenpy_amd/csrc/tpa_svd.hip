@@ -2166,7 +2166,7 @@ int tpa_svd_use_qrp = 1;   // real data: rank-revealing pivoted QR before the Ja
 
 int tpa_svd_fused_round = 1;   // real data: one launch per Jacobi round (sibling workgroups synchronise through a counter)
 int tpa_svd_local_sweeps = 1;
-int tpa_svd_predict_convergence = 0;   // 1: a sweep without "big" rotations ends the iteration (no verification sweep); GPU-unvalidated
+int tpa_svd_predict_convergence = 1;   // a sweep without "big" rotations (scaled cosine > 1e-7) ends the iteration: no verification sweep (validated on the MI355X in round 2)
 int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block pairs
                         // 32 x 32 solve dominates); kept as a tuning option, off by default
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
@@ -2925,7 +2925,7 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_cross_only = (pairwise & 4) ? 0 : 1;
     tpa_svd_use_qrp = (pairwise & 512) ? 0 : 1;    // bit 9: no pivoted-QR preconditioner
     tpa_svd_fused_round = (pairwise & 2) ? 0 : 1;  // bit 1: two-kernel rounds (gram, then solve + apply)
-    tpa_svd_predict_convergence = (pairwise & 1024) ? 1 : 0;   // bit 10: skip the verification sweep (see svd_big_rotation)
+    tpa_svd_predict_convergence = (pairwise & 1024) ? 0 : 1;   // bit 10: always run the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
 }

@@ -2179,12 +2179,14 @@ def trace(a, leg1=0, leg2=1):
 # decompositions
 # ======================================================================================================
 
-# Absolute floor rho of the Jacobi stopping rule (include/tenpy_amd.h, tpa_svd_batch `tol`): row pairs whose
-# larger norm is below rho*||block||_F are judged against rho*||block||_F instead of their own norm, i.e. the
-# numerical null space of a rank-deficient block (DMRG wave functions: rank <= chi of d*chi) is not rotated
-# against itself.  Singular values keep absolute accuracy eps*||A||; singular vectors of sigma < rho*||A||
-# are orthogonal to ~eps*rho*||A||/sigma instead of eps.  0 = purely relative criterion.
-SVD_ABS_FLOOR = 1.e-6
+# Absolute floor rho of the Jacobi stopping rule (include/tenpy_amd.h, tpa_svd_batch `tol`): row pairs whose larger norm is
+# below rho*||block||_F are judged against rho*||block||_F instead of their own norm.  rho = 0 (default since round 2) is the
+# purely relative criterion: every returned singular vector (sigma >= 1e-15 ||A||, the rank cut of the pivoted QR) is orthogonal
+# to the others to machine precision, like LAPACK's -- measured on a saturated chi = 2048 theta: |V V^T - 1| = 7e-15 over all
+# sigma > 1e-14 sigma_max, 8 sweeps / 20.1 ms per call.  rho = 1e-6 (round 1) saves two sweeps (17.9 ms) but leaves vectors of
+# sigma < rho ||A|| orthogonal only to eps*rho*||A||/sigma (5e-7 at sigma = 1e-14): a chi = 2048 Heisenberg state KEEPS such
+# values (its 2048th Schmidt value is 9e-15), so the faster setting is a tuning knob, not the default.
+SVD_ABS_FLOOR = 0.
 svd_stats = {'calls': 0, 'sweeps': 0, 'max_block': 0}
 
 
