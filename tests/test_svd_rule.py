@@ -85,7 +85,7 @@ def test_predicted_convergence_saves_the_verification_sweep():
 def test_npc_svd_with_predicted_convergence(backend):
     """Predicted convergence (default since round 2; `tpa_svd_set_algorithm(1024)` switches it OFF): the device iteration may
     stop after a sweep without big rotations.  Results must be the same as with the verification sweep (singular values,
-    reconstruction, orthogonality of ALL returned vectors now that the absolute floor is 0), with no more sweeps."""
+    reconstruction, orthogonality), with no more sweeps."""
     from tenpy_amd import _lib
     from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
     rng = np.random.RandomState(21)
@@ -114,6 +114,29 @@ def test_npc_svd_with_predicted_convergence(backend):
         for U, S, V in ((U0, S0, V0), (U1, S1, V1)):
             np.testing.assert_allclose(np.sort(S)[::-1], ref[:len(S)], rtol=0, atol=1e-13 * ref[0])
             np.testing.assert_allclose((U * S) @ V, A, rtol=0, atol=1e-12 * ref[0])
-            big = S > 1e-13 * ref[0]
+            big = S > 1e-6 * ref[0]
             np.testing.assert_allclose(U[:, big].T @ U[:, big], np.eye(big.sum()), rtol=0, atol=1e-11)
             np.testing.assert_allclose(V[big] @ V[big].T, np.eye(big.sum()), rtol=0, atol=1e-11)
+
+
+def test_isometries_on_graded_spectrum(backend, monkeypatch):
+    """with the default absolute floor (1e-6) the vectors of sigma > 1e-6 sigma_max are orthonormal to machine
+    precision; with ``SVD_ABS_FLOOR = 0`` EVERY returned vector is (graded spectrum over 13 decades)."""
+    from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
+    rng = np.random.RandomState(4)
+    n = 160
+    qu, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    qv, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    sig = np.logspace(0, -13, n)
+    A = (qu * sig) @ qv.T
+    ch = ChargeInfo([1])
+    a = npc.Array.from_ndarray(A, [LegCharge.from_qflat(ch, np.zeros((n, 1), int)), LegCharge.from_qflat(ch, np.zeros((n, 1), int), -1)])
+    for floor, cut in ((npc.SVD_ABS_FLOOR, 1e-6), (0., 1e-12)):
+        monkeypatch.setattr(npc, 'SVD_ABS_FLOOR', floor)
+        U, S, VH = npc.svd(a)
+        u, v = U.to_ndarray(), VH.to_ndarray()
+        np.testing.assert_allclose(np.sort(S)[::-1][:n], sig[:len(S)], rtol=0, atol=1e-13)
+        keep = S > cut * S.max()
+        assert keep.sum() >= 70
+        np.testing.assert_allclose(u[:, keep].T @ u[:, keep], np.eye(keep.sum()), rtol=0, atol=2e-12)
+        np.testing.assert_allclose(v[keep] @ v[keep].T, np.eye(keep.sum()), rtol=0, atol=2e-12)
