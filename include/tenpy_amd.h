@@ -78,6 +78,13 @@ int tpa_nrm2sq(int dtype, int64_t n, const void *x_dev, double *out_dev, double 
 int tpa_lanczos_update(int dtype, int64_t n, void *w_dev, double alpha_re, double alpha_im,
                        const void *v1_dev, double beta_re, double beta_im, const void *v0_dev,
                        double *out_dev, double *scratch_dev, void *stream);
+/* The same step with the scalars kept on the device, so that the host never waits between a matvec and the next one
+ * (LanczosGroundState._build_krylov, krylov_based.py:655-672; the host reads alpha / beta one step late for the tridiagonal
+ * eigen-problem and the convergence test):
+ *   alpha = Re <w|v1> ;  w -= alpha v1 ;  w -= sqrt(bsq_prev[0]) v0 (v0, bsq_prev may be NULL) ;  bsq = |w|^2 ;  w /= sqrt(bsq)
+ *   ab_out[0] = alpha, ab_out[1] = bsq.  scratch_dev: TPA_RED_SCRATCH doubles. */
+int tpa_lanczos_step(int dtype, int64_t n, void *w_dev, const void *v1_dev, const void *v0_dev,
+                     const double *bsq_prev_dev, double *ab_out_dev, double *scratch_dev, void *stream);
 
 /* ---- K8/K9/K10: data movement ---------------------------------------------------------
  * Generic strided N-d block copy (N <= TPA_COPY_MAXDIM), batched.  Replaces

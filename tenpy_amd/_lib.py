@@ -32,6 +32,7 @@ _SIGS = {
     "tpa_nrm2sq": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "tpa_lanczos_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_double, ctypes.c_double, _vp,
                                           ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    "tpa_lanczos_step": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpa_copy_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]),
     "tpa_lincomb_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "tpa_scale_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp]),

@@ -134,6 +134,64 @@ __global__ __launch_bounds__(NT) void lanczos_update_kernel(int64_t n, double *_
     }
 }
 
+// ---- one Lanczos step with device-resident scalars (no host round trip between the kernels) ----------------------------
+// alpha comes from ab[0] (written by the dot reduction just before), beta_prev = sqrt(bsq_prev[0]) from the previous step.
+template <bool CPLX, bool HAVE_V0>
+__global__ __launch_bounds__(NT) void lanczos_update_dev_kernel(int64_t n, double *__restrict__ w,
+                                                                const double *__restrict__ ab,
+                                                                const double *__restrict__ v1,
+                                                                const double *__restrict__ bsq_prev,
+                                                                const double *__restrict__ v0,
+                                                                double *__restrict__ partial) {
+    __shared__ double red[NT / 64];
+    const double ar = ab[0];
+    const double br = HAVE_V0 ? sqrt(bsq_prev[0]) : 0.0;
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        if (!CPLX) {
+            double t = w[i];
+            t = fma(-ar, v1[i], t);
+            if (HAVE_V0) t = fma(-br, v0[i], t);
+            w[i] = t;
+            s = fma(t, t, s);
+        } else {
+            double2 t = reinterpret_cast<double2 *>(w)[i];
+            const double2 p = reinterpret_cast<const double2 *>(v1)[i];
+            t.x -= ar * p.x;
+            t.y -= ar * p.y;
+            if (HAVE_V0) {
+                const double2 q = reinterpret_cast<const double2 *>(v0)[i];
+                t.x -= br * q.x;
+                t.y -= br * q.y;
+            }
+            reinterpret_cast<double2 *>(w)[i] = t;
+            s += t.x * t.x + t.y * t.y;
+        }
+    }
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = 0;
+    }
+}
+
+// second pass of the norm: out[1] = sum of the partials (out[0] keeps alpha)
+__global__ __launch_bounds__(NT) void reduce_pass2_to(int nblk, const double *__restrict__ partial, double *__restrict__ out) {
+    __shared__ double red[NT / 64];
+    double sr = 0;
+    for (int i = threadIdx.x; i < nblk; i += NT) sr += partial[2 * i];
+    sr = block_sum<NT>(sr, red);
+    if (threadIdx.x == 0) out[0] = sr;
+}
+
+// x *= 1 / sqrt(bsq[0])  (x as flat doubles; nothing happens for bsq <= 0)
+__global__ __launch_bounds__(NT) void scal_rsqrt_dev_kernel(int64_t nd, double *__restrict__ x, const double *__restrict__ bsq) {
+    const double b = bsq[0];
+    if (!(b > 0.0)) return;
+    const double f = 1.0 / sqrt(b);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nd; i += (int64_t)gridDim.x * NT) x[i] *= f;
+}
+
 }  // namespace
 
 extern "C" int tpa_axpy(int dtype, int64_t n, double ar, double ai, const void *x, void *y,
@@ -220,5 +278,39 @@ extern "C" int tpa_lanczos_update(int dtype, int64_t n, void *w, double ar, doub
 extern "C" int tpa_fill_zero(void *dst, int64_t n_bytes, void *stream) {
     if (n_bytes <= 0) return 0;
     TPA_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)n_bytes, (hipStream_t)stream));
+    return 0;
+}
+
+// One Lanczos step of krylov_based.py:655-672 with the scalars kept on the device, so that the host can enqueue the next
+// matvec without waiting:   alpha = Re <w|v1> ;  w -= alpha v1 ;  w -= beta_prev v0 ;  bsq = |w|^2 ;  w /= sqrt(bsq).
+// ab_out[0] = alpha, ab_out[1] = bsq (= beta^2 of this step; the NEXT step passes &ab_out[1] as bsq_prev).
+extern "C" int tpa_lanczos_step(int dtype, int64_t n, void *w, const void *v1, const void *v0,
+                                const double *bsq_prev, double *ab_out, double *scratch, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    TPA_ARG_CHECK(v1 != nullptr && ab_out != nullptr && (v0 == nullptr || bsq_prev != nullptr));
+    hipStream_t st = (hipStream_t)stream;
+    const bool cplx = (dtype == TPA_C128);
+    const int g = (n > 0) ? grid_for(n, 8) : 1;
+    if (!cplx)
+        reduce_pass1<0><<<g, NT, 0, st>>>(n, (const double *)w, (const double *)v1, scratch);
+    else
+        reduce_pass1<1><<<g, NT, 0, st>>>(n, (const double *)w, (const double *)v1, scratch);
+    reduce_pass2<<<1, NT, 0, st>>>(g, scratch, ab_out);          // ab_out[0] = Re <w|v1>, ab_out[1] = Im (overwritten below)
+    double *part2 = scratch + 2 * MAXBLK;
+    if (!cplx) {
+        if (v0)
+            lanczos_update_dev_kernel<false, true><<<g, NT, 0, st>>>(n, (double *)w, ab_out, (const double *)v1, bsq_prev, (const double *)v0, part2);
+        else
+            lanczos_update_dev_kernel<false, false><<<g, NT, 0, st>>>(n, (double *)w, ab_out, (const double *)v1, nullptr, nullptr, part2);
+    } else {
+        if (v0)
+            lanczos_update_dev_kernel<true, true><<<g, NT, 0, st>>>(n, (double *)w, ab_out, (const double *)v1, bsq_prev, (const double *)v0, part2);
+        else
+            lanczos_update_dev_kernel<true, false><<<g, NT, 0, st>>>(n, (double *)w, ab_out, (const double *)v1, nullptr, nullptr, part2);
+    }
+    reduce_pass2_to<<<1, NT, 0, st>>>(g, part2, ab_out + 1);
+    const int64_t nd = cplx ? 2 * n : n;
+    scal_rsqrt_dev_kernel<<<grid_for(nd, 8), NT, 0, st>>>(nd, (double *)w, ab_out + 1);
+    TPA_LAUNCH_CHECK();
     return 0;
 }

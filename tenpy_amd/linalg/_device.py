@@ -96,6 +96,32 @@ def read_scalar(out, cplx):
     return complex(float(v[0]), float(v[1])) if cplx else float(v[0])
 
 
+class ScalarPipe:
+    """A few device-resident doubles per step of an iteration plus their delayed read-back: the device buffer the kernels
+    write into (``dev[step]``, 2 doubles) and a pinned host mirror filled by asynchronous copies, each followed by an event
+    on the launch stream.  ``get(step)`` waits for THAT copy only, so the host can be one step behind the device."""
+
+    def __init__(self, n_steps):
+        t = torch()
+        self.dev = t.zeros((n_steps, 2), dtype=t.float64, device='cuda')
+        self.host = t.zeros((n_steps, 2), dtype=t.float64).pin_memory()
+        self.events = [None] * n_steps
+
+    def ptr(self, step, which=0):
+        return self.dev.data_ptr() + 8 * (2 * step + which)
+
+    def post(self, step):
+        t = torch()
+        self.host[step].copy_(self.dev[step], non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record()
+        self.events[step] = ev
+
+    def get(self, step):
+        self.events[step].synchronize()
+        return float(self.host[step, 0]), float(self.host[step, 1])
+
+
 def check(rc, what=""):
     _lib.check(rc, what)
 

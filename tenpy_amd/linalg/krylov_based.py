@@ -19,6 +19,9 @@ from . import np_conserved as npc
 
 logger = logging.getLogger(__name__)
 
+import os as _os
+PIPELINED = _os.environ.get('TPA_LANCZOS_PIPELINED', '1') != '0'     # device-resident alpha / beta in LanczosGroundState (off: one host read per scalar, as in round 1)
+
 __all__ = ['LanczosGroundState', 'LanczosEvolution', 'Arnoldi', 'lanczos', 'gram_schmidt', 'iscale_prefactor', 'iadd_prefactor_other']
 
 
@@ -74,13 +77,79 @@ class LanczosGroundState:
         return w.stored_blocks > 0 and w._is_packed() and all(w._same_structure(o) and w.dtype == o.dtype for o in others)
 
     def _build_krylov(self):
-        h = self._h_krylov
         w = self.psi0
         beta = npc.norm(w)
         if beta < self._cutoff:
             raise ValueError("Norm of self.psi0 too small: {0}".format(beta))
         if self._psi0_norm is None:
             self._psi0_norm = beta
+        if not self.reortho and PIPELINED and w.stored_blocks > 0 and w._is_packed():
+            return self._build_krylov_pipelined(w, beta)
+        return self._build_krylov_stepwise(w, beta)
+
+    def _build_krylov_pipelined(self, w, beta):
+        """The recurrence with alpha / beta kept on the device (``tpa_lanczos_step``): per step the host enqueues matvec,
+        dot, update, norm and normalisation without waiting, and reads the two scalars of the PREVIOUS step for the
+        tridiagonal eigen-problem and the stopping test of the reference (:673) while the device is already working on
+        the next matvec.  If that test says "stop at k", the step in flight is discarded -- the same Krylov space, the same
+        (E0, psi0, N) as the step-by-step loop."""
+        h = self._h_krylov
+        L = dev.lib()
+        pipe = dev.ScalarPipe(self.N_max + 1)
+        _, scr = dev.reduction_buffers()
+        code = dev.code(w.dtype)
+        w.iscale_prefactor(1. / beta)
+
+        done = [False] * (self.N_max + 1)
+
+        def record(j, alpha, b):          # host side of step j; True = stop after it
+            done[j] = True
+            h[j, j] = alpha
+            self._calc_result_krylov(j)
+            h[j, j + 1] = h[j + 1, j] = b
+            return abs(b) < self._cutoff or (j + 1 >= self.N_min and self._converged(j))
+
+        def finish(j):
+            alpha, bsq = pipe.get(j)
+            return record(j, alpha, float(np.sqrt(bsq)))
+        k = 0
+        for k in range(self.N_max):
+            self._to_cache(w)
+            v1 = self._cache[-1]
+            w = self._matvec(v1)
+            v0 = self._cache[-2] if k > 0 else None
+            if self._flat_ok(w, v1, *([v0] if v0 is not None else [])):
+                dev.check(L.tpa_lanczos_step(code, w._arena.numel(), w._arena.data_ptr(), v1._arena.data_ptr(),
+                                             v0._arena.data_ptr() if v0 is not None else None,
+                                             pipe.ptr(k - 1, 1) if v0 is not None else None, pipe.ptr(k), scr.data_ptr(),
+                                             dev.stream()), "lanczos_step")
+                pipe.post(k)
+                if k > 0 and not done[k - 1] and finish(k - 1):
+                    self._cache.pop()       # v_k was cached for a step that is not part of the result
+                    return k
+                continue
+            # the operator created / dropped blocks (e.g. the first steps from a product state): this step the slow way
+            if k > 0 and not done[k - 1] and finish(k - 1):
+                self._cache.pop()
+                return k
+            alpha = float(np.real(npc.inner(w, v1, axes='range', do_conj=True)))
+            w.iadd_prefactor_other(-alpha, v1)
+            if v0 is not None:
+                w.iadd_prefactor_other(-h[k - 1, k], v0)
+            b = npc.norm(w)
+            pipe.dev[k, 0], pipe.dev[k, 1] = alpha, b * b        # the next (device-side) step reads beta from here
+            stop = record(k, alpha, b)
+            if stop:
+                return k + 1
+            w.iscale_prefactor(1. / b)
+            if not w._is_packed():
+                w._repack()
+        if not done[k]:
+            finish(k)
+        return k + 1
+
+    def _build_krylov_stepwise(self, w, beta):
+        h = self._h_krylov
         k = 0
         for k in range(self.N_max):
             w.iscale_prefactor(1. / beta)

@@ -162,6 +162,20 @@ class MockLib:
         return 0
 
     # ---- data movement ----------------------------------------------------------------------------
+    def tpa_lanczos_step(self, code, n, w_p, v1_p, v0_p, bsq_prev_p, ab_p, scr_p, stream):
+        dt = _npdt(code)
+        w, v1 = REG.view(w_p, dt)[:n], REG.view(v1_p, dt)[:n]
+        ab = REG.view(ab_p, np.float64)
+        alpha = float(np.real(np.vdot(w, v1)))
+        w -= alpha * v1
+        if v0_p:
+            w -= np.sqrt(REG.view(bsq_prev_p, np.float64)[0]) * REG.view(v0_p, dt)[:n]
+        bsq = float(np.real(np.vdot(w, w)))
+        ab[0], ab[1] = alpha, bsq
+        if bsq > 0.:
+            w *= 1. / np.sqrt(bsq)
+        return 0
+
     def tpa_copy_batch(self, code, jobs_p, n_jobs, max_elems, src_p, dst_p, stream):
         dt = _npdt(code)
         W = 4 + 3 * MAXD
@@ -353,6 +367,22 @@ def install(monkeypatch):
             def current_device():
                 return 0
 
+    class ScalarPipe:
+        """Emulation of dev.ScalarPipe: the 'device' buffer is a registered CPU tensor, reads are immediate."""
+
+        def __init__(self, n_steps):
+            self.dev = REG.add(torch.zeros((n_steps, 2), dtype=torch.float64))
+
+        def ptr(self, step, which=0):
+            return self.dev.data_ptr() + 8 * (2 * step + which)
+
+        def post(self, step):
+            pass
+
+        def get(self, step):
+            return float(self.dev[step, 0]), float(self.dev[step, 1])
+
+    monkeypatch.setattr(dev, "ScalarPipe", ScalarPipe)
     monkeypatch.setattr(dev, "empty", empty)
     monkeypatch.setattr(dev, "zeros", zeros)
     monkeypatch.setattr(dev, "to_device", to_device)
