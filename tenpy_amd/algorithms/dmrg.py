@@ -7,7 +7,7 @@ in the reference's order (``prepare_update_local`` -> ``update_local
 ``update_env``) for finite chains without a mixer, which is exactly BASELINE.json's timed workload.
 
 Options (names as in the reference): ``trunc_params``, ``lanczos_params``, ``chi_list`` (dict sweep -> chi_max);
-``shard_matvec`` (multi-GPU, ``algorithms/sharded.py``), ``profile`` (per-phase timers; synchronises the device).
+``shard_matvec`` (multi-GPU, ``algorithms/sharded.py``; with ``krylov_row_panels`` the Krylov vectors are row panels), ``profile`` (per-phase timers; synchronises the device).
 """
 import pickle
 import time
@@ -107,7 +107,11 @@ class TwoSiteDMRGEngine:
             eff_H = TwoSiteH(env, i0, combine=True, move_right=move_right)
         theta = eff_H.combine_theta(psi.get_theta(i0, n=2))
         self._tick('heff')
-        E0, theta, N = LanczosGroundState(eff_H, theta, self.lanczos_params).run()
+        if self.shard_matvec and self.options.get('krylov_row_panels', False):
+            from .sharded import lanczos_row_panels          # north_star: Krylov vectors as row panels, scalars by all-reduce
+            E0, theta, N = lanczos_row_panels(eff_H, theta, self.lanczos_params)
+        else:
+            E0, theta, N = LanczosGroundState(eff_H, theta, self.lanczos_params).run()
         theta = eff_H.prepare_svd(theta)                      # fused matrix [(vL.p0), (p1.vR)]
         self._tick('lanczos')
         previous = npc.SVD_DIST_GROUP
