@@ -457,7 +457,87 @@ def gen_api2():
     save('api2.pkl', out)
 
 
-GENERATORS = dict(api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
+
+def probe_array(a, seed, n=96):
+    """Size-independent fingerprint of a result Array: exact integer bookkeeping (qdata, block shapes), its 2-norm, the sum of
+    its entries and the values at `n` seeded random positions of the STORED blocks (block index, flat offset in the block)."""
+    a = a.copy(deep=True)
+    a.isort_qdata()
+    r = np.random.RandomState(seed)
+    sizes = np.array([b.size for b in a._data], dtype=np.int64)
+    blk = r.randint(0, len(sizes), size=n) if len(sizes) else np.zeros(0, int)
+    pos = np.array([r.randint(0, sizes[b]) for b in blk], dtype=np.int64)
+    vals = np.array([a._data[b].reshape(-1)[o] for b, o in zip(blk, pos)])
+    return dict(qdata=np.array(a._qdata), shapes=[tuple(b.shape) for b in a._data], qtotal=np.array(a.qtotal),
+                labels=list(a._labels), norm=float(npc.norm(a)), sum=complex(sum(np.sum(b) for b in a._data)),
+                probe_block=blk, probe_pos=pos, probe_val=vals, dtype=str(a.dtype))
+
+
+def seeded_array(legs, seed, cplx=False, labels=None):
+    """Operand with every charge-allowed block filled from RandomState(seed): blocks are drawn in lexicographic qindex order
+    (last leg most significant), each block C-ordered -- the test regenerates the identical tensor from the legs + seed."""
+    r = np.random.RandomState(seed)
+
+    def f(size):
+        x = r.standard_normal(size)
+        return x + 1.j * r.standard_normal(size) if cplx else x
+    a = npc.Array.from_func(f, legs, dtype=np.complex128 if cplx else np.float64, qtotal=None, shape_kw='size')
+    if labels is not None:
+        a.iset_leg_labels(labels)
+    return a
+
+
+def gen_percall():
+    """SURVEY 8(c) "extra fixtures": per-call results of the reference on operands with the block structure of REAL DMRG
+    states at chi = 64 and chi = 512 (XXZ, Sz): the two tensordots of TwoSiteH.matvec, inner, iadd_prefactor_other, norm,
+    svd (singular values), combine_legs / split_legs.  Operands are seeded random tensors on the legs of the converged
+    run (block data of chi = 512 environments would be 8 MB per tensor); results are stored as fingerprints (probe_array)."""
+    from tenpy.algorithms import dmrg
+    from tenpy.algorithms.mps_common import TwoSiteH
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = []
+    for L, chi, n_sw in ((24, 64, 5), (48, 512, 6)):
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'conserve': 'Sz', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
+                                              'trunc_params': {'chi_max': chi, 'svd_min': 1.e-12},
+                                              'lanczos_params': {'N_min': 2, 'N_max': 6}})
+        for _ in range(n_sw):
+            eng.sweep()
+        i0 = L // 2 - 1
+        eff = TwoSiteH(eng.env, i0, combine=True)
+        theta0 = eff.combine_theta(psi.get_theta(i0, n=2))
+        LH = seeded_array(eff.LHeff.legs, 11, labels=eff.LHeff.get_leg_labels())
+        RH = seeded_array(eff.RHeff.legs, 12, labels=eff.RHeff.get_leg_labels())
+        th = seeded_array(theta0.legs, 13, labels=theta0.get_leg_labels())
+        th2 = seeded_array(theta0.legs, 14, labels=theta0.get_leg_labels())
+        rec = dict(L=L, chi=int(max(psi.chi)), legs_LHeff=[dump_leg(l) for l in eff.LHeff.legs], labels_LHeff=eff.LHeff.get_leg_labels(),
+                   legs_RHeff=[dump_leg(l) for l in eff.RHeff.legs], labels_RHeff=eff.RHeff.get_leg_labels(),
+                   legs_theta=[dump_leg(l) for l in theta0.legs], labels_theta=theta0.get_leg_labels(),
+                   operands=dict(LH=probe_array(LH, 1), RH=probe_array(RH, 2), th=probe_array(th, 3)))
+        t1 = npc.tensordot(LH, th, axes=['(vR.p0*)', '(vL.p0)'])                     # mps_common.py:1336
+        t2 = npc.tensordot(t1, RH, axes=[['wR', '(p1.vR)'], ['wL', '(p1*.vL)']])     # :1337
+        rec['step1'] = probe_array(t1, 4)
+        rec['step2'] = probe_array(t2, 5)
+        rec['inner'] = complex(npc.inner(th, t2.replace_labels(['(vR*.p0)', '(p1.vL*)'], ['(vL.p0)', '(p1.vR)']), axes='labels', do_conj=True))
+        w = th.copy(deep=True)
+        w.iadd_prefactor_other(-0.375, th2)
+        rec['axpy'] = probe_array(w, 6)
+        rec['norm'] = float(npc.norm(th))
+        U, S, VH = npc.svd(th, inner_labels=['vR', 'vL'])
+        rec['svd_S'] = np.array(S)
+        rec['svd_U_qdata'], rec['svd_VH_qdata'] = np.array(U._qdata), np.array(VH._qdata)
+        sp = th.split_legs()
+        rec['split'] = probe_array(sp, 7)
+        rec['recombined'] = probe_array(sp.combine_legs([['vL', 'p0'], ['p1', 'vR']], qconj=[+1, -1]), 8)
+        rec['transposed'] = probe_array(sp.transpose(['p1', 'vR', 'vL', 'p0']), 9)
+        out.append(rec)
+        print('percall', L, rec['chi'], [l['slices'][-1] for l in rec['legs_theta']], len(rec['svd_S']))
+    save('percall.pkl', out)
+
+
+GENERATORS = dict(percall=gen_percall, api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
                   reshape=gen_reshape, linalg=gen_linalg, truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd,
                   qr_theta=gen_qr_theta)
 
