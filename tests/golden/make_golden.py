@@ -537,7 +537,62 @@ def gen_percall():
     save('percall.pkl', out)
 
 
-GENERATORS = dict(percall=gen_percall, api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
+
+def gen_midsize():
+    """Mid-size end-to-end runs of the reference (minutes, not hours): XXZ L=32 chi=128 two-site DMRG
+    (per-sweep energies, centre Schmidt values), Hubbard ladder 2x6 chi=128, TFI-parity real-time TEBD L=16 chi=64 (complex)."""
+    from tenpy.algorithms import dmrg, tebd
+    from tenpy.models.hubbard import FermiHubbardModel
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mps import MPS
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        L = 32
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+        eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
+                                              'trunc_params': {'chi_max': 128, 'svd_min': 1.e-10}, 'lanczos_params': {}})
+        Es = []
+        for _ in range(6):
+            eng.sweep()
+            Es.append(float(eng.update_stats['E_total'][-1]))
+        out['xxz_L32_chi128'] = dict(L=L, chi=128, E_sweeps=Es, chi_final=int(max(psi.chi)), S_mid=np.array(psi.get_SL(L // 2)),
+                                     S_ent=np.array(psi.entanglement_entropy()))
+        print('xxz_L32_chi128', Es[-1], max(psi.chi))
+        Lx = 6
+        M = FermiHubbardModel({'lattice': 'Ladder', 'L': Lx, 't': 1., 'U': 8., 'mu': 0., 'cons_N': 'N', 'cons_Sz': 'Sz',
+                               'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * Lx, bc='finite')
+        eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
+                                              'trunc_params': {'chi_max': 128, 'svd_min': 1.e-10}, 'lanczos_params': {}})
+        Es = []
+        for _ in range(7):
+            eng.sweep()
+            Es.append(float(eng.update_stats['E_total'][-1]))
+        out['hubbard_2x6_chi128'] = dict(Lx=Lx, chi=128, t=1., U=8., mu=0., E_sweeps=Es, chi_final=int(max(psi.chi)),
+                                         S_ent=np.array(psi.entanglement_entropy()))
+        print('hubbard_2x6_chi128', Es[-1], max(psi.chi))
+        L = 16
+        M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': 'parity', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+        eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 1, 'trunc_params': {'chi_max': 64, 'svd_min': 1.e-10}})
+        S_t, chi_t = [], []
+        for step in range(40):
+            eng.run()
+            if step % 4 == 3:
+                S_t.append(np.array(psi.entanglement_entropy()))
+                chi_t.append(int(max(psi.chi)))
+        out['tebd_tfi_parity_L16_chi64'] = dict(L=L, J=1., g=1.5, dt=0.05, chi=64, every=4, S_t=np.array(S_t), chi_t=chi_t,
+                                                S_mid=np.array(psi.get_SL(L // 2)),
+                                                h_bond=[None if h is None else h.transpose(['p0', 'p1', 'p0*', 'p1*']).to_ndarray() for h in M.H_bond],
+                                                state_labels=list(M.lat.mps_sites()[0].state_labels.items()))
+        print('tebd', chi_t[-1], S_t[-1][L // 2 - 1])
+    save('midsize.pkl', out)
+
+
+GENERATORS = dict(midsize=gen_midsize, percall=gen_percall, api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
                   reshape=gen_reshape, linalg=gen_linalg, truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd,
                   qr_theta=gen_qr_theta)
 

@@ -71,6 +71,36 @@ def test_reference_example_d_dmrg_on_mirror():
     assert abs(E - (-40.3843131612185)) < 1e-10 * 40
 
 
+def test_reference_dmrg_with_mixer_combine_false_and_fused_lanczos():
+    """``install(fused=True)``: the reference's ``dmrg.run`` (density-matrix mixer, ``combine=False`` -- its default TwoSiteH form,
+    mps_common.py:144) with ``LanczosGroundState`` rebound to the device recurrence; Heisenberg L=16, chi=32 against the same run
+    of the plain reference module on the mirror."""
+    code = (
+        "import warnings, refsuite_plugin\n"
+        "import tenpy_amd.install as ti\n"
+        "FUSED = %s\n"
+        "if FUSED: ti.use_fused_callers()\n"
+        "warnings.simplefilter('ignore')\n"
+        "from tenpy.algorithms import dmrg\n"
+        "from tenpy.models.xxz_chain import XXZChain\n"
+        "from tenpy.networks.mps import MPS\n"
+        "import tenpy_amd.linalg.krylov_based as kb\n"
+        "assert (dmrg.LanczosGroundState is kb.LanczosGroundState) == FUSED\n"
+        "M = XXZChain({'L': 16, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'sort_charge': True})\n"
+        "psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * 8, bc='finite')\n"
+        "info = dmrg.run(psi, M, {'mixer': True, 'max_N_for_ED': 0, 'combine': False, 'max_sweeps': 6,\n"
+        "                         'trunc_params': {'chi_max': 32, 'svd_min': 1e-10}})\n"
+        "print('ENERGY %%.13f' %% info['E'])\n")
+    env = dict(os.environ)
+    env['PYTHONPATH'] = os.pathsep.join([HERE, ROOT, REF, env.get('PYTHONPATH', '')])
+    E = []
+    for fused in (True, False):
+        res = subprocess.run([sys.executable, '-c', code % fused], env=env, capture_output=True, text=True, timeout=1200)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        E.append(float([l for l in res.stdout.splitlines() if l.startswith('ENERGY')][0].split()[1]))
+    assert abs(E[0] - E[1]) < 1e-10 * abs(E[1]) and abs(E[0] - (-6.9117371455749)) < 1e-6      # (exact: open Heisenberg chain L=16)
+
+
 @pytest.mark.skipif(not os.environ.get('TPA_REFSUITE_FULL'), reason="takes ~10 min; set TPA_REFSUITE_FULL=1")
 @pytest.mark.parametrize("args", [['test_truncation.py'], ['test_dmrg.py', '-k', 'not arpack'], ['test_tebd.py'],
                                   ['test_mps.py'], ['test_mpo.py'], ['test_site.py'], ['test_model.py']], ids=lambda a: a[0])
