@@ -128,6 +128,7 @@ class HostBlock(np.ndarray):
         root = self._root
         if root is None or self._owner is None or not np.shares_memory(self, root):
             return
+        self._owner._own_arena()
         arena = self._owner._arena
         flat = np.asarray(root).reshape(-1)
         arena[self._offset:self._offset + flat.size].copy_(dev.to_device(flat.astype(self._owner.dtype, copy=False)))
@@ -176,7 +177,7 @@ def _get_block(self, qindices, insert=False):
         off = old_n
     else:
         off = int(self._offsets[int(hit[0])])
-    host = dev.to_host(self._arena[off:off + n]).reshape(shape)
+    host = np.array(dev.to_host(self._arena[off:off + n]), copy=True).reshape(shape)     # never a view of the arena itself
     return HostBlock(host, self, off)
 
 
@@ -274,10 +275,7 @@ def _setitem(self, inds, other):
     if all_int:
         if not np.all(self._get_block_charge(_locate(self, inds)[0]) == self.qtotal):
             raise IndexError("trying to set an entry of a block incompatible with the charges")
-        val = np.asarray(other)
-        if val.dtype.kind == 'c' and dense.dtype.kind != 'c':
-            dense = dense.astype(np.complex128)
-        dense[tuple(int(i) for i in inds)] = other
+        dense[tuple(int(i) for i in inds)] = other     # (cast to self.dtype like the reference's block assignment, :986)
     else:
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
@@ -300,8 +298,8 @@ def _setitem(self, inds, other):
             val = other.to_ndarray()
         else:
             val = np.asarray(other)
-        if val.dtype.kind == 'c' and dense.dtype.kind != 'c':
-            dense = dense.astype(np.complex128)
+        # a complex `other` assigned into a real Array keeps the real part, with numpy's ComplexWarning (reference :2790;
+        # networks/mpo.py:3509-3512 relies on it)
         # numpy index with the reference's "outer product" meaning of several index arrays
         basic = [slice(None)] * self.rank
         for a, i in zip(fixed_axes, fixed_idx):

@@ -542,7 +542,16 @@ class LegCharge:
         return self.charges[qindex] * self.qconj
 
     def charge_sectors(self):
-        return np.unique(self.charges, axis=0)
+        """Unique rows of ``charges`` in the ``np.lexsort(charges.T)`` order of a sorted leg (reference :1368; the LAST charge is
+        the primary key, unlike ``np.unique(axis=0)``)."""
+        charges = self.charges
+        if self.block_number == 0:
+            return charges.copy()
+        if charges.shape[1] == 0:               # no conserved charge: one (empty) sector
+            return charges[:1].copy()
+        charges = charges[np.lexsort(charges.T), :]
+        keep = np.concatenate([[True], np.any(charges[1:] != charges[:-1], axis=1)])
+        return charges[keep]
 
     # ---- sort / bunch / project ----------------------------------------------------------------------
     def sort(self, bunch=True):

@@ -190,6 +190,26 @@ class Array:
     def _arena(self, tensor):
         self.__dict__['_arena_t'] = tensor
         self.__dict__['_host_blocks'] = None
+        self._drop_cow()
+
+    def _drop_cow(self):
+        token = self.__dict__.get('_cow')
+        if token is not None:
+            token[0] -= 1
+            self.__dict__['_cow'] = None
+
+    def _own_arena(self):
+        """Copy-on-write.  The reference's in-place methods (``iscale_axis``, ``iconj``, ``iscale_prefactor``, ...) REBIND the
+        block list (np_conserved.py:2130, :2213, :2398), so a shallow copy (``copy(deep=False)``, ``replace_label``,
+        ``gauge_total_charge``, ...) never sees them; here they write into the arena, hence an arena that is shared with a
+        shallow copy is cloned before the first write."""
+        token = self.__dict__.get('_cow')
+        if token is not None:
+            t = self._arena
+            shared = token[0] > 1           # ``_cow`` = [number of Arrays that were given this arena]; collected ones still count
+            self._drop_cow()
+            if shared and t is not None:
+                self.__dict__['_arena_t'] = dev.clone(t)
 
     @property
     def _offsets(self):
@@ -212,6 +232,8 @@ class Array:
         pending = self.__dict__.get('_host_blocks')
         if pending is not None:
             return pending
+        if '_data_placeholder' in self.__dict__:        # tools/cache.py:541 parks the block count here while on disk
+            return self.__dict__['_data_placeholder']
         if self.stored_blocks == 0 or self.__dict__.get('_arena_t') is None:
             return _HostBlockList(self, [])
         host = dev.to_host(self._arena)
@@ -221,6 +243,11 @@ class Array:
 
     @_data.setter
     def _data(self, blocks):
+        self.__dict__.pop('_data_placeholder', None)
+        if not _is_iterable(blocks):                    # ``value._data = len(data)`` (tools/cache.py:541): the blocks are gone
+            self._arena = None
+            self.__dict__['_data_placeholder'] = blocks
+            return
         self.__dict__['_host_blocks'] = _HostBlockList(self, list(blocks), dirty=True)
         self._skey = None
 
@@ -236,6 +263,7 @@ class Array:
         flat = np.concatenate([np.ascontiguousarray(b, dtype=self.dtype).reshape(-1) for b in blocks]) if len(blocks) \
             else np.zeros(0, self.dtype)
         self.__dict__['_arena_t'] = dev.to_device(flat)
+        self._drop_cow()
         self._skey = None
         self.__dict__.pop('_sz_cache', None)
         self.__dict__.pop('_pk_cache', None)
@@ -273,14 +301,20 @@ class Array:
         res = Array.__new__(Array)
         self._arena                 # (uploads blocks assigned through `_data`, if any, before the fields are shared)
         res.__dict__.update(self.__dict__)
+        res.__dict__['_cow'] = None
         res.legs = list(self.legs)
         res._labels = list(self._labels)
         if deep:
             res._qdata = self._qdata.copy()
             res._offsets = self._offsets.copy()
             res.qtotal = self.qtotal.copy()
-            if self._arena is not None:
-                res._arena = dev.clone(self._arena)
+            res._arena = None if self._arena is None else dev.clone(self._arena)
+        else:
+            token = self.__dict__.get('_cow')                           # see _own_arena
+            if token is None:
+                token = self.__dict__['_cow'] = [1]
+            token[0] += 1
+            res.__dict__['_cow'] = token
         return res
 
     def zeros_like(self):
@@ -292,7 +326,13 @@ class Array:
         data_flat = np.asarray(data_flat)
         chinfo = ChargeInfo()
         legs = [LegCharge.from_trivial(s, chinfo) for s in data_flat.shape]
-        return cls.from_ndarray(data_flat, legs, dtype, labels=labels)
+        if dtype is None:
+            dtype = data_flat.dtype
+        res = cls(legs, dtype, labels=labels)            # one block, kept also if it is zero (reference :443-446)
+        res._qdata = np.zeros((1, res.rank), np.intp)
+        res._data = [data_flat.astype(res.dtype, copy=False)]
+        res._qdata_sorted = True
+        return res
 
     @classmethod
     def from_ndarray(cls, data_flat, legcharges, dtype=None, qtotal=None, cutoff=None, labels=None,
@@ -507,6 +547,7 @@ class Array:
         state.pop('_arena_t', None)
         state['_offsets'] = state.pop('_offsets_v')
         state.pop('_host_blocks', None)
+        state.pop('_cow', None)
         state['_arena'] = None if arena is None else dev.to_host(arena)
         state['_skey'] = None
         state.pop('_sz_cache', None)
@@ -675,8 +716,22 @@ class Array:
             else:
                 dims.extend((na, [a]) for a in src)
         nd = len(dims)
-        if nd > COPY_MAXDIM:
+        if nd > COPY_MAXDIM and res.rank <= COPY_MAXDIM:
             return self._combine_legs_via_transpose(combine_legs, new_axes, pipes, transp)
+        if nd > COPY_MAXDIM:
+            # a result of rank > 6 only occurs in set-up utilities (MPS.from_full of >= 5 sites, networks/mps.py:2439): host copy
+            host = dev.to_host(self._arena)
+            out = np.zeros(int(res._arena.numel()), dtype=self.dtype)
+            perm = [a for src in src_axes for a in src]
+            for b in range(nold):
+                blk = host[self._offsets[b]:self._offsets[b] + int(np.prod(old_shapes[b]))].reshape(tuple(old_shapes[b]))
+                nb = int(new_index[b])
+                shape_in = tuple(int(np.prod(old_shapes[b, src])) for src in src_axes)
+                view = out[res._offsets[nb]:res._offsets[nb] + int(np.prod(new_shapes[nb]))].reshape(tuple(new_shapes[nb]))
+                sl = tuple(slice(int(start[b, na]), int(start[b, na]) + shape_in[na]) for na in range(res.rank))
+                view[sl] = np.transpose(blk, perm).reshape(shape_in)
+            res._arena = dev.to_device(out)
+            return res
         new_strides = _c_strides(new_shapes)[new_index]  # (nold, res.rank)
         jobs = np.zeros((nold, 4 + 3 * COPY_MAXDIM), dtype=np.int64)
         jobs[:, 2] = nd
@@ -709,8 +764,6 @@ class Array:
             if na in sizes:
                 groups.append(list(range(pos, pos + w)))
             pos += w
-        if n_new > COPY_MAXDIM:
-            raise NotImplementedError("combine_legs with a result of rank > %d" % COPY_MAXDIM)
         return tr.combine_legs(groups, new_axes=list(new_axes), pipes=list(pipes))
 
     def _combine_legs_make_pipes(self, combine_legs, pipes, qconj):
@@ -825,8 +878,21 @@ class Array:
         new_shapes = res._block_shapes()
         # copy dims: ONE per old axis -- the legs a pipe is split into subdivide a contiguous index range of the old
         # block in C order and are neighbours in the new block, so they move as a single dim
-        if self.rank > COPY_MAXDIM:
-            raise NotImplementedError("split_legs of a tensor of rank > %d" % COPY_MAXDIM)
+        if self.rank > COPY_MAXDIM:         # set-up utilities only (see combine_legs): host copy
+            host = dev.to_host(self._arena)
+            out = np.empty(int(res._arena.numel()), dtype=self.dtype)
+            shapes_old = self._block_shapes()
+            for k in range(nnew):
+                b = int(old_idx[k])
+                blk = host[self._offsets[b]:self._offsets[b] + int(np.prod(shapes_old[b]))].reshape(tuple(shapes_old[b]))
+                ext = [int(np.prod(new_shapes[k, new_of_old[a]])) for a in range(self.rank)]
+                sl = tuple(slice(int(old_start[k, a]), int(old_start[k, a]) + ext[a]) for a in range(self.rank))
+                n = int(np.prod(new_shapes[k]))
+                out[res._offsets[k]:res._offsets[k] + n] = blk[sl].reshape(-1)
+            res._arena = dev.to_device(out)
+            if cutoff > 0.:
+                res.ipurge_zeros(cutoff)
+            return res
         old_shapes = self._block_shapes()[old_idx]
         old_strides = _c_strides(old_shapes)
         new_strides = _c_strides(new_shapes)
@@ -846,6 +912,11 @@ class Array:
         if cutoff > 0.:
             res.ipurge_zeros(cutoff)
         return res
+
+    @staticmethod
+    def _combine_leg_labels(labels):
+        """``'(a.b.(c.d))'`` for ``['a', 'b', '(c.d)']`` (reference :2852)."""
+        return '(' + '.'.join(labels) + ')'
 
     @staticmethod
     def _split_leg_label(label, count):
@@ -973,6 +1044,8 @@ class Array:
         return self
 
     def transpose(self, axes=None):
+        """``itranspose`` on a copy (reference :2084); the permuted blocks go to a new arena, an identity permutation
+        leaves the arena shared copy-on-write."""
         res = self.copy(deep=False)
         res._qdata = self._qdata.copy()
         return res.itranspose(axes)
@@ -1005,6 +1078,7 @@ class Array:
             self._become(self.astype(np.complex128))
         if self.stored_blocks == 0:
             return self
+        self._own_arena()
         s_cplx = s.dtype.kind == 'c'
         s_dev = dev.to_device(s.astype(np.complex128 if s_cplx else np.float64))
         shapes = self._block_shapes()
@@ -1025,12 +1099,13 @@ class Array:
 
     def _become(self, other):
         other._arena
+        self._drop_cow()
         self.__dict__.update(other.__dict__)
 
     def astype(self, dtype, copy=True):
         dtype = _calc_dtype(dtype)
-        if dtype == self.dtype:
-            return self.copy(deep=True) if copy else self
+        if dtype == self.dtype:               # (reference :1882: a new Array object also for copy=False)
+            return self.copy(deep=bool(copy))
         res = self.copy(deep=False)
         res._qdata = self._qdata.copy()
         res._offsets = self._offsets.copy()
@@ -1050,6 +1125,7 @@ class Array:
         """Conjugate: complex conjugate data, conjugate all legs, negate qtotal, toggle '*' on labels."""
         res = self if inplace else self.copy(deep=True)
         if complex_conj and res.dtype.kind == 'c' and res._arena is not None:
+            res._own_arena()
             n = res._arena.numel()
             dev.check(dev.lib().tpa_convert(1, 1, n, res._arena.data_ptr(), res._arena.data_ptr(), 1, dev.stream()), "conj")
         res.qtotal = res.chinfo.make_valid(-res.qtotal)
@@ -1138,6 +1214,7 @@ class Array:
             return self
         p = complex(prefactor)
         self._repack()
+        self._own_arena()
         dev.check(dev.lib().tpa_scal(dev.code(self.dtype), self._arena.numel(), p.real, p.imag,
                                      self._arena.data_ptr(), dev.stream()), "scal")
         return self
@@ -1163,6 +1240,7 @@ class Array:
         p = complex(prefactor)
         L = dev.lib()
         if self.stored_blocks and self._same_structure(other) and self._is_packed():
+            self._own_arena()
             dev.check(L.tpa_axpy(dev.code(calc), self._arena.numel(), p.real, p.imag, other._arena.data_ptr(),
                                  self._arena.data_ptr(), dev.stream()), "axpy")
             return self
@@ -1689,12 +1767,12 @@ def polar(a, cutoff=1.e-16, left=False, inner_labels=[None, None]):
 
 
 def detect_qtotal(flat_array, legcharges, cutoff=None):
-    """Total charge of the first non-zero entry of a dense array (reference :3346)."""
+    """Total charge of the entry of largest magnitude of a dense array (reference :3346-3379)."""
     if cutoff is None:
         cutoff = QCUTOFF
     chinfo = legcharges[0].chinfo
-    inds = np.unravel_index(np.argmax(np.abs(flat_array) > cutoff), flat_array.shape)
-    if abs(flat_array[inds]) <= cutoff:
+    inds = np.unravel_index(np.argmax(np.abs(flat_array)), flat_array.shape)
+    if abs(flat_array[inds]) < cutoff:
         warnings.warn("can't detect total charge: no entry larger than cutoff. Return 0 charge.", stacklevel=2)
         return chinfo.make_valid()
     q = chinfo.make_valid()

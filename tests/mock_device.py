@@ -11,6 +11,7 @@ Host-only entry points (``tpa_plan_tensordot``, ``tpa_gemm_tile_shape``, ...) ar
 shared library.
 """
 import bisect
+import threading
 import ctypes
 import weakref
 
@@ -30,6 +31,7 @@ class _Registry:
     def __init__(self):
         self.starts, self.refs = [], []
         self.n_add = 0
+        self.lock = threading.RLock()       # the reference's `+ h.c.` worker (dmrg_parallel.py) contracts in a second thread
 
     def _purge(self):
         alive = [(s, r) for s, r in zip(self.starts, self.refs) if r() is not None]
@@ -39,6 +41,10 @@ class _Registry:
     def add(self, t):
         if t.numel() == 0:
             return t
+        with self.lock:
+            return self._add(t)
+
+    def _add(self, t):
         self.n_add += 1
         if self.n_add % 2000 == 0:
             self._purge()
@@ -54,6 +60,10 @@ class _Registry:
         """numpy view (of dtype) starting at ptr up to the end of the owning tensor."""
         if ptr is None or ptr == 0:
             return None
+        with self.lock:
+            return self._view(ptr, np_dtype)
+
+    def _view(self, ptr, np_dtype):
         i = bisect.bisect_right(self.starts, ptr) - 1
         while i >= 0:
             t = self.refs[i]()

@@ -243,3 +243,59 @@ def test_item_access_grid_and_charges(backend):
     np.testing.assert_allclose(X.binary_blockwise(np.add, Y).to_ndarray(), X.to_ndarray() + Y.to_ndarray(), atol=1e-15)
     np.testing.assert_allclose(X.binary_blockwise(np.maximum, Y).to_ndarray(), np.maximum(X.to_ndarray(), Y.to_ndarray()))
     assert (X == X.copy(deep=True)) and not (X == Y)
+
+
+# ---- value semantics of copies: the reference's in-place methods rebind the block list, ours write into the arena ---------------
+_NEW_OBJECT = {
+    'transpose (identity)': lambda T: T.transpose(['a', 'b']),
+    'transpose': lambda T: T.transpose(['b', 'a']),
+    'replace_label': lambda T: T.replace_label('a', 'c'),
+    'replace_labels': lambda T: T.replace_labels(['a'], ['c']),
+    'copy(deep=False)': lambda T: T.copy(deep=False),
+    'astype(copy=False)': lambda T: T.astype(T.dtype, copy=False),
+    'gauge_total_charge': lambda T: T.gauge_total_charge('b', [1]),
+    'sort_legcharge(False)': lambda T: T.sort_legcharge(False, False)[1],
+    'conj': lambda T: T.conj(),
+    'add_trivial_leg': lambda T: T.add_trivial_leg(1, 't'),
+    'split_legs (no pipe)': lambda T: T.split_legs(),
+    'scale_axis': lambda T: T.scale_axis(np.ones(T.shape[1]), 'b'),
+    'apply_charge_mapping': lambda T: T.apply_charge_mapping(lambda q: q),
+}
+_WRITES = {
+    'iscale_prefactor': lambda R: R.iscale_prefactor(3.),
+    'iscale_axis': lambda R: R.iscale_axis(np.arange(2., 2. + R.shape[-1]), -1),
+    'iadd_prefactor_other': lambda R: R.iadd_prefactor_other(2., R.copy()),
+    'iconj (complex)': lambda R: R.iconj(),
+    'block write': lambda R: R.get_block(R._qdata[0]).__setitem__(Ellipsis, 7.),
+}
+
+
+@pytest.mark.parametrize("how", sorted(_NEW_OBJECT))
+@pytest.mark.parametrize("write", sorted(_WRITES))
+def test_derived_arrays_do_not_alias(backend, how, write):
+    """``LHeff = LHeff.transpose(...)`` followed by ``LHeff.iscale_axis(...)`` (mps_common.py:2142-2144, the single-site mixer)
+    must leave the cached original alone, also when the permutation is the identity; the same for every other way the
+    reference derives a new Array without copying blocks (np_conserved.py:794, :813, :1227, :1882, :2084)."""
+    rng = np.random.default_rng(3)
+    T = _rand_matrix(rng, 9, 11, cplx=(write == 'iconj (complex)'))
+    before = T.to_ndarray().copy()
+    R = _NEW_OBJECT[how](T)
+    assert R is not T
+    kept = R.to_ndarray().copy()
+    _WRITES[write](R)
+    np.testing.assert_array_equal(T.to_ndarray(), before)
+    R2 = _NEW_OBJECT[how](T)            # ... and a write into the ORIGINAL does not reach an earlier derived Array either
+    kept2 = R2.to_ndarray().copy()
+    if write != 'block write' or T.stored_blocks:
+        _WRITES[write](T)
+    np.testing.assert_array_equal(R2.to_ndarray(), kept2)
+    del kept
+
+
+def test_detect_qtotal_uses_largest_entry(backend):
+    """reference :3372: the charge of the entry of largest magnitude decides, not the first non-zero one."""
+    ci = ChargeInfo([1])
+    legs = [LegCharge.from_qflat(ci, [[0], [1], [2]]), LegCharge.from_qflat(ci, [[0], [1]], -1)]
+    flat = np.array([[1., 0.], [5., 0.], [0., 0.]])
+    assert npc.detect_qtotal(flat, legs).tolist() == [1]
+    assert npc.Array._combine_leg_labels(['a', 'b', '(c.d)']) == '(a.b.(c.d))'
