@@ -526,15 +526,19 @@ __device__ __forceinline__ double sum_coherent(const double *base, int64_t strid
 constexpr int FIT = 2;                      // chunks per wavefront kept in LDS
 constexpr unsigned FUSED_SPIN_MAX = 4000000u;
 
-__global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__restrict__ jobs,
-                                                              const BEntry *__restrict__ entries, int round,
-                                                              double *__restrict__ W, double *__restrict__ G,
-                                                              double *gpart, unsigned int *pair_cnt, unsigned int seq,
-                                                              unsigned int *__restrict__ n_rot,
-                                                              const double *__restrict__ fro2, double rho,
-                                                              int local_sweeps, int full_local, int *err_flag) {
-    __shared__ double Xs[NTG / 64][FIT][TRJ][CHP];
-    __shared__ double Gs[NTG / 64][TRJ][TRJ + 1];
+__global__ __launch_bounds__(NTG, 4) void svd_round_fused_kernel(const SvdJob *__restrict__ jobs,
+                                                                 const BEntry *__restrict__ entries, int round,
+                                                                 double *__restrict__ W, double *__restrict__ G,
+                                                                 double *gpart, unsigned int *pair_cnt, unsigned int seq,
+                                                                 unsigned int *__restrict__ n_rot,
+                                                                 const double *__restrict__ fro2, double rho,
+                                                                 int local_sweeps, int full_local, int *err_flag) {
+    // Occupancy is the point of this layout: the chunks of a part live in REGISTERS between the Gram and the application
+    // (FIT x 16 doubles per lane) and pass through ONE per-wavefront LDS staging tile for the MFMA operand layouts, so a
+    // workgroup needs 38 KB of LDS and <= 128 VGPRs -> 4 workgroups per CU, 1024 on the chip.  A chi = 2048 theta has ~970
+    // (pair, part) entries per round: with the previous 80 KB layout (2 per CU) every round ran as two waves of workgroups
+    // (measured in round 2: 17.6 of the 25 us of a round were there with Gram exchange and local solve removed).
+    __shared__ double Xs[NTG / 64][TRJ][CHP];
     __shared__ double Sm[TRJ][TRJ + 1], Qm[TRJ][TRJ + 1];
     __shared__ double csA[TRJ], cpA[TRJ];
     __shared__ int partA[TRJ];
@@ -544,51 +548,55 @@ __global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__re
     const SvdJob J = jobs[E.job];
     int64_t bi, bj, NB;
     block_pair_of(J, E.pair, round, bi, bj, NB);
-    const int64_t R = J.R, L = J.L;
+    const int R = (int)J.R, L = (int)J.L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    int64_t rowoff[TRJ];
-#pragma unroll
-    for (int t = 0; t < TRJ; ++t) {
-        const int64_t b = (t < BRJ) ? bi : bj;
-        const int64_t r = b * BRJ + (t % BRJ);
-        rowoff[t] = (b < NB && r < R) ? r : -1;
-    }
-    const int64_t nchW = (L + CHJ - 1) / CHJ, nchG = (R + CHJ - 1) / CHJ;
-    const int64_t w_lo = nchW * E.part / E.nparts, w_hi = nchW * (E.part + 1) / E.nparts;
-    const int64_t g_lo = nchG * E.part / E.nparts, g_hi = nchG * (E.part + 1) / E.nparts;
-    const int64_t nW = w_hi - w_lo, nU = nW + (g_hi - g_lo);
-    // ---- load all chunks of this part (both iterations in flight), W chunks also feed the Gram partial
+    const int row_i = (bi < NB) ? (int)bi * BRJ : R, row_j = (bj < NB) ? (int)bj * BRJ : R;      // row t: (t < 8 ? row_i : row_j) + t % 8
+    const int nchW = (L + CHJ - 1) / CHJ, nchG = (R + CHJ - 1) / CHJ;
+    const int w_lo = (int)((int64_t)nchW * E.part / E.nparts), w_hi = (int)((int64_t)nchW * (E.part + 1) / E.nparts);
+    const int g_lo = (int)((int64_t)nchG * E.part / E.nparts), g_hi = (int)((int64_t)nchG * (E.part + 1) / E.nparts);
+    const int nW = w_hi - w_lo, nU = nW + (g_hi - g_lo);
+    double (*Xw)[CHP] = Xs[wave];
+    // ---- load all chunks of this part (both iterations in flight)
     double reg[FIT][TRJ];
 #pragma unroll
     for (int it = 0; it < FIT; ++it) {
-        const int64_t u = wave + (int64_t)it * (NTG / 64);
+        const int u = wave + it * (NTG / 64);
         const bool isW = u < nW;
         const double *M = isW ? (W + J.w_off) : (G + J.g_off);
-        const int64_t len = isW ? L : R;
-        const int64_t c = isW ? (w_lo + u) : (g_lo + (u - nW));
-        const int64_t col = c * CHJ + lane;
+        const int len = isW ? L : R;
+        const int col = (isW ? (w_lo + u) : (g_lo + (u - nW))) * CHJ + lane;
+        const bool ok = u < nU && col < len;
 #pragma unroll
-        for (int t = 0; t < TRJ; ++t) reg[it][t] = (u < nU && rowoff[t] >= 0 && col < len) ? M[rowoff[t] * len + col] : 0.0;
+        for (int t = 0; t < TRJ; ++t) {
+            const int row = ((t < BRJ) ? row_i : row_j) + (t % BRJ);
+            reg[it][t] = (ok && row < R) ? M[(int64_t)row * len + col] : 0.0;
+        }
     }
+    // ---- partial Gram of the W chunks
     d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < FIT; ++it) {
-        const int64_t u = wave + (int64_t)it * (NTG / 64);
-#pragma unroll
-        for (int t = 0; t < TRJ; ++t) Xs[wave][it][t][lane] = reg[it][t];
+        const int u = wave + it * (NTG / 64);
         if (u < nW) {   // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) Xw[t][lane] = reg[it][t];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ks = 0; ks < CHJ / 4; ks += 2) {
-                const double a0 = Xs[wave][it][l15][ks * 4 + l4];
-                const double a1 = Xs[wave][it][l15][ks * 4 + 4 + l4];
+                const double a0 = Xw[l15][ks * 4 + l4];
+                const double a1 = Xw[l15][ks * 4 + 4 + l4];
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
             }
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    // the staging tile of this wavefront now carries its 16 x 16 partial (pitch TRJ + 1) to the cross-wave sum
+    double (*Gw)[TRJ + 1] = reinterpret_cast<double (*)[TRJ + 1]>(&Xs[wave][0][0]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Gs[wave][l4 + 4 * r][l15] = acc0[r] + acc1[r];
+    for (int r = 0; r < 4; ++r) Gw[l4 + 4 * r][l15] = acc0[r] + acc1[r];
     if (tid == 0) any_flag = 0;
     __syncthreads();
     const int64_t first = (int64_t)blockIdx.x - E.part;
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__re
         const int i = tid >> 4, j = tid & 15;
         double sacc = 0;
 #pragma unroll
-        for (int w = 0; w < NTG / 64; ++w) sacc += Gs[w][i][j];
+        for (int w = 0; w < NTG / 64; ++w) sacc += reinterpret_cast<double (*)[TRJ + 1]>(&Xs[w][0][0])[i][j];
         // write-through store (agent scope -> sc1): the partial is not left dirty in this XCD's L2, so no cache
         // write-back fence is needed before the flag (a __threadfence() here cost ~45 us per round with ~400
         // workgroups fencing at once)
@@ -643,18 +651,22 @@ __global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__re
     }
     if (wave == 0) svd_local_solve(Sm, Qm, csA, cpA, partA, lane, local_sweeps, full_local, tol, floor2);
     __syncthreads();
-    // ---- apply Q to the LDS-resident chunks
+    // ---- apply Q to the register-resident chunks (through the staging tile again, now in the B-operand layout)
     double qa[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qa[kk] = Qm[l15][kk * 4 + l4];
 #pragma unroll
     for (int it = 0; it < FIT; ++it) {
-        const int64_t u = wave + (int64_t)it * (NTG / 64);
+        const int u = wave + it * (NTG / 64);
         if (u >= nU) continue;
         const bool isW = u < nW;
         double *M = isW ? (W + J.w_off) : (G + J.g_off);
-        const int64_t len = isW ? L : R;
-        const int64_t c = isW ? (w_lo + u) : (g_lo + (u - nW));
+        const int len = isW ? L : R;
+        const int c0 = (isW ? (w_lo + u) : (g_lo + (u - nW))) * CHJ;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < TRJ; ++t) Xw[t][lane] = reg[it][t];
+        __builtin_amdgcn_wave_barrier();
         d4 o[CHJ / 16];
 #pragma unroll
         for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
@@ -662,16 +674,17 @@ __global__ __launch_bounds__(NTG) void svd_round_fused_kernel(const SvdJob *__re
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int tile = 0; tile < CHJ / 16; ++tile) {
-                const double bb = Xs[wave][it][kk * 4 + l4][tile * 16 + l15];
+                const double bb = Xw[kk * 4 + l4][tile * 16 + l15];
                 o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
             }
 #pragma unroll
         for (int tile = 0; tile < CHJ / 16; ++tile) {
-            const int64_t oc = c * CHJ + tile * 16 + l15;
+            const int oc = c0 + tile * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t gr = rowoff[l4 + 4 * r];
-                if (gr >= 0 && oc < len) M[gr * len + oc] = o[tile][r];
+                const int t = l4 + 4 * r;
+                const int row = ((t < BRJ) ? row_i : row_j) + (t % BRJ);
+                if (row < R && oc < len) M[(int64_t)row * len + oc] = o[tile][r];
             }
         }
     }
