@@ -28,7 +28,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'tests')), r
 def run_reference_tests(args, timeout=3000, plugin='refsuite_plugin'):
     env = dict(os.environ)
     env['PYTHONPATH'] = os.pathsep.join([HERE, ROOT, REF, env.get('PYTHONPATH', '')])
-    cmd = [sys.executable, '-m', 'pytest', '-p', plugin, '-p', 'no:cacheprovider', '-q', '-x'] + list(args)
+    cmd = [sys.executable, '-m', 'pytest', '-p', plugin, '-p', 'no:cacheprovider', '-q'] + ([] if '-n' in args else ['-x']) + list(args)
     res = subprocess.run(cmd, cwd=os.path.join(REF, 'tests'), env=env, capture_output=True, text=True, timeout=timeout)
     tail = (res.stdout[-3000:] + "\n" + res.stderr[-2000:])
     assert res.returncode == 0, "reference tests failed on the mirror:\n" + tail
@@ -40,6 +40,11 @@ FAST = [
     ['test_np_conserved.py', '-k', 'not test_expm'],
     ['test_krylov_based.py', 'test_sparse.py', 'test_svd_robust.py'],
     ['test_truncation.py', '-k', 'truncate or (decompose and 45-True-parity-True)'],
+    # callers: two-site DMRG, single-site DMRG with the subspace-expansion mixer (in-place scaling of a transposed H_eff half:
+    # needs the copy-on-write arenas), finite TEBD, MPS.from_full of 5 sites (rank-12 combine_legs), a purification
+    ['test_dmrg.py', '-k', 'finite-True-False-2 or finite-True-True-1'],
+    ['test_tebd.py', '-k', 'finite-standard'],
+    ['test_purification.py', '-k', 'from_density_matrix and Sz'],
 ]
 
 
@@ -101,11 +106,14 @@ def test_reference_dmrg_with_mixer_combine_false_and_fused_lanczos():
     assert abs(E[0] - E[1]) < 1e-10 * abs(E[1]) and abs(E[0] - (-6.9117371455749)) < 1e-6      # (exact: open Heisenberg chain L=16)
 
 
-@pytest.mark.skipif(not os.environ.get('TPA_REFSUITE_FULL'), reason="takes ~10 min; set TPA_REFSUITE_FULL=1")
-@pytest.mark.parametrize("args", [['test_truncation.py'], ['test_dmrg.py', '-k', 'not arpack'], ['test_tebd.py'],
-                                  ['test_mps.py'], ['test_mpo.py'], ['test_site.py'], ['test_model.py']], ids=lambda a: a[0])
-def test_reference_long_tests_on_mirror(args):
-    run_reference_tests(args, timeout=12000)
+@pytest.mark.skipif(not os.environ.get('TPA_REFSUITE_FULL'), reason="~10 min on 8 cores; set TPA_REFSUITE_FULL=1")
+def test_reference_whole_test_directory_on_mirror():
+    """EVERY test file of the reference (``/root/reference/tests``: linalg, networks, models, algorithms -- DMRG incl. mixers,
+    single-site, infinite, excited states, `+ h.c.` worker thread; TEBD, TDVP, VUMPS, purification, MPO evolution, simulations,
+    tools) in one xdist run on the mirror; ``profiles/r02_reference_suite_on_mirror.txt`` is the record of such a run."""
+    out = run_reference_tests(['-n', str(max(1, (os.cpu_count() or 2) - 1)), '.', '--ignore=benchmark', '--deselect',
+                               'test_np_conserved.py::test_expm'], timeout=12000)
+    assert ' passed' in out and ' failed' not in out
 
 
 def test_expm_is_closer_to_exact_than_scipy(backend):
