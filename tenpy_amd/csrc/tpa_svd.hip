@@ -691,6 +691,137 @@ __global__ __launch_bounds__(NTG, 4) void svd_round_fused_kernel(const SvdJob *_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// One WORKGROUP per pair: 16 wavefronts x FIT chunks cover up to 32 chunks = 2048 columns of [W | G], which is every
+// block the rank-revealing QR leaves of a chi <= 2048 DMRG theta (r + N <= 570 + 1084).  The partial Grams of the
+// wavefronts meet in LDS, so the whole exchange of the fused round (write-through store, counter, spin, coherent
+// reload: ~4 of its ~22 us) and the redundant local solves of the sibling parts disappear, and no workgroup ever
+// waits for another one (no co-residency requirement).  Same arithmetic in the same order as the fused round with
+// nparts = 1 except for the grouping of the partial sums (16 wavefronts instead of parts x 4).
+constexpr int NTW = 1024;
+
+__global__ __launch_bounds__(NTW) void svd_round_wide_kernel(const SvdJob *__restrict__ jobs, const int2 *__restrict__ wpairs,
+                                                             int round, double *__restrict__ W, double *__restrict__ G,
+                                                             unsigned int *__restrict__ n_rot, const double *__restrict__ fro2,
+                                                             double rho, int local_sweeps, int full_local) {
+    __shared__ double Xs[NTW / 64][TRJ][CHP];
+    __shared__ double Sm[TRJ][TRJ + 1], Qm[TRJ][TRJ + 1];
+    __shared__ double csA[TRJ], cpA[TRJ];
+    __shared__ int partA[TRJ];
+    __shared__ int any_flag;
+    const int2 E = wpairs[blockIdx.x];
+    if (E.x < 0) return;
+    const SvdJob J = jobs[E.x];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.y, round, bi, bj, NB);
+    const int R = (int)J.R, L = (int)J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int row_i = (bi < NB) ? (int)bi * BRJ : R, row_j = (bj < NB) ? (int)bj * BRJ : R;
+    const int nW = (L + CHJ - 1) / CHJ, nU = nW + (R + CHJ - 1) / CHJ;       // host guarantees nU <= FIT * NTW / 64
+    double (*Xw)[CHP] = Xs[wave];
+    double reg[FIT][TRJ];
+#pragma unroll
+    for (int it = 0; it < FIT; ++it) {
+        const int u = wave + it * (NTW / 64);
+        const bool isW = u < nW;
+        const double *M = isW ? (W + J.w_off) : (G + J.g_off);
+        const int len = isW ? L : R;
+        const int col = (isW ? u : (u - nW)) * CHJ + lane;
+        const bool ok = u < nU && col < len;
+#pragma unroll
+        for (int t = 0; t < TRJ; ++t) {
+            const int row = ((t < BRJ) ? row_i : row_j) + (t % BRJ);
+            reg[it][t] = (ok && row < R) ? M[(int64_t)row * len + col] : 0.0;
+        }
+    }
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < FIT; ++it) {
+        const int u = wave + it * (NTW / 64);
+        if (u < nW) {   // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < TRJ; ++t) Xw[t][lane] = reg[it][t];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < CHJ / 4; ks += 2) {
+                const double a0 = Xw[l15][ks * 4 + l4];
+                const double a1 = Xw[l15][ks * 4 + 4 + l4];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double (*Gw)[TRJ + 1] = reinterpret_cast<double (*)[TRJ + 1]>(&Xs[wave][0][0]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Gw[l4 + 4 * r][l15] = acc0[r] + acc1[r];
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[E.x];
+    if (tid < TRJ * TRJ) {
+        const int i = tid >> 4, j = tid & 15;
+        double sacc = 0;
+#pragma unroll
+        for (int w = 0; w < NTW / 64; ++w) sacc += reinterpret_cast<double (*)[TRJ + 1]>(&Xs[w][0][0])[i][j];   // fixed order
+        Sm[i][j] = sacc;
+        Qm[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (tid < TRJ * TRJ) {
+        const int ei = tid >> 4, ej = tid & 15;
+        const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
+        if (relevant && svd_needs_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], tol, floor2))
+            atomicOr(&any_flag, svd_big_rotation(Sm[ei][ei], Sm[ej][ej], Sm[ei][ej] * Sm[ei][ej], floor2) ? 3 : 1);
+    }
+    __syncthreads();
+    if (any_flag == 0) return;
+    if (tid == 0) {
+        atomicAdd(n_rot, 1u);
+        if (any_flag & 2) atomicAdd(n_rot + 1, 1u);
+    }
+    if (wave == 0) svd_local_solve(Sm, Qm, csA, cpA, partA, lane, local_sweeps, full_local, tol, floor2);
+    __syncthreads();
+    double qa[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qa[kk] = Qm[l15][kk * 4 + l4];
+#pragma unroll
+    for (int it = 0; it < FIT; ++it) {
+        const int u = wave + it * (NTW / 64);
+        if (u >= nU) continue;
+        const bool isW = u < nW;
+        double *M = isW ? (W + J.w_off) : (G + J.g_off);
+        const int len = isW ? L : R;
+        const int c0 = (isW ? u : (u - nW)) * CHJ;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < TRJ; ++t) Xw[t][lane] = reg[it][t];
+        __builtin_amdgcn_wave_barrier();
+        d4 o[CHJ / 16];
+#pragma unroll
+        for (int tile = 0; tile < CHJ / 16; ++tile) o[tile] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int tile = 0; tile < CHJ / 16; ++tile) {
+                const double bb = Xw[kk * 4 + l4][tile * 16 + l15];
+                o[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[kk], bb, o[tile], 0, 0, 0);
+            }
+#pragma unroll
+        for (int tile = 0; tile < CHJ / 16; ++tile) {
+            const int oc = c0 + tile * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = l4 + 4 * r;
+                const int row = ((t < BRJ) ? row_i : row_j) + (t % BRJ);
+                if (row < R && oc < len) M[(int64_t)row * len + oc] = o[tile][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Complex (Hermitian) version of the split block-Jacobi round.  Same structure; chunks are 32 complex columns
 // (512 B per row segment), re / im planes in LDS, 4 real MFMAs per complex product.
 //   S = X X^H :  Re S = Xr Xr^T + Xi Xi^T ,  Im S = Xi Xr^T - Xr Xi^T
@@ -2178,6 +2309,7 @@ __global__ __launch_bounds__(NT) void qrp_output_kernel_c(const QrpJob *__restri
 
 int tpa_svd_use_qrp = 1;   // real data: rank-revealing pivoted QR before the Jacobi iteration
 
+int tpa_svd_wide_round = 1;    // real data, every block <= 2048 columns of [W | G]: one 1024-thread workgroup per pair (svd_round_wide_kernel)
 int tpa_svd_fused_round = 1;   // real data: one launch per Jacobi round (sibling workgroups synchronise through a counter)
 int tpa_svd_local_sweeps = 1;
 int tpa_svd_predict_convergence = 1;   // a sweep without "big" rotations (scaled cosine > 1e-7) ends the iteration: no verification sweep (validated on the MI355X in round 2)
@@ -2190,12 +2322,14 @@ struct Layout {
     std::vector<int2> rows;   // (job,row) per wavefront, padded to multiple of 4 with (-1,-1)
     std::vector<int2> pairs;  // (job,pair)
     std::vector<BEntry> bentries;  // (job, pair, part, nparts) for the split rounds
+    std::vector<int2> wpairs;      // (job, block pair) for the one-workgroup-per-pair round
+    bool wide_ok = true;           // every job has <= FIT * NTW / 64 column chunks of [W | G]
     int64_t nb_max_pad = 0;
     int64_t max_part_chunks = 0;   // largest number of (W + G) column chunks of one part (fused round: <= 4 * FIT)
     int64_t w_elems = 0, g_elems = 0, sig_elems = 0, rmax_pad = 0;
     // byte offsets inside work buffer
     int64_t off_w = 0, off_g = 0, off_sig = 0, off_perm = 0, off_jobs = 0, off_rows = 0, off_pairs = 0,
-            off_bent = 0, off_pcnt = 0, off_gpart = 0, off_cnt = 0, off_fro = 0, off_fpart = 0, total = 0;
+            off_bent = 0, off_wpairs = 0, off_pcnt = 0, off_gpart = 0, off_cnt = 0, off_fro = 0, off_fpart = 0, total = 0;
 };
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -2245,6 +2379,8 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
             }
             for (int64_t p = 0; p < NBp / 2; ++p)
                 for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
+            for (int64_t p = 0; p < NBp / 2; ++p) lay.wpairs.push_back(int2{b, (int)p});
+            if (nch_all > FIT * (NTW / 64)) lay.wide_ok = false;
             if (dtype != TPA_C128 && NBp >= 2) {
                 const int64_t nchG = (J.R + 63) / 64;
                 for (int q = 0; q < nparts; ++q) {
@@ -2276,6 +2412,8 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.pairs.size() * sizeof(int2), 256);
     lay.off_bent = o;
     o = align_up(o + (int64_t)lay.bentries.size() * sizeof(BEntry), 256);
+    lay.off_wpairs = o;
+    o = align_up(o + (int64_t)lay.wpairs.size() * sizeof(int2), 256);
     lay.off_pcnt = o;
     o = align_up(o + (int64_t)lay.bentries.size() * 4 + 64, 256);   // per-entry pair counters + error flag
     lay.off_gpart = o;
@@ -2322,6 +2460,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     BEntry *bent = (BEntry *)(work + lay.off_bent);
     double *gpart = (double *)(work + lay.off_gpart);
     TPA_HIP_CHECK(hipMemcpyAsync(bent, lay.bentries.data(), lay.bentries.size() * sizeof(BEntry), hipMemcpyHostToDevice, st));
+    int2 *wpairs = (int2 *)(work + lay.off_wpairs);
+    TPA_HIP_CHECK(hipMemcpyAsync(wpairs, lay.wpairs.data(), lay.wpairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     // pageable host memory: the copies above are staged before returning, vectors may die later.
     const int g_rows = (int)(lay.rows.size() / (NT / 64));
     const int g_pairs = (int)(lay.pairs.size() / (NT / 64));
@@ -2351,6 +2491,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     }();
     const bool use_fused = use_block && !CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FIT &&
                            (int64_t)lay.bentries.size() <= oversub * fused_round_capacity();
+    const bool use_wide = use_block && !CPLX && tpa_svd_fused_round && tpa_svd_wide_round && lay.wide_ok;
     unsigned int *pcnt = (unsigned int *)(work + lay.off_pcnt);
     int *perr = (int *)(pcnt + lay.bentries.size());
     unsigned int fused_seq = 0;
@@ -2363,6 +2504,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             if (use_block && CPLX) {
                 svd_gram_part_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (const double2 *)W, gpart);
                 svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
+            } else if (use_wide) {
+                svd_round_wide_kernel<<<(int)lay.wpairs.size(), NTW, 0, st>>>(jobs, wpairs, r, W, G, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
             } else if (use_fused) {
                 ++fused_seq;
                 svd_round_fused_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, W, G, gpart, pcnt, fused_seq, cnt, fro2, rho,
@@ -2377,7 +2520,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         unsigned int h2[2] = {0, 0};
         int herr = 0;
         TPA_HIP_CHECK(hipMemcpyAsync(h2, cnt, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        if (use_fused) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (use_fused && !use_wide) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
         TPA_HIP_CHECK(hipStreamSynchronize(st));
         if (herr) {
             snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: sibling workgroups of a fused Jacobi round lost each other (spin limit)");
@@ -2947,6 +3090,7 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_cross_only = (pairwise & 4) ? 0 : 1;
     tpa_svd_use_qrp = (pairwise & 512) ? 0 : 1;    // bit 9: no pivoted-QR preconditioner
     tpa_svd_fused_round = (pairwise & 2) ? 0 : 1;  // bit 1: two-kernel rounds (gram, then solve + apply)
+    tpa_svd_wide_round = (pairwise & 2048) ? 0 : 1;   // bit 11: no one-workgroup-per-pair round (-> fused round with column parts)
     tpa_svd_predict_convergence = (pairwise & 1024) ? 0 : 1;   // bit 10: always run the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
