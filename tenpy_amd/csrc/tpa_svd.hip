@@ -1259,8 +1259,8 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                                                        double *__restrict__ tau, int64_t *__restrict__ cperm,
                                                        QrpState *__restrict__ state, const double *__restrict__ fro2,
                                                        double tol2, double *__restrict__ Tpan, int pivot) {
-    __shared__ double rv[NTP / 64];
-    __shared__ int64_t ri[NTP / 64];
+    __shared__ double rv[2 * (NTP / 64)];
+    __shared__ int64_t ri[2 * (NTP / 64)];
     __shared__ double red[NTP / 64][PNB + 1];
     __shared__ int64_t s_p[PNB];
     __shared__ int s_nbk;
@@ -1292,50 +1292,46 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
             s_nbk = nb_;
         }
         __syncthreads();
-    } else
-    for (int l = 0; l < PNB; ++l) {
-        double bv = -3.0;
-        int64_t bidx = N;
+    } else {
+        // One barrier per pivot: every wavefront finds its best candidate (value by wave_max, smallest index among equal values
+        // by wave_min), publishes it in a double-buffered LDS slot, and EVERY thread merges the NTP/64 entries itself.
+        int nsel = 0;
+        for (int l = 0; l < PNB; ++l) {
+            double bv = -3.0;
+            int bidx = 0x7fffffff;
 #pragma unroll
-        for (int t = 0; t < RPT; ++t)
-            if (cand[t] > bv) {
-                bv = cand[t];
-                bidx = tid + (int64_t)t * NTP;
-            }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(bv, off, 64);
-            const int64_t oi = __shfl_xor(bidx, off, 64);
-            if (ov > bv || (ov == bv && oi < bidx)) {
-                bv = ov;
-                bidx = oi;
-            }
-        }
-        __syncthreads();
-        if (lane == 0) {
-            rv[wave] = bv;
-            ri[wave] = bidx;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double v0 = rv[0];
-            int64_t i0 = ri[0];
-            for (int w = 1; w < NTP / 64; ++w)
-                if (rv[w] > v0 || (rv[w] == v0 && ri[w] < i0)) {
-                    v0 = rv[w];
-                    i0 = ri[w];
+            for (int t = 0; t < RPT; ++t)
+                if (cand[t] > bv) {
+                    bv = cand[t];
+                    bidx = tid + t * NTP;
                 }
-            if (v0 > thresh && s_nbk == l) {
-                s_p[l] = i0;
-                s_nbk = l + 1;
+            const double wv = wave_max(bv);
+            const int wi = wave_min((bv == wv) ? bidx : 0x7fffffff);
+            if (lane == 0) {
+                rv[(l & 1) * (NTP / 64) + wave] = wv;
+                ri[(l & 1) * (NTP / 64) + wave] = wi;
             }
-        }
-        __syncthreads();
-        if (s_nbk <= l) break;   // uniform
-        const int64_t w = s_p[l];
+            __syncthreads();
+            double v0 = rv[(l & 1) * (NTP / 64)];
+            int64_t i0 = ri[(l & 1) * (NTP / 64)];
 #pragma unroll
-        for (int t = 0; t < RPT; ++t)
-            if (tid + (int64_t)t * NTP == w) cand[t] = -4.0;
+            for (int w = 1; w < NTP / 64; ++w) {
+                const double vw = rv[(l & 1) * (NTP / 64) + w];
+                const int64_t iw = ri[(l & 1) * (NTP / 64) + w];
+                if (vw > v0 || (vw == v0 && iw < i0)) {
+                    v0 = vw;
+                    i0 = iw;
+                }
+            }
+            if (!(v0 > thresh)) break;   // uniform: every thread merged the same entries
+            if (tid == 0) s_p[l] = i0;
+            nsel = l + 1;
+#pragma unroll
+            for (int t = 0; t < RPT; ++t)
+                if (tid + t * NTP == (int)i0) cand[t] = -4.0;
+        }
+        if (tid == 0) s_nbk = nsel;
+        __syncthreads();
     }
     const int nbk = s_nbk;
     if (nbk == 0) {
