@@ -77,6 +77,14 @@ __device__ __forceinline__ int wave_min(int v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also waits for every outstanding GLOBAL store of the
+// wavefront (vmcnt(0) of its workgroup-scope fence): in a latency chain that stores results to memory as it goes (panel
+// factorisation) each barrier would then cost a full store round trip.  Use only where no thread reads global data that another
+// thread of the workgroup wrote earlier in the same kernel.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Sum over a workgroup of NT threads; result valid in every thread. `red` >= NT/64 doubles of LDS.
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, double *red) {

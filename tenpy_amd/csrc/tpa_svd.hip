@@ -1224,25 +1224,29 @@ constexpr int NTP_MAX = 256;   // threads of the panel kernel: 64 (one wavefront
 constexpr int PNB = 8;    // pivot columns factorised per launch (panel pivoting: the PNB largest residual columns)
 constexpr int RPT_MAX = 32;  // rows / candidate columns per thread held in registers (template RPT = 8, 16, 32)  ->  max(m, n) <= 8192
 
-// sum K values over the workgroup (NTP threads); results valid in every thread
+// sum the values v[q], q < n or q == extra, over the workgroup (NTP threads); results valid in every thread.  The callers
+// sit in fully unrolled loops, so n / extra are constants after unrolling and the unused entries cost nothing.
 template <int NTP, int K>
-__device__ __forceinline__ void block_sum_vec(double (&v)[K], double (*red)[PNB + 1]) {
+__device__ __forceinline__ void block_sum_vec(double (&v)[K], double (*red)[PNB + 1], int n, int extra) {
 #pragma unroll
-    for (int q = 0; q < K; ++q) v[q] = wave_sum(v[q]);
+    for (int q = 0; q < K; ++q)
+        if (q < n || q == extra) v[q] = wave_sum(v[q]);
     if (NTP == 64) return;   // a single wavefront: wave_sum already left the total in every lane
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int q = 0; q < K; ++q) red[threadIdx.x >> 6][q] = v[q];
+        for (int q = 0; q < K; ++q)
+            if (q < n || q == extra) red[threadIdx.x >> 6][q] = v[q];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
-    for (int q = 0; q < K; ++q) {
-        double t = 0;
+    for (int q = 0; q < K; ++q)
+        if (q < n || q == extra) {
+            double t = 0;
 #pragma unroll
-        for (int w = 0; w < NTP / 64; ++w) t += red[w][q];
-        v[q] = t;
-    }
+            for (int w = 0; w < NTP / 64; ++w) t += red[w][q];
+            v[q] = t;
+        }
 }
 
 // One workgroup per block: pick the (up to) PNB unprocessed columns with the largest residual norms and factorise
@@ -1291,7 +1295,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
             for (int l = 0; l < nb_; ++l) s_p[l] = (int64_t)k + l;
             s_nbk = nb_;
         }
-        __syncthreads();
+        lds_barrier();
     } else {
         // One barrier per pivot: every wavefront finds its best candidate (value by wave_max, smallest index among equal values
         // by wave_min), publishes it in a double-buffered LDS slot, and EVERY thread merges the NTP/64 entries itself.
@@ -1311,7 +1315,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                 rv[(l & 1) * (NTP / 64) + wave] = wv;
                 ri[(l & 1) * (NTP / 64) + wave] = wi;
             }
-            __syncthreads();
+            lds_barrier();
             double v0 = rv[(l & 1) * (NTP / 64)];
             int64_t i0 = ri[(l & 1) * (NTP / 64)];
 #pragma unroll
@@ -1331,7 +1335,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                 if (tid + t * NTP == (int)i0) cand[t] = -4.0;
         }
         if (tid == 0) s_nbk = nsel;
-        __syncthreads();
+        lds_barrier();
     }
     const int nbk = s_nbk;
     if (nbk == 0) {
@@ -1348,7 +1352,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
         cperm[J.c_off + k + tid] = s_p[tid];
         cn[J.c_off + s_p[tid]] = -1.0;     // processed
     }
-    __syncthreads();
+    lds_barrier();
     double *Xb = X + J.x_off;
     // ---- gather the panel into registers (X is column-major: contiguous loads)
     double c[PNB][RPT];
@@ -1374,7 +1378,7 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                         for (int t = 0; t < RPT; ++t) y[m] = fma(c[m][t], c[l][t], y[m]);
                     }
                 }
-                block_sum_vec<NTP, PNB>(y, red);
+                block_sum_vec<NTP, PNB>(y, red, l, -1);
                 double z[PNB];
 #pragma unroll
                 for (int m = 0; m < PNB; ++m) {
@@ -1412,13 +1416,24 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
                         if (m < l) s_vrow[m] = c[m][t];
                 }
             }
-            block_sum_vec<NTP, PNB + 1>(g, red);
+            block_sum_vec<NTP, PNB + 1>(g, red, l, PNB);
             const double s2 = g[PNB], alpha = s_alpha;
+            // beta = -sign(alpha) |x|,  tau = (beta - alpha) / beta = 1 + |alpha| / |x|,  scale = 1 / (alpha - beta): one reciprocal
+            // square root and one reciprocal, both from the hardware seed + Newton steps (~1 ulp; a Householder vector does not need
+            // correctly rounded divisions, and these sit on the serial path of every column)
             double beta = alpha, tk = 0.0, scale = 0.0;
             if (s2 > 0.0) {
-                beta = -copysign(sqrt(alpha * alpha + s2), alpha);
-                tk = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
+                const double x2 = fma(alpha, alpha, s2);
+                double r = __builtin_amdgcn_rsq(x2);
+                r = r * fma(-0.5 * x2 * r, r, 1.5);
+                r = r * fma(-0.5 * x2 * r, r, 1.5);          // 1 / |x|
+                const double nx = x2 * r;                   // |x|
+                beta = -copysign(nx, alpha);
+                tk = fma(fabs(alpha), r, 1.0);
+                const double d = alpha - beta;              // = sign(alpha) (|alpha| + |x|): no cancellation
+                double q = __builtin_amdgcn_rcp(d);
+                q = q * fma(-d, q, 2.0);
+                scale = q * fma(-d, q, 2.0);
             }
             // column l of the compact-WY factor: Tf[i2][l] = -tau sum_{m=i2}^{l-1} Tf[i2][m] (v_m^T v_l), thread i2 each
             if (tid < l) {
@@ -1436,23 +1451,15 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
 #pragma unroll
             for (int t = 0; t < RPT; ++t) {
                 const int64_t i = tid + (int64_t)t * NTP;
-                if (i < M) {
-                    double v;
-                    if (i < kl) {
-                        v = 0.0;
-                        xc[i] = c[l][t];              // R entry (rows k .. kl-1 were changed by this panel's earlier reflectors)
-                    } else if (i == kl) {
-                        xc[i] = beta;
-                        v = 1.0;
-                    } else {
-                        xc[i] = 0.0;
-                        v = c[l][t] * scale;
-                    }
+                if (i < M) {   // (selects, no divergent branches)
+                    const double cv = c[l][t];
+                    const double v = (i > kl) ? cv * scale : ((i == kl) ? 1.0 : 0.0);
+                    xc[i] = (i < kl) ? cv : ((i == kl) ? beta : 0.0);   // R entry (rows k .. kl-1 were changed by this panel's earlier reflectors)
                     vk[i] = v;
                     c[l][t] = v;
                 }
             }
-            __syncthreads();   // Tf column l, s_alpha / s_vrow reuse
+            lds_barrier();   // Tf column l, s_alpha / s_vrow reuse
         }
     }
     if (tid < PNB * PNB) Tpan[(int64_t)b * PNB * PNB + tid] = Tf[tid / PNB][tid % PNB];
