@@ -253,86 +253,77 @@ constexpr int NTG = 256;  // 4 wavefronts per (pair, part) workgroup
 __device__ __forceinline__ void svd_local_solve(double (*Sm)[TRJ + 1], double (*Qm)[TRJ + 1], double *csA, double *cpA,
                                                 int *partA, int lane, int local_sweeps, int full_local, double tol,
                                                 double floor2) {
-    // ---- local solve: ONE wavefront, 4 matrix elements per lane, no workgroup barriers ---------------
-    // `full` rounds sweep all 120 pairs of the 16 rows (15 local rounds); otherwise only the 64 CROSS pairs
-    // between the two 8-row blocks are rotated (8 local rounds, partner of i<8 is 8 + (i + rr) % 8): pairs
-    // inside a block were orthogonalised when the block last took part in a full round and are only
-    // perturbed at second order since.  The host requests a full round once per sweep for every pair.
-    {
-        const int ei = lane >> 2, ej0 = (lane & 3) * 4;
-        const int n_local = full_local ? (TRJ - 1) : BRJ;
-        for (int sweep = 0; sweep < local_sweeps; ++sweep) {
-            bool rotated = false;
-            for (int rr = 0; rr < n_local; ++rr) {
-                bool rot_now = false;
-                if (lane < TRJ) {
-                    const int i = lane;
-                    int pi;
-                    if (full_local) {
-                        if (i == TRJ - 1)
-                            pi = rr;
-                        else if (i == rr)
-                            pi = TRJ - 1;
-                        else
-                            pi = (2 * rr - i + 2 * (TRJ - 1)) % (TRJ - 1);
-                    } else {
-                        pi = (i < BRJ) ? (BRJ + ((i + rr) & (BRJ - 1))) : (((i - BRJ) - rr) & (BRJ - 1));
-                    }
-                    const int p = (i < pi) ? i : pi, q = (i < pi) ? pi : i;
-                    const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
-                    double c = 1.0, s = 0.0;
-                    if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
-                        const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
-                        const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
-                        const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
-                        const double x = fma(t, t, 1.0);
-                        double c0 = __builtin_amdgcn_rsq(x);
-                        c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
-                        c = c0 * fma(-0.5 * x * c0, c0, 1.5);
-                        s = c * t;
-                        rotated = true;
-                        rot_now = true;
-                    }
-                    partA[i] = pi;
-                    csA[i] = c;
-                    cpA[i] = (i == p) ? -s : s;
-                }
-                if (!__any(rot_now)) continue;   // no pair of this local round needs a rotation: skip the update passes
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                {
-                    const int pi = partA[ei];
-                    const double cs = csA[ei], cp = cpA[ei];
-                    double s_new[4], q_new[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        s_new[u] = cs * Sm[ei][ej0 + u] + cp * Sm[pi][ej0 + u];
-                        q_new[u] = cs * Qm[ei][ej0 + u] + cp * Qm[pi][ej0 + u];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        Sm[ei][ej0 + u] = s_new[u];
-                        Qm[ei][ej0 + u] = q_new[u];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                {
-                    double s_new[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ej = ej0 + u, pj = partA[ej];
-                        s_new[u] = csA[ej] * Sm[ei][ej] + cpA[ej] * Sm[ei][pj];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) Sm[ei][ej0 + u] = s_new[u];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // ONE wavefront, 4 matrix elements per lane (row ei = lane / 4, columns ej0 .. ej0 + 3), no workgroup barriers.
+    // `full` rounds sweep all 120 pairs of the 16 rows (15 local rounds); otherwise only the 64 CROSS pairs between the two
+    // 8-row blocks are rotated (8 local rounds, partner of i < 8 is 8 + (i + rr) % 8): pairs inside a block were orthogonalised
+    // when the block last took part in a full round and are only perturbed at second order since.  The host requests a full
+    // round once per sweep for every pair.
+    // A local round is a chain of LDS round trips, so it is kept short (measured in round 2: the solve was 7 of the 22 us of a
+    // Jacobi round): every lane computes the rotation of ITS row itself (no hand-over of the row parameters), only the column
+    // parameters go through LDS, and S <- R^T S R is applied in one pass,
+    //     S'[i][j] = cs_i (c_j S[i][j] + s_j S[i][pj]) + cp_i (c_j S[pi][j] + s_j S[pi][pj]),
+    // i.e. per local round: read 3 -> rotation -> write parameters -> read 36 -> write 8.
+    const int ei = lane >> 2, ej0 = (lane & 3) * 4;
+    const int n_local = full_local ? (TRJ - 1) : BRJ;
+    for (int sweep = 0; sweep < local_sweeps; ++sweep) {
+        bool rotated = false;
+        for (int rr = 0; rr < n_local; ++rr) {
+            int pi;
+            if (full_local) {
+                if (ei == TRJ - 1)
+                    pi = rr;
+                else if (ei == rr)
+                    pi = TRJ - 1;
+                else
+                    pi = (2 * rr - ei + 2 * (TRJ - 1)) % (TRJ - 1);
+            } else {
+                pi = (ei < BRJ) ? (BRJ + ((ei + rr) & (BRJ - 1))) : (((ei - BRJ) - rr) & (BRJ - 1));
             }
-            if (!__any(rotated)) break;
+            const int p = (ei < pi) ? ei : pi, q = (ei < pi) ? pi : ei;
+            const double a = Sm[p][p], b = Sm[q][q], g = Sm[p][q];
+            double cs = 1.0, cp = 0.0;
+            bool rot_now = false;
+            if (svd_needs_rotation(a, b, g * g, tol, floor2)) {
+                const double zeta = (b - a) * __builtin_amdgcn_rcp(2.0 * g);
+                const double h = __builtin_amdgcn_sqrt(fma(zeta, zeta, 1.0));
+                const double t = copysign(1.0, zeta) * __builtin_amdgcn_rcp(fabs(zeta) + h);
+                const double x = fma(t, t, 1.0);
+                double c0 = __builtin_amdgcn_rsq(x);
+                c0 = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                cs = c0 * fma(-0.5 * x * c0, c0, 1.5);
+                const double sn = cs * t;
+                cp = (ei == p) ? -sn : sn;
+                rot_now = true;
+            }
+            if (!__any(rot_now)) continue;   // no pair of this local round needs a rotation
+            rotated = true;
+            if ((lane & 3) == 0) {
+                partA[ei] = pi;
+                csA[ei] = cs;
+                cpA[ei] = cp;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            double s_new[4], q_new[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ej = ej0 + u, pj = partA[ej];
+                const double cj = csA[ej], sj = cpA[ej];
+                const double r0 = fma(cj, Sm[ei][ej], sj * Sm[ei][pj]);
+                const double r1 = fma(cj, Sm[pi][ej], sj * Sm[pi][pj]);
+                s_new[u] = fma(cs, r0, cp * r1);
+                q_new[u] = fma(cs, Qm[ei][ej], cp * Qm[pi][ej]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Sm[ei][ej0 + u] = s_new[u];
+                Qm[ei][ej0 + u] = q_new[u];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
+        if (!__any(rotated)) break;
     }
-    }
+}
 
 
 __global__ __launch_bounds__(NTG) void svd_gram_part_kernel(const SvdJob *__restrict__ jobs,
