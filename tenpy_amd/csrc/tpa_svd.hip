@@ -2473,18 +2473,12 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
     const bool use_block = !tpa_svd_force_pairwise;
-    // fused one-launch round: spin-waits between sibling workgroups need the whole grid resident (<= 2 workgroups of
-    // 70 KB LDS per CU) and every part must fit the LDS-resident chunk budget
-    // Only the <= 8 sibling parts of ONE pair wait for each other, so a grid larger than the resident set still completes
-    // (workgroups are dispatched in ascending order).  Measured in round 2 (chi = 2048 sweep, ~40 % of the rounds have more
-    // entries than fit at once): oversubscribing by 4x / 16x made the SVD phase SLOWER (4.32 / 4.31 s against 4.10 s per sweep
-    // with the two-kernel round for those blocks) -- spinning siblings hold CUs that the late parts need.  Default 1 = off.
-    static const int64_t oversub = []() {
-        const char *e = getenv("TPA_SVD_FUSED_OVERSUB");
-        return (int64_t)((e && atoi(e) > 0) ? atoi(e) : 1);
-    }();
+    // fused one-launch round: the spin-waits between sibling workgroups need the whole grid resident (4 workgroups of 38 KB LDS
+    // per CU) and every part must fit the register-resident chunk budget.  (Oversubscribing the resident set by 4x / 16x was
+    // measured in round 2 and is SLOWER, 4.32 / 4.31 against 4.10 s of SVD per sweep: spinning siblings hold the CUs that the
+    // late parts need.)
     const bool use_fused = use_block && !CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FIT &&
-                           (int64_t)lay.bentries.size() <= oversub * fused_round_capacity();
+                           (int64_t)lay.bentries.size() <= fused_round_capacity();
     const bool use_wide = use_block && !CPLX && tpa_svd_fused_round && tpa_svd_wide_round && lay.wide_ok;
     unsigned int *pcnt = (unsigned int *)(work + lay.off_pcnt);
     int *perr = (int *)(pcnt + lay.bentries.size());
