@@ -135,6 +135,8 @@ def reference_entry(config_name, chi):
             ref = json.load(f)
     except Exception:
         return None, None
+    if config_name == 'hubbard1024':
+        return ref.get('hubbard%d' % chi), ref
     return ref.get('dmrg%d' % chi) if config_name in ('heis2048', 'xxz512') else None, ref
 
 
@@ -346,7 +348,7 @@ def main():
             out["chi_reached"] = eng.sweep_stats['max_chi'][-1]
             out["E_sweeps"] = sweep_E
             ref, ref_all = reference_entry(args.config, chi)
-            if ref is not None and L == 100 and args.lanczos_N == 8:
+            if ref is not None and L == (80 if args.config == 'hubbard1024' else 100) and args.lanczos_N == 8:
                 # the reference ran the same protocol; its sweep list starts with the same ramp
                 ref_E = [e['E'] for e in ref['sweeps']]
                 idx = min(len(sweep_E), len(ref_E)) - 1
@@ -364,7 +366,7 @@ def main():
                 mid = [t for i, t in zip(eng.update_stats['i0'][n0:], upd_t) if abs(i - L // 2) <= 1]
                 gpu_bond_s = float(np.mean(mid)) if mid else s_per_step / n_upd
                 base = None
-                if ref_all is not None and args.config in ('heis2048', 'xxz512'):
+                if ref_all is not None and args.config in ('heis2048', 'xxz512', 'hubbard1024'):
                     envi = ref_all.get('environment', {})
                     if ref is not None:
                         base = {"value": ref['s_per_sweep_best'], "unit": unit, "cores": envi.get('cores'), "kind": "reference",

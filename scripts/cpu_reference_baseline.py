@@ -52,12 +52,19 @@ def env_info():
             "blas_threads": os.environ.get('OMP_NUM_THREADS', 'default (all cores)'), "optimization_level": 3}
 
 
-def dmrg_protocol(L, chi, n_sweeps_at_chi, label):
+def dmrg_protocol(L, chi, n_sweeps_at_chi, label, model='xxz'):
     """bench.py's protocol, sweep by sweep, on the reference: Neel state, 2 sweeps at chi=64, one sweep per doubling of chi
     (adaptive Lanczos N<=20), then `n_sweeps_at_chi` sweeps at the target chi with Lanczos N=8.  Energy and time of EVERY
-    sweep are recorded: the energies are what bench.py's `energy_err` compares with."""
-    M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'conserve': 'Sz', 'sort_charge': True})
-    psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+    sweep are recorded: the energies are what bench.py's `energy_err` compares with.  ``model='hubbard'``: BASELINE config 4,
+    FermiHubbardModel on a 2 x (L/2) ladder, t=1, U=8, half filling, charges (N, Sz) (bench.py --config hubbard1024)."""
+    if model == 'hubbard':
+        from tenpy.models.hubbard import FermiHubbardModel
+        M = FermiHubbardModel({'lattice': 'Ladder', 'L': L // 2, 't': 1., 'U': 8., 'mu': 0., 'cons_N': 'N', 'cons_Sz': 'Sz',
+                               'bc_MPS': 'finite', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+    else:
+        M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'conserve': 'Sz', 'sort_charge': True})
+        psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
     eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
                                           'trunc_params': {'chi_max': min(64, chi), 'svd_min': 1.e-14},
                                           'lanczos_params': {'N_min': 2, 'N_max': 20}})
@@ -83,8 +90,10 @@ def dmrg_protocol(L, chi, n_sweeps_at_chi, label):
         sweep('N=8')
     S = psi.get_SL(L // 2)
     at = [e for e in log if e['lanczos'] == 'N=8']
-    return {"workload": "bench.py protocol on the reference: XXZChain L=%d (Sz), TwoSiteDMRGEngine combine=True, no mixer, "
-                        "svd_min=1e-14; chi ramp 64 x2, doubling, then %d sweeps at chi=%d with Lanczos N=8" % (L, n_sweeps_at_chi, chi),
+    return {"workload": "bench.py protocol on the reference: %s, TwoSiteDMRGEngine combine=True, no mixer, "
+                        "svd_min=1e-14; chi ramp 64 x2, doubling, then %d sweeps at chi=%d with Lanczos N=8"
+                        % ("FermiHubbardModel ladder 2 x %d (N, Sz)" % (L // 2) if model == 'hubbard' else "XXZChain L=%d (Sz)" % L,
+                           n_sweeps_at_chi, chi),
             "sweeps": log, "s_per_sweep_best": min(e['s'] for e in at[1:]) if len(at) > 1 else at[0]['s'],
             "E_final": at[-1]['E'], "centre_schmidt_values_top16": [float(x) for x in np.sort(S)[::-1][:16]],
             "bond_updates_per_sweep": 2 * (L - 2)}
@@ -210,6 +219,10 @@ if __name__ == '__main__':
     if what.startswith('dmrg'):            # e.g. dmrg2048:3  or  dmrg512:4
         chi, n = (what[4:].split(':') + ['3'])[:2]
         out['dmrg%s' % chi] = dmrg_protocol(100, int(chi), int(n), 'dmrg%s' % chi)
+        json.dump(out, open(OUT, 'w'), indent=1)
+    if what.startswith('hubbard'):         # e.g. hubbard1024:3   (ladder 2 x 40)
+        chi, n = (what[7:].split(':') + ['3'])[:2]
+        out['hubbard%s' % chi] = dmrg_protocol(80, int(chi), int(n), 'hubbard%s' % chi, model='hubbard')
         json.dump(out, open(OUT, 'w'), indent=1)
     if what in ('sweep512', 'all'):
         out['sweep512'] = sweep512()
