@@ -487,6 +487,67 @@ def seeded_array(legs, seed, cplx=False, labels=None):
     return a
 
 
+def _percall_record(eff, theta0, L, chi):
+    """The hot-path calls of one bond update on seeded operands with the legs of `eff` / `theta0`; results as fingerprints."""
+    LH = seeded_array(eff.LHeff.legs, 11, labels=eff.LHeff.get_leg_labels())
+    RH = seeded_array(eff.RHeff.legs, 12, labels=eff.RHeff.get_leg_labels())
+    th = seeded_array(theta0.legs, 13, labels=theta0.get_leg_labels())
+    th2 = seeded_array(theta0.legs, 14, labels=theta0.get_leg_labels())
+    rec = dict(L=L, chi=chi, legs_LHeff=[dump_leg(l) for l in eff.LHeff.legs], labels_LHeff=eff.LHeff.get_leg_labels(),
+               legs_RHeff=[dump_leg(l) for l in eff.RHeff.legs], labels_RHeff=eff.RHeff.get_leg_labels(),
+               legs_theta=[dump_leg(l) for l in theta0.legs], labels_theta=theta0.get_leg_labels(),
+               operands=dict(LH=probe_array(LH, 1), RH=probe_array(RH, 2), th=probe_array(th, 3)))
+    t1 = npc.tensordot(LH, th, axes=['(vR.p0*)', '(vL.p0)'])                     # mps_common.py:1336
+    t2 = npc.tensordot(t1, RH, axes=[['wR', '(p1.vR)'], ['wL', '(p1*.vL)']])     # :1337
+    rec['step1'] = probe_array(t1, 4)
+    rec['step2'] = probe_array(t2, 5)
+    rec['inner'] = complex(npc.inner(th, t2.replace_labels(['(vR*.p0)', '(p1.vL*)'], ['(vL.p0)', '(p1.vR)']), axes='labels', do_conj=True))
+    w = th.copy(deep=True)
+    w.iadd_prefactor_other(-0.375, th2)
+    rec['axpy'] = probe_array(w, 6)
+    rec['norm'] = float(npc.norm(th))
+    U, S, VH = npc.svd(th, inner_labels=['vR', 'vL'])
+    rec['svd_S'] = np.array(S)
+    rec['svd_U_qdata'], rec['svd_VH_qdata'] = np.array(U._qdata), np.array(VH._qdata)
+    sp = th.split_legs()
+    rec['split'] = probe_array(sp, 7)
+    rec['recombined'] = probe_array(sp.combine_legs([['vL', 'p0'], ['p1', 'vR']], qconj=[+1, -1]), 8)
+    rec['transposed'] = probe_array(sp.transpose(['p1', 'vR', 'vL', 'p0']), 9)
+    print('percall', L, rec['chi'], [l['slices'][-1] for l in rec['legs_theta']], len(rec['svd_S']))
+    return rec
+
+
+def gen_percall2048():
+    """The same calls at BASELINE's full size: legs of a chi = 2048 Heisenberg centre bond (10 bond sectors
+    [2, 24, 122, 334, 542, 542, 334, 122, 24, 2], the block structure of the real chi = 2048 state, cf. scripts/cpu_reference_baseline.py),
+    fused theta 4096 x 4096 in blocks up to 1084 x 1084, LHeff / RHeff of 131 MB each.  Seeded operands, fingerprints only (a few KB)."""
+    from tenpy.algorithms.mps_common import TwoSiteH
+    from tenpy.models.xxz_chain import XXZChain
+    from tenpy.networks.mpo import MPOEnvironment
+    L, sectors = 100, [2, 24, 122, 334, 542, 542, 334, 122, 24, 2]
+    M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'conserve': 'Sz', 'sort_charge': True})
+    i0 = L // 2 - 1
+    site = M.lat.mps_sites()[i0]
+    q = np.arange(-(len(sectors) - 1), len(sectors), 2)
+    vL = npc.LegCharge.from_qind(site.leg.chinfo, np.concatenate([[0], np.cumsum(sectors)]), q[:, None], qconj=+1)
+    vR = vL.conj()
+    W0, W1 = M.H_MPO.get_W(i0), M.H_MPO.get_W(i0 + 1)
+    LP = seeded_array([vL, W0.get_leg('wL').conj(), vL.conj()], 21, labels=['vR*', 'wR', 'vR'])
+    RP = seeded_array([vR.conj(), W1.get_leg('wR').conj(), vR], 22, labels=['vL', 'wL', 'vL*'])
+    theta = seeded_array([vL, site.leg, site.leg, vR], 23, labels=['vL', 'p0', 'p1', 'vR'])
+
+    class Env:
+        H = M.H_MPO
+        get_LP = staticmethod(lambda i, store=True: LP)
+        get_RP = staticmethod(lambda i, store=True: RP)
+    Env._contract_LHeff = lambda i, label_p='p0', pipe=None: MPOEnvironment._contract_LHeff(Env, i, label_p, pipe)
+    Env._contract_RHeff = lambda i, label_p='p1', pipe=None: MPOEnvironment._contract_RHeff(Env, i, label_p, pipe)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        eff = TwoSiteH(Env, i0, combine=True)
+        save('percall2048.pkl', [_percall_record(eff, eff.combine_theta(theta), L, 2048)])
+
+
 def gen_percall():
     """SURVEY 8(c) "extra fixtures": per-call results of the reference on operands with the block structure of REAL DMRG
     states at chi = 64 and chi = 512 (XXZ, Sz): the two tensordots of TwoSiteH.matvec, inner, iadd_prefactor_other, norm,
@@ -508,32 +569,7 @@ def gen_percall():
         i0 = L // 2 - 1
         eff = TwoSiteH(eng.env, i0, combine=True)
         theta0 = eff.combine_theta(psi.get_theta(i0, n=2))
-        LH = seeded_array(eff.LHeff.legs, 11, labels=eff.LHeff.get_leg_labels())
-        RH = seeded_array(eff.RHeff.legs, 12, labels=eff.RHeff.get_leg_labels())
-        th = seeded_array(theta0.legs, 13, labels=theta0.get_leg_labels())
-        th2 = seeded_array(theta0.legs, 14, labels=theta0.get_leg_labels())
-        rec = dict(L=L, chi=int(max(psi.chi)), legs_LHeff=[dump_leg(l) for l in eff.LHeff.legs], labels_LHeff=eff.LHeff.get_leg_labels(),
-                   legs_RHeff=[dump_leg(l) for l in eff.RHeff.legs], labels_RHeff=eff.RHeff.get_leg_labels(),
-                   legs_theta=[dump_leg(l) for l in theta0.legs], labels_theta=theta0.get_leg_labels(),
-                   operands=dict(LH=probe_array(LH, 1), RH=probe_array(RH, 2), th=probe_array(th, 3)))
-        t1 = npc.tensordot(LH, th, axes=['(vR.p0*)', '(vL.p0)'])                     # mps_common.py:1336
-        t2 = npc.tensordot(t1, RH, axes=[['wR', '(p1.vR)'], ['wL', '(p1*.vL)']])     # :1337
-        rec['step1'] = probe_array(t1, 4)
-        rec['step2'] = probe_array(t2, 5)
-        rec['inner'] = complex(npc.inner(th, t2.replace_labels(['(vR*.p0)', '(p1.vL*)'], ['(vL.p0)', '(p1.vR)']), axes='labels', do_conj=True))
-        w = th.copy(deep=True)
-        w.iadd_prefactor_other(-0.375, th2)
-        rec['axpy'] = probe_array(w, 6)
-        rec['norm'] = float(npc.norm(th))
-        U, S, VH = npc.svd(th, inner_labels=['vR', 'vL'])
-        rec['svd_S'] = np.array(S)
-        rec['svd_U_qdata'], rec['svd_VH_qdata'] = np.array(U._qdata), np.array(VH._qdata)
-        sp = th.split_legs()
-        rec['split'] = probe_array(sp, 7)
-        rec['recombined'] = probe_array(sp.combine_legs([['vL', 'p0'], ['p1', 'vR']], qconj=[+1, -1]), 8)
-        rec['transposed'] = probe_array(sp.transpose(['p1', 'vR', 'vL', 'p0']), 9)
-        out.append(rec)
-        print('percall', L, rec['chi'], [l['slices'][-1] for l in rec['legs_theta']], len(rec['svd_S']))
+        out.append(_percall_record(eff, theta0, L, int(max(psi.chi))))
     save('percall.pkl', out)
 
 
@@ -592,7 +628,7 @@ def gen_midsize():
     save('midsize.pkl', out)
 
 
-GENERATORS = dict(midsize=gen_midsize, percall=gen_percall, api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
+GENERATORS = dict(midsize=gen_midsize, percall=gen_percall, percall2048=gen_percall2048, api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
                   reshape=gen_reshape, linalg=gen_linalg, truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd,
                   qr_theta=gen_qr_theta)
 

@@ -37,7 +37,23 @@ def check(a, fp, tol=1e-12):
 
 @pytest.mark.parametrize("idx", [0, 1], ids=['chi64', 'chi512'])
 def test_percall_vs_reference(backend, idx):
-    rec = golden('percall.pkl')[idx]
+    _percall(golden('percall.pkl')[idx])
+
+
+@pytest.mark.gpu
+def test_percall_vs_reference_full_size():
+    """BASELINE's full size: chi = 2048 Heisenberg centre bond (bond sectors [2, 24, 122, 334, 542, 542, 334, 122, 24, 2]; fused theta
+    4096 x 4096 in blocks up to 1084 x 1084, LHeff / RHeff 131 MB each) against fingerprints the REFERENCE computed on the same seeded
+    operands (``make_golden.py:gen_percall2048``).  GPU only: the numpy emulation would spend minutes in Python tile loops."""
+    from tenpy_amd import _lib
+    from tenpy_amd.linalg import np_conserved as npc
+    _lib.require_gpu()
+    npc._plan_cache.clear()
+    _percall(golden('percall2048.pkl')[0])
+    npc._plan_cache.clear()
+
+
+def _percall(rec):
     LH = seeded_array([load_leg(l) for l in rec['legs_LHeff']], 11, rec['labels_LHeff'])
     RH = seeded_array([load_leg(l) for l in rec['legs_RHeff']], 12, rec['labels_RHeff'])
     th = seeded_array([load_leg(l) for l in rec['legs_theta']], 13, rec['labels_theta'])
