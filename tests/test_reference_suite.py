@@ -106,7 +106,8 @@ def test_reference_dmrg_with_mixer_combine_false_and_fused_lanczos():
     assert abs(E[0] - E[1]) < 1e-10 * abs(E[1]) and abs(E[0] - (-6.9117371455749)) < 1e-6      # (exact: open Heisenberg chain L=16)
 
 
-@pytest.mark.skipif(not os.environ.get('TPA_REFSUITE_FULL'), reason="~10 min on 8 cores; set TPA_REFSUITE_FULL=1")
+@pytest.mark.timeout(14400)          # (pytest.ini's per-test limit is for the everyday suite)
+@pytest.mark.skipif(not os.environ.get('TPA_REFSUITE_FULL'), reason="~12 min on 8 idle cores; set TPA_REFSUITE_FULL=1")
 def test_reference_whole_test_directory_on_mirror():
     """EVERY test file of the reference (``/root/reference/tests``: linalg, networks, models, algorithms -- DMRG incl. mixers,
     single-site, infinite, excited states, `+ h.c.` worker thread; TEBD, TDVP, VUMPS, purification, MPO evolution, simulations,
