@@ -102,6 +102,11 @@ def parity_and_port(eng, args, gpu_bond_s):
         want = fac.prepare_svd(fac.matvec(th_fac))
         LH, RH, th = oracle_tensor(eff.LHeff), oracle_tensor(eff.RHeff), oracle_tensor(theta)
         # --- device side of the comparison
+        if os.environ.get('TPA_DUMP_THETA') and i0 == bonds[0]:
+            # charge blocks of the wave function the SVD sees (after one Lanczos run), for scripts/svd_file_bench.py: this is how
+            # scripts/data/theta_chi2048_sat.npz (not tracked: 25 MB) is produced -- `TPA_DUMP_THETA=path python bench.py`
+            _, th_opt, _ = LanczosGroundState(fac, th_fac, {'N_min': args.lanczos_N, 'N_max': args.lanczos_N}).run()
+            np.savez(os.environ['TPA_DUMP_THETA'], **{'b%02d' % k: np.asarray(b) for k, b in enumerate(fac.prepare_svd(th_opt)._data)})
         U, S_dev, VH = npc.svd(fac.prepare_svd(th_fac), inner_labels=['vR', 'vL'])
         E_dev, _, N_dev = LanczosGroundState(fac, th_fac, {'N_min': args.lanczos_N, 'N_max': args.lanczos_N}).run()
         # --- oracle: timed part = N matvecs (+ the vector work of a Lanczos step) + block SVD

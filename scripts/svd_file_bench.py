@@ -1,5 +1,7 @@
 """Dev harness for the batched block SVD: loads the charge blocks of a dumped theta (npz, default the saturated chi=2048
-Heisenberg theta), runs tpa_svd_batch, prints time / sweeps / accuracy against LAPACK (host, checker only)."""
+Heisenberg theta), runs tpa_svd_batch, prints time / sweeps / accuracy against LAPACK (host, checker only).
+The default file is not tracked (25 MB); regenerate it on a GPU box with
+``TPA_DUMP_THETA=scripts/data/theta_chi2048_sat.npz python bench.py --steps 1``."""
 import ctypes
 import os
 import sys
