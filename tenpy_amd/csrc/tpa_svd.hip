@@ -303,15 +303,33 @@ __device__ __forceinline__ void svd_local_solve(double (*Sm)[TRJ + 1], double (*
                 cpA[ei] = cp;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // all LDS reads of the pass are issued in two groups (the second depends on the partner indices of the first) and
+            // only then consumed: left to itself the compiler waits for each of the 8 dependent reads separately
+            int pjv[4];
+            double cj[4], sj[4], s_ii[4], s_pi[4], q_i[4], q_p[4], s_ip[4], s_pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pjv[u] = partA[ej0 + u];
+                cj[u] = csA[ej0 + u];
+                sj[u] = cpA[ej0 + u];
+                s_ii[u] = Sm[ei][ej0 + u];
+                s_pi[u] = Sm[pi][ej0 + u];
+                q_i[u] = Qm[ei][ej0 + u];
+                q_p[u] = Qm[pi][ej0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s_ip[u] = Sm[ei][pjv[u]];
+                s_pp[u] = Sm[pi][pjv[u]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             double s_new[4], q_new[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ej = ej0 + u, pj = partA[ej];
-                const double cj = csA[ej], sj = cpA[ej];
-                const double r0 = fma(cj, Sm[ei][ej], sj * Sm[ei][pj]);
-                const double r1 = fma(cj, Sm[pi][ej], sj * Sm[pi][pj]);
+                const double r0 = fma(cj[u], s_ii[u], sj[u] * s_ip[u]);
+                const double r1 = fma(cj[u], s_pi[u], sj[u] * s_pp[u]);
                 s_new[u] = fma(cs, r0, cp * r1);
-                q_new[u] = fma(cs, Qm[ei][ej], cp * Qm[pi][ej]);
+                q_new[u] = fma(cs, q_i[u], cp * q_p[u]);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
