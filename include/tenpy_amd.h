@@ -153,7 +153,8 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
 /* Algorithm switch (test / benchmark hook): 0 (default) = pivoted-QR preconditioner + block Jacobi (16-row MFMA
  * Gram + in-LDS eigen-solve); bit 0 = one wavefront per row pair; bit 1 = two-kernel Jacobi rounds instead of the fused one; bit 2 = full local
  * sweep in every round; bits 4-7 = local sweeps; bit 9 (512) = no pivoted-QR preconditioner; bit 10 (1024) = NO predicted
- * convergence.  Predicted convergence (default since round 2, validated on the MI355X on chi = 2048 blocks: same singular values
+ * convergence; bit 11 (2048) = no one-workgroup-per-pair round (real data, blocks with rank + columns <= 2048; the fused round with
+ * column parts is used instead).  Predicted convergence (default since round 2, validated on the MI355X on chi = 2048 blocks: same singular values
  * to 1.4e-15 sigma_max, same orthogonality, one to two sweeps fewer): a sweep in which no rotated pair had a scaled cosine
  * above 1e-7 ends the iteration without the verification sweep (quadratic convergence leaves cosines <= 1e-14). */
 int tpa_svd_set_algorithm(int pairwise);
