@@ -2321,6 +2321,7 @@ __global__ __launch_bounds__(NT) void qrp_output_kernel_c(const QrpJob *__restri
 
 int tpa_svd_use_qrp = 1;   // real data: rank-revealing pivoted QR before the Jacobi iteration
 
+int tpa_svd_small_panel = 1;   // test hook (TPA_SVD_SMALL_PANEL=0): one-wavefront panel kernel for blocks <= 512 x 512
 int tpa_svd_wide_round = 1;    // real data, every block <= 2048 columns of [W | G]: one 1024-thread workgroup per pair (svd_round_wide_kernel)
 int tpa_svd_fused_round = 1;   // real data: one launch per Jacobi round (sibling workgroups synchronise through a counter)
 int tpa_svd_local_sweeps = 1;
@@ -2653,6 +2654,7 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     TPA_HIP_CHECK(hipMemcpyAsync(sjobs, lay.jobs.data(), lay.jobs.size() * sizeof(SvdJob), hipMemcpyHostToDevice, st));
     svd_fro_kernel<CPLX><<<dim3(FRO_PARTS, n_jobs), NT, 0, st>>>(sjobs, (const double *)a_base, fpart);
     svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(fpart, fro2);
+    { const char *e = getenv("TPA_SVD_SMALL_PANEL"); if (e) tpa_svd_small_panel = atoi(e); }
     const int nmax = (int)q.n_max;
     if (CPLX)
         qrp_init_kernel_c<<<dim3((nmax + 63) / 64, n_jobs), NT, 0, st>>>(qjobs, sjobs, (const cd *)a_base, (cd *)X, cn, cperm, state);
@@ -2668,7 +2670,11 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
                 qrp_panel_kernel_c<256, 4><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan, 1);
             else
                 qrp_panel_kernel_c<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, tol2, (cd *)Tpan, 1);
-        } else if (q.m_max <= 8 * 256)
+        } else if (q.m_max <= 8 * 64 && q.n_max <= 8 * 64 && tpa_svd_small_panel)
+            // small blocks (chi <= 512, Hubbard ladders): the whole panel in ONE wavefront -- no workgroup barriers, no LDS stage in
+            // the reductions (for >= 1000 rows this variant was 1.6x slower, here the barriers are all there is to save)
+            qrp_panel_kernel<64, 8><<<n_jobs, 64, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan, 1);
+        else if (q.m_max <= 8 * 256)
             qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan, 1);
         else if (q.m_max <= 16 * 256)
             qrp_panel_kernel<256, 16><<<n_jobs, 256, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, cn, (double *)tau, cperm, state, fro2, tol2, (double *)Tpan, 1);
