@@ -27,8 +27,20 @@ def lib():
     return _lib.load()
 
 
+_raw_stream = None
+
+
 def stream():
-    return torch().cuda.current_stream().cuda_stream
+    """Raw handle of torch's CURRENT stream on the current device (so `torch.cuda.stream(...)` contexts are honoured).  Goes through
+    torch's C entry point: `torch.cuda.current_stream().cuda_stream` builds a Python Stream object per call (9 us; ~100 calls per bond
+    update = 0.19 s per sweep at any chi, measured with cProfile in round 2)."""
+    global _raw_stream
+    if _raw_stream is None:
+        t = torch()
+        fast = getattr(t._C, '_cuda_getCurrentRawStream', None)
+        getdev = getattr(t._C, '_cuda_getDevice', None) or t.cuda.current_device
+        _raw_stream = (lambda: fast(getdev())) if fast is not None else (lambda: t.cuda.current_stream().cuda_stream)
+    return _raw_stream()
 
 
 def code(dtype):

@@ -482,14 +482,16 @@ class LegCharge:
     def test_contractible(self, other):
         """Raise ValueError unless ``self`` can be contracted with ``other``: equal ChargeInfo and slices, charges equal
         up to the opposite sign convention (reference :1071)."""
-        if self.chinfo != other.chinfo:
+        if self.chinfo is not other.chinfo and self.chinfo != other.chinfo:
             raise ValueError(''.join(["incompatible ChargeInfo\n", str(self.chinfo), str(other.chinfo)]))
         if not self._same_charges(other, -1):
             raise ValueError("incompatible LegCharge\nself\n" + str(self) + "\nother (conjugated)\n" + str(other.conj()))
 
     def test_equal(self, other):
         """Raise ValueError unless slices and charges (with ``qconj``, modulo the charge moduli) agree (reference :1114)."""
-        if self.chinfo != other.chinfo:
+        if self is other:
+            return
+        if self.chinfo is not other.chinfo and self.chinfo != other.chinfo:
             raise ValueError(''.join(["incompatible ChargeInfo\n", str(self.chinfo), str(other.chinfo)]))
         if not self._same_charges(other, +1):
             raise ValueError("incompatible LegCharge\nself\n" + str(self) + "\nother\n" + str(other))

@@ -1225,10 +1225,11 @@ class Array:
         if self.rank != other.rank:
             raise ValueError("different rank!")
         for self_leg, other_leg in zip(self.legs, other.legs):
-            self_leg.test_equal(other_leg)
+            if self_leg is not other_leg:                   # (Krylov vectors share their leg objects: nothing to compare)
+                self_leg.test_equal(other_leg)
         if np.any(self.qtotal != other.qtotal):
             raise ValueError("Arrays can't have different `qtotal`!")
-        if self.legs[0].chinfo != other.legs[0].chinfo:
+        if self.legs[0].chinfo is not other.legs[0].chinfo and self.legs[0].chinfo != other.legs[0].chinfo:
             raise ValueError("Arrays have different ChargeInfo")
         if prefactor == 0. or other.stored_blocks == 0:
             return self
