@@ -216,8 +216,21 @@ class LanczosGroundState:
         assert N == len(vf) > 1
         psif = self.psi0 * vf[0]
         len_cache = len(self._cache)
-        for k in range(1, min(len_cache + 1, N)):
-            psif.iadd_prefactor_other(vf[N - k], self._cache[-k])
+        terms = [(vf[N - k], self._cache[-k]) for k in range(1, min(len_cache + 1, N))]
+        key = psif._struct_key()
+        if psif.stored_blocks and psif._is_packed() and all(
+                v.dtype == psif.dtype and v._struct_key() == key and all(a is b for a, b in zip(v.legs, psif.legs))
+                for _, v in terms):
+            # the Krylov vectors of one run share block structure and leg objects: flat axpys on the arenas, without the
+            # per-call argument checks of iadd_prefactor_other (11 of them per bond update cost 0.7 ms of host time)
+            L, code, n, st = dev.lib(), dev.code(psif.dtype), psif._arena.numel(), dev.stream()
+            psif._own_arena()
+            for c, v in terms:
+                c = complex(c)
+                dev.check(L.tpa_axpy(code, n, c.real, c.imag, v._arena.data_ptr(), psif._arena.data_ptr(), st), "axpy")
+        else:
+            for c, v in terms:
+                psif.iadd_prefactor_other(c, v)
         self._cache = []
         self._rebuild_krylov_for_result_full(psif, N - len_cache - 1)
         nrm = npc.norm(psif)
