@@ -902,64 +902,10 @@ __global__ __launch_bounds__(NTG) void svd_gram_part_kernel_c(const SvdJob *__re
     }
 }
 
-__global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__restrict__ jobs,
-                                                                const BEntry *__restrict__ entries, int round,
-                                                                double2 *__restrict__ W, double2 *__restrict__ G,
-                                                                const double *__restrict__ gpart,
-                                                                unsigned int *__restrict__ n_rot,
-                                                                const double *__restrict__ fro2, double rho,
-                                                                int local_sweeps, int full_local) {
-    __shared__ double Xr[NTG / 64][TRJ][CHCP], Xi[NTG / 64][TRJ][CHCP];
-    __shared__ double Sr[TRJ][TRJ + 1], Si[TRJ][TRJ + 1], Qr[TRJ][TRJ + 1], Qi[TRJ][TRJ + 1];
-    __shared__ double csA[TRJ], cprA[TRJ], cpiA[TRJ];
-    __shared__ int partA[TRJ];
-    __shared__ int any_flag;
-    const BEntry E = entries[blockIdx.x];
-    if (E.job < 0) return;
-    const SvdJob J = jobs[E.job];
-    int64_t bi, bj, NB;
-    block_pair_of(J, E.pair, round, bi, bj, NB);
-    const int64_t R = J.R, L = J.L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int half = lane >> 5, l31 = lane & 31;
-    int64_t rowoff[TRJ];
-#pragma unroll
-    for (int t = 0; t < TRJ; ++t) {
-        const int64_t b = (t < BRJ) ? bi : bj;
-        const int64_t r = b * BRJ + (t % BRJ);
-        rowoff[t] = (b < NB && r < R) ? r : -1;
-    }
-    {
-        const int64_t first = (int64_t)blockIdx.x - E.part;
-        double sr = 0, si = 0;
-        for (int p = 0; p < E.nparts; ++p) {
-            sr += gpart[(first + p) * 512 + tid];
-            si += gpart[(first + p) * 512 + 256 + tid];
-        }
-        Sr[tid >> 4][tid & 15] = sr;
-        Si[tid >> 4][tid & 15] = si;
-        Qr[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
-        Qi[tid >> 4][tid & 15] = 0.0;
-    }
-    if (tid == 0) any_flag = 0;
-    __syncthreads();
-    const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[E.job];
-    {
-        const int ei = tid >> 4, ej = tid & 15;
-        const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
-        if (relevant && svd_needs_rotation(Sr[ei][ei], Sr[ej][ej], Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej], tol, floor2))
-            atomicOr(&any_flag, svd_big_rotation(Sr[ei][ei], Sr[ej][ej], Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej], floor2) ? 3 : 1);
-    }
-    __syncthreads();
-    if (any_flag == 0) return;
-    if (tid == 0 && E.part == 0) {
-        atomicAdd(n_rot, 1u);
-        if (any_flag & 2) atomicAdd(n_rot + 1, 1u);
-    }
-
-    if (wave == 0) {
+// Local solve of the 16 x 16 Hermitian problem by ONE wavefront (complex counterpart of svd_local_solve).
+__device__ __forceinline__ void svd_local_solve_c(double (*Sr)[TRJ + 1], double (*Si)[TRJ + 1], double (*Qr)[TRJ + 1],
+                                                  double (*Qi)[TRJ + 1], double *csA, double *cprA, double *cpiA, int *partA,
+                                                  int lane, int local_sweeps, int full_local, double tol, double floor2) {
         const int ei = lane >> 2, ej0 = (lane & 3) * 4;
         const int n_local = full_local ? (TRJ - 1) : BRJ;
         for (int sweep = 0; sweep < local_sweeps; ++sweep) {
@@ -1053,7 +999,66 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__
             }
             if (!__any(rotated)) break;
         }
+}
+
+__global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__restrict__ jobs,
+                                                                const BEntry *__restrict__ entries, int round,
+                                                                double2 *__restrict__ W, double2 *__restrict__ G,
+                                                                const double *__restrict__ gpart,
+                                                                unsigned int *__restrict__ n_rot,
+                                                                const double *__restrict__ fro2, double rho,
+                                                                int local_sweeps, int full_local) {
+    __shared__ double Xr[NTG / 64][TRJ][CHCP], Xi[NTG / 64][TRJ][CHCP];
+    __shared__ double Sr[TRJ][TRJ + 1], Si[TRJ][TRJ + 1], Qr[TRJ][TRJ + 1], Qi[TRJ][TRJ + 1];
+    __shared__ double csA[TRJ], cprA[TRJ], cpiA[TRJ];
+    __shared__ int partA[TRJ];
+    __shared__ int any_flag;
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.pair, round, bi, bj, NB);
+    const int64_t R = J.R, L = J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int half = lane >> 5, l31 = lane & 31;
+    int64_t rowoff[TRJ];
+#pragma unroll
+    for (int t = 0; t < TRJ; ++t) {
+        const int64_t b = (t < BRJ) ? bi : bj;
+        const int64_t r = b * BRJ + (t % BRJ);
+        rowoff[t] = (b < NB && r < R) ? r : -1;
     }
+    {
+        const int64_t first = (int64_t)blockIdx.x - E.part;
+        double sr = 0, si = 0;
+        for (int p = 0; p < E.nparts; ++p) {
+            sr += gpart[(first + p) * 512 + tid];
+            si += gpart[(first + p) * 512 + 256 + tid];
+        }
+        Sr[tid >> 4][tid & 15] = sr;
+        Si[tid >> 4][tid & 15] = si;
+        Qr[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+        Qi[tid >> 4][tid & 15] = 0.0;
+    }
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[E.job];
+    {
+        const int ei = tid >> 4, ej = tid & 15;
+        const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
+        if (relevant && svd_needs_rotation(Sr[ei][ei], Sr[ej][ej], Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej], tol, floor2))
+            atomicOr(&any_flag, svd_big_rotation(Sr[ei][ei], Sr[ej][ej], Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej], floor2) ? 3 : 1);
+    }
+    __syncthreads();
+    if (any_flag == 0) return;
+    if (tid == 0 && E.part == 0) {
+        atomicAdd(n_rot, 1u);
+        if (any_flag & 2) atomicAdd(n_rot + 1, 1u);
+    }
+
+    if (wave == 0) svd_local_solve_c(Sr, Si, Qr, Qi, csA, cprA, cpiA, partA, lane, local_sweeps, full_local, tol, floor2);
     __syncthreads();
 
     // ---- apply X <- Q X (complex): Xr' = Qr Xr - Qi Xi ; Xi' = Qr Xi + Qi Xr
@@ -1094,6 +1099,199 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__
                     const int64_t gr = rowoff[l4 + 4 * r];
                     if (gr >= 0 && oc < len) M[gr * len + oc] = double2{orr[r], oii[r]};
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Complex fused round: Gram, sibling exchange, local solve and application in ONE launch -- the complex counterpart of
+// svd_round_fused_kernel (same hand-off protocol: write-through partials, one counter per pair, bounded spin).  A part's chunks
+// (32 complex columns each, <= 2 per wavefront) stay in registers between Gram and application; the 16 x 16 matrices S and Q
+// live in the staging tiles of wavefronts 2 and 3 while those are idle, so a workgroup needs 34 KB of LDS (4 per CU).
+// TEBD at chi = 1024 (two 1024 x 1024 complex blocks): the two-kernel round cost 15.5 + 38.7 us.
+constexpr int FITC = 2;
+
+__device__ __forceinline__ void sum_coherent2(const double *base, int64_t stride, int n, double &re, double &im) {
+    re = sum_coherent(base, stride, n);
+    im = sum_coherent(base + 256, stride, n);
+}
+
+__global__ __launch_bounds__(NTG, 4) void svd_round_fused_kernel_c(const SvdJob *__restrict__ jobs,
+                                                                   const BEntry *__restrict__ entries, int round,
+                                                                   double2 *__restrict__ W, double2 *__restrict__ G,
+                                                                   double *gpart, unsigned int *pair_cnt, unsigned int seq,
+                                                                   unsigned int *__restrict__ n_rot,
+                                                                   const double *__restrict__ fro2, double rho,
+                                                                   int local_sweeps, int full_local, int *err_flag) {
+    __shared__ double Xr[NTG / 64][TRJ][CHCP], Xi[NTG / 64][TRJ][CHCP];
+    __shared__ double csA[TRJ], cprA[TRJ], cpiA[TRJ];
+    __shared__ int partA[TRJ];
+    __shared__ int any_flag;
+    const BEntry E = entries[blockIdx.x];
+    if (E.job < 0) return;
+    const SvdJob J = jobs[E.job];
+    int64_t bi, bj, NB;
+    block_pair_of(J, E.pair, round, bi, bj, NB);
+    const int R = (int)J.R, L = (int)J.L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int half = lane >> 5, l31 = lane & 31;      // two rows per load instruction: lanes 0-31 row t, 32-63 row t + 1
+    const int row_i = (bi < NB) ? (int)bi * BRJ : R, row_j = (bj < NB) ? (int)bj * BRJ : R;
+    const int nchW = (L + CHC - 1) / CHC, nchG = (R + CHC - 1) / CHC;
+    const int w_lo = (int)((int64_t)nchW * E.part / E.nparts), w_hi = (int)((int64_t)nchW * (E.part + 1) / E.nparts);
+    const int g_lo = (int)((int64_t)nchG * E.part / E.nparts), g_hi = (int)((int64_t)nchG * (E.part + 1) / E.nparts);
+    const int nW = w_hi - w_lo, nU = nW + (g_hi - g_lo);
+    double (*Xrw)[CHCP] = Xr[wave], (*Xiw)[CHCP] = Xi[wave];
+    // S and Q (pitch TRJ + 1 <= CHCP) in the staging planes of wavefronts 2 and 3
+    double (*Sr)[TRJ + 1] = reinterpret_cast<double (*)[TRJ + 1]>(&Xr[2][0][0]);
+    double (*Si)[TRJ + 1] = reinterpret_cast<double (*)[TRJ + 1]>(&Xi[2][0][0]);
+    double (*Qr)[TRJ + 1] = reinterpret_cast<double (*)[TRJ + 1]>(&Xr[3][0][0]);
+    double (*Qi)[TRJ + 1] = reinterpret_cast<double (*)[TRJ + 1]>(&Xi[3][0][0]);
+    // ---- load the chunks of this part (all in flight): lane (half, l31) holds rows t + half, t = 0, 2, .., 14, column l31
+    double2 reg[FITC][TRJ / 2];
+#pragma unroll
+    for (int it = 0; it < FITC; ++it) {
+        const int u = wave + it * (NTG / 64);
+        const bool isW = u < nW;
+        const double2 *M = isW ? (W + J.w_off) : (G + J.g_off);
+        const int len = isW ? L : R;
+        const int col = (isW ? (w_lo + u) : (g_lo + (u - nW))) * CHC + l31;
+        const bool ok = u < nU && col < len;
+#pragma unroll
+        for (int t = 0; t < TRJ; t += 2) {
+            const int tt = t + half;
+            const int row = ((tt < BRJ) ? row_i : row_j) + (tt % BRJ);
+            reg[it][t / 2] = (ok && row < R) ? M[(int64_t)row * len + col] : double2{0, 0};
+        }
+    }
+    // ---- partial Gram of the W chunks:  Re S = Xr Xr^T + Xi Xi^T ,  Im S = Xi Xr^T - Xr Xi^T
+    d4 ar0 = {0, 0, 0, 0}, ai0 = {0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < FITC; ++it) {
+        const int u = wave + it * (NTG / 64);
+        if (u < nW) {   // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < TRJ; t += 2) {
+                Xrw[t + half][l31] = reg[it][t / 2].x;
+                Xiw[t + half][l31] = reg[it][t / 2].y;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < CHC / 4; ++ks) {
+                const double xr = Xrw[l15][ks * 4 + l4], xi = Xiw[l15][ks * 4 + l4];
+                ar0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, ar0, 0, 0, 0);
+                ar0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, ar0, 0, 0, 0);
+                ai0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xr, ai0, 0, 0, 0);
+                ai0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xr, xi, ai0, 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Xrw[l4 + 4 * r][l15] = ar0[r];
+        Xiw[l4 + 4 * r][l15] = ai0[r];
+    }
+    if (tid == 0) any_flag = 0;
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x - E.part;
+    {
+        const int i = tid >> 4, j = tid & 15;
+        double sr = 0, si = 0;
+#pragma unroll
+        for (int w = 0; w < NTG / 64; ++w) {
+            sr += Xr[w][i][j];
+            si += Xi[w][i][j];
+        }
+        __hip_atomic_store(&gpart[(int64_t)blockIdx.x * 512 + tid], sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&gpart[(int64_t)blockIdx.x * 512 + 256 + tid], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (E.nparts > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores have reached the coherent level
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(&pair_cnt[first], 1u);
+            const unsigned int target = (unsigned int)E.nparts * seq;
+            unsigned int spins = 0;
+            while (__hip_atomic_load(&pair_cnt[first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > FUSED_SPIN_MAX) {
+                    atomicExch(err_flag, 1);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();       // (also: every wavefront is done with the partials in its staging planes)
+    {
+        double sr, si;
+        sum_coherent2(gpart + first * 512 + tid, 512, E.nparts, sr, si);
+        Sr[tid >> 4][tid & 15] = sr;
+        Si[tid >> 4][tid & 15] = si;
+        Qr[tid >> 4][tid & 15] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+        Qi[tid >> 4][tid & 15] = 0.0;
+    }
+    __syncthreads();
+    const double tol = 2.220446049250313e-16 * sqrt((double)L);
+    const double floor2 = rho * rho * fro2[E.job];
+    {
+        const int ei = tid >> 4, ej = tid & 15;
+        const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
+        const double g2 = Sr[ei][ej] * Sr[ei][ej] + Si[ei][ej] * Si[ei][ej];
+        if (relevant && svd_needs_rotation(Sr[ei][ei], Sr[ej][ej], g2, tol, floor2))
+            atomicOr(&any_flag, svd_big_rotation(Sr[ei][ei], Sr[ej][ej], g2, floor2) ? 3 : 1);
+    }
+    __syncthreads();
+    if (any_flag == 0) return;
+    if (tid == 0 && E.part == 0) {
+        atomicAdd(n_rot, 1u);
+        if (any_flag & 2) atomicAdd(n_rot + 1, 1u);
+    }
+    if (wave == 0) svd_local_solve_c(Sr, Si, Qr, Qi, csA, cprA, cpiA, partA, lane, local_sweeps, full_local, tol, floor2);
+    __syncthreads();
+    // ---- Q to registers BEFORE the staging planes (which hold it) are reused
+    double qar[4], qai[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qar[kk] = Qr[l15][kk * 4 + l4];
+        qai[kk] = Qi[l15][kk * 4 + l4];
+    }
+    __syncthreads();
+    // ---- apply X <- Q X (complex): Xr' = Qr Xr - Qi Xi ; Xi' = Qr Xi + Qi Xr
+#pragma unroll
+    for (int it = 0; it < FITC; ++it) {
+        const int u = wave + it * (NTG / 64);
+        if (u >= nU) continue;
+        const bool isW = u < nW;
+        double2 *M = isW ? (W + J.w_off) : (G + J.g_off);
+        const int len = isW ? L : R;
+        const int c0 = (isW ? (w_lo + u) : (g_lo + (u - nW))) * CHC;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < TRJ; t += 2) {
+            Xrw[t + half][l31] = reg[it][t / 2].x;
+            Xiw[t + half][l31] = reg[it][t / 2].y;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tile = 0; tile < CHC / 16; ++tile) {
+            d4 orr = {0, 0, 0, 0}, oii = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double br = Xrw[kk * 4 + l4][tile * 16 + l15], bim = Xiw[kk * 4 + l4][tile * 16 + l15];
+                orr = __builtin_amdgcn_mfma_f64_16x16x4f64(qar[kk], br, orr, 0, 0, 0);
+                orr = __builtin_amdgcn_mfma_f64_16x16x4f64(-qai[kk], bim, orr, 0, 0, 0);
+                oii = __builtin_amdgcn_mfma_f64_16x16x4f64(qar[kk], bim, oii, 0, 0, 0);
+                oii = __builtin_amdgcn_mfma_f64_16x16x4f64(qai[kk], br, oii, 0, 0, 0);
+            }
+            const int oc = c0 + tile * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = l4 + 4 * r;
+                const int row = ((t < BRJ) ? row_i : row_j) + (t % BRJ);
+                if (row < R && oc < len) M[(int64_t)row * len + oc] = double2{orr[r], oii[r]};
             }
         }
     }
@@ -2389,6 +2587,16 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
                     return w;
                 };
                 while (nparts < 8 && worst(nparts) > 8) ++nparts;
+            } else {                   // complex fused round: chunks of 32 columns, <= 4 * FITC register-resident chunks per part
+                const int64_t nW0 = (J.L + CHC - 1) / CHC, nG0 = (J.R + CHC - 1) / CHC;
+                auto worst = [&](int np) {
+                    int64_t w = 0;
+                    for (int q = 0; q < np; ++q) w = std::max(w, (nW0 * (q + 1) / np - nW0 * q / np) + (nG0 * (q + 1) / np - nG0 * q / np));
+                    return w;
+                };
+                nparts = (int)std::min<int64_t>(8, std::max<int64_t>(1, (nW0 + nG0 + 4 * FITC - 1) / (4 * FITC)));
+                while (nparts < 8 && worst(nparts) > 4 * FITC) ++nparts;
+                if (NBp >= 2) lay.max_part_chunks = std::max(lay.max_part_chunks, worst(nparts));
             }
             for (int64_t p = 0; p < NBp / 2; ++p)
                 for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
@@ -2456,6 +2664,20 @@ int64_t fused_round_capacity() {
     return cap;
 }
 
+int64_t fused_round_capacity_c() {
+    static int64_t cap = -1;
+    if (cap < 0) {
+        int per_cu = 0, dev_id = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev_id) != hipSuccess || hipGetDeviceProperties(&prop, dev_id) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, svd_round_fused_kernel_c, NTG, 0) != hipSuccess)
+            cap = 0;
+        else
+            cap = (int64_t)per_cu * prop.multiProcessorCount;
+    }
+    return cap;
+}
+
 template <bool CPLX>
 int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, double *s_dev,
             void *vh_base, char *work, int max_sweeps, int *sweeps_done, hipStream_t st, double rho) {
@@ -2499,16 +2721,22 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     const bool use_fused = use_block && !CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FIT &&
                            (int64_t)lay.bentries.size() <= fused_round_capacity();
     const bool use_wide = use_block && !CPLX && tpa_svd_fused_round && tpa_svd_wide_round && lay.wide_ok;
+    const bool use_fused_c = use_block && CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FITC &&
+                             (int64_t)lay.bentries.size() <= fused_round_capacity_c();
     unsigned int *pcnt = (unsigned int *)(work + lay.off_pcnt);
     int *perr = (int *)(pcnt + lay.bentries.size());
     unsigned int fused_seq = 0;
-    if (use_fused) TPA_HIP_CHECK(hipMemsetAsync(pcnt, 0, lay.bentries.size() * 4 + 4, st));
+    if (use_fused || use_fused_c) TPA_HIP_CHECK(hipMemsetAsync(pcnt, 0, lay.bentries.size() * 4 + 4, st));
     const int rounds = use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1) : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
             const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
-            if (use_block && CPLX) {
+            if (use_fused_c) {
+                ++fused_seq;
+                svd_round_fused_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, pcnt, fused_seq, cnt,
+                                                                                  fro2, rho, tpa_svd_local_sweeps, full_local, perr);
+            } else if (use_block && CPLX) {
                 svd_gram_part_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (const double2 *)W, gpart);
                 svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
             } else if (use_wide) {
@@ -2527,7 +2755,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         unsigned int h2[2] = {0, 0};
         int herr = 0;
         TPA_HIP_CHECK(hipMemcpyAsync(h2, cnt, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        if (use_fused && !use_wide) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
+        if ((use_fused && !use_wide) || use_fused_c) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
         TPA_HIP_CHECK(hipStreamSynchronize(st));
         if (herr) {
             snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: sibling workgroups of a fused Jacobi round lost each other (spin limit)");
