@@ -830,6 +830,8 @@ __global__ __launch_bounds__(NTW) void svd_round_wide_kernel(const SvdJob *__res
     }
 }
 
+#include "tpa_svd_b32.inc"
+
 // ---------------------------------------------------------------------------------------------------
 // Complex (Hermitian) version of the split block-Jacobi round.  Same structure; chunks are 32 complex columns
 // (512 B per row segment), re / im planes in LDS, 4 real MFMAs per complex product.
@@ -2527,6 +2529,7 @@ int tpa_svd_predict_convergence = 1;   // a sweep without "big" rotations (scale
 int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block pairs
                         // 32 x 32 solve dominates); kept as a tuning option, off by default
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
+int tpa_svd_b32 = 1;             // real data: 32-row blocks, three launches per round (tpa_svd_b32.inc); bit 12 of tpa_svd_set_algorithm switches it off
 
 struct Layout {
     std::vector<SvdJob> jobs;
@@ -2534,6 +2537,10 @@ struct Layout {
     std::vector<int2> pairs;  // (job,pair)
     std::vector<BEntry> bentries;  // (job, pair, part, nparts) for the split rounds
     std::vector<int2> wpairs;      // (job, block pair) for the one-workgroup-per-pair round
+    std::vector<B32Entry> b32_entries;   // (job, pair, part) of the 32-row-block rounds
+    std::vector<B32Pair> b32_pairs;
+    int64_t nb32_max_pad = 0;
+    int64_t off_b32e = 0, off_b32p = 0, off_b32g = 0, off_b32q = 0, off_b32f = 0;
     bool wide_ok = true;           // every job has <= FIT * NTW / 64 column chunks of [W | G]
     int64_t nb_max_pad = 0;
     int64_t max_part_chunks = 0;   // largest number of (W + G) column chunks of one part (fused round: <= 4 * FIT)
@@ -2601,6 +2608,17 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
             for (int64_t p = 0; p < NBp / 2; ++p)
                 for (int q = 0; q < nparts; ++q) lay.bentries.push_back(BEntry{b, (int)p, q, nparts});
             for (int64_t p = 0; p < NBp / 2; ++p) lay.wpairs.push_back(int2{b, (int)p});
+            {   // 32-row blocks
+                const int64_t NB32 = (J.R + BB - 1) / BB, NB32p = (NB32 + 1) / 2 * 2;
+                const int64_t nW32 = (J.L + CB - 1) / CB, nG32 = (J.R + CB - 1) / CB;
+                const int np32 = (int)std::min<int64_t>(B32_MAX_PARTS, std::max<int64_t>(1, (nW32 + nG32 + 3) / 4));
+                for (int64_t p = 0; p < NB32p / 2; ++p) {
+                    const int pairidx = (int)lay.b32_pairs.size();
+                    lay.b32_pairs.push_back(B32Pair{b, (int)p, (int)lay.b32_entries.size(), np32});
+                    for (int q = 0; q < np32; ++q) lay.b32_entries.push_back(B32Entry{b, (int)p, q, np32, pairidx, 0, 0, 0});
+                }
+                lay.nb32_max_pad = std::max(lay.nb32_max_pad, NB32p);
+            }
             if (nch_all > FIT * (NTW / 64)) lay.wide_ok = false;
             if (dtype != TPA_C128 && NBp >= 2) {
                 const int64_t nchG = (J.R + 63) / 64;
@@ -2645,6 +2663,18 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.jobs.size() * 8, 256);
     lay.off_fpart = o;
     o = align_up(o + (int64_t)lay.jobs.size() * 64 * 8, 256);
+    lay.off_b32e = o;
+    o = align_up(o + (int64_t)lay.b32_entries.size() * sizeof(B32Entry), 256);
+    lay.off_b32p = o;
+    o = align_up(o + (int64_t)lay.b32_pairs.size() * sizeof(B32Pair), 256);
+    lay.off_b32f = o;
+    o = align_up(o + (int64_t)lay.b32_pairs.size() * 4, 256);
+    if (dtype != TPA_C128) {
+        lay.off_b32g = o;
+        o = align_up(o + (int64_t)lay.b32_entries.size() * GSZ * 8, 256);
+        lay.off_b32q = o;
+        o = align_up(o + (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
+    }
     lay.total = o;
     return lay;
 }
@@ -2721,18 +2751,32 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     const bool use_fused = use_block && !CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FIT &&
                            (int64_t)lay.bentries.size() <= fused_round_capacity();
     const bool use_wide = use_block && !CPLX && tpa_svd_fused_round && tpa_svd_wide_round && lay.wide_ok;
+    const bool use_b32 = use_block && !CPLX && tpa_svd_b32 && !lay.b32_pairs.empty();
+    B32Entry *b32e = (B32Entry *)(work + lay.off_b32e);
+    B32Pair *b32p = (B32Pair *)(work + lay.off_b32p);
+    int *b32f = (int *)(work + lay.off_b32f);
+    double *b32g = (double *)(work + lay.off_b32g), *b32q = (double *)(work + lay.off_b32q);
+    if (use_b32) {
+        TPA_HIP_CHECK(hipMemcpyAsync(b32e, lay.b32_entries.data(), lay.b32_entries.size() * sizeof(B32Entry), hipMemcpyHostToDevice, st));
+        TPA_HIP_CHECK(hipMemcpyAsync(b32p, lay.b32_pairs.data(), lay.b32_pairs.size() * sizeof(B32Pair), hipMemcpyHostToDevice, st));
+    }
     const bool use_fused_c = use_block && CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FITC &&
                              (int64_t)lay.bentries.size() <= fused_round_capacity_c();
     unsigned int *pcnt = (unsigned int *)(work + lay.off_pcnt);
     int *perr = (int *)(pcnt + lay.bentries.size());
     unsigned int fused_seq = 0;
     if (use_fused || use_fused_c) TPA_HIP_CHECK(hipMemsetAsync(pcnt, 0, lay.bentries.size() * 4 + 4, st));
-    const int rounds = use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1) : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
+    const int rounds = use_b32 ? (int)std::max<int64_t>(lay.nb32_max_pad - 1, 1)
+                               : use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1) : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
             const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
-            if (use_fused_c) {
+            if (use_b32) {
+                svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, b32g);
+                svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local);
+                svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, G, b32q, b32f);
+            } else if (use_fused_c) {
                 ++fused_seq;
                 svd_round_fused_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, pcnt, fused_seq, cnt,
                                                                                   fro2, rho, tpa_svd_local_sweeps, full_local, perr);
@@ -2755,7 +2799,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         unsigned int h2[2] = {0, 0};
         int herr = 0;
         TPA_HIP_CHECK(hipMemcpyAsync(h2, cnt, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        if ((use_fused && !use_wide) || use_fused_c) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (!use_b32 && ((use_fused && !use_wide) || use_fused_c)) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
         TPA_HIP_CHECK(hipStreamSynchronize(st));
         if (herr) {
             snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: sibling workgroups of a fused Jacobi round lost each other (spin limit)");
@@ -3331,6 +3375,7 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_use_qrp = (pairwise & 512) ? 0 : 1;    // bit 9: no pivoted-QR preconditioner
     tpa_svd_fused_round = (pairwise & 2) ? 0 : 1;  // bit 1: two-kernel rounds (gram, then solve + apply)
     tpa_svd_wide_round = (pairwise & 2048) ? 0 : 1;   // bit 11: no one-workgroup-per-pair round (-> fused round with column parts)
+    tpa_svd_b32 = ((pairwise & 4096) || (pairwise & 2)) ? 0 : 1;   // bit 12 (or the two-kernel 8-row rounds of bit 1): no 32-row-block rounds
     tpa_svd_predict_convergence = (pairwise & 1024) ? 0 : 1;   // bit 10: always run the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
