@@ -93,7 +93,7 @@ def parity_and_port(eng, args, gpu_bond_s):
     L = eng.psi.L
     n_b = max(1, args.cpu_sample_bonds)
     bonds = [L // 2 - 1 + i for i in range(n_b)]
-    t_cpu, mv_err, sv_err, e0_err = 0., [], [], []
+    t_cpu, mv_err, sv_err, e0_err, sv_ind, iso = 0., [], [], [], [], []
     for i0 in bonds:
         eff = TwoSiteH(eng.env, i0, factored=False)       # the fused form LHeff . theta . RHeff that the oracle restates
         theta = eff.combine_theta(eng.psi.get_theta(i0, n=2))
@@ -120,6 +120,13 @@ def parity_and_port(eng, args, gpu_bond_s):
         a, b = np.sort(np.asarray(S_dev))[::-1], np.sort(np.asarray(S_orc))[::-1]
         n = min(len(a), len(b))
         sv_err.append(float(np.max(np.abs(a[:n] - b[:n])) / b[0]))
+        big = b[:n] > 1.e-8 * b[0]
+        sv_ind.append(float(np.max(np.abs(a[:n][big] - b[:n][big]) / b[:n][big])))
+        # isometry defect over all kept vectors (sigma > 1e-14 sigma_max, what svd_min = 1e-14 keeps)
+        Ud, Vd = U.to_ndarray(), VH.to_ndarray()
+        kept = np.asarray(S_dev) > 1.e-14 * np.max(S_dev)
+        iso.append(float(max(np.max(np.abs(Ud[:, kept].conj().T @ Ud[:, kept] - np.eye(int(kept.sum())))),
+                             np.max(np.abs(Vd[kept] @ Vd[kept].conj().T - np.eye(int(kept.sum())))))))
         e0_err.append(abs(E_dev - E_orc) / abs(E_orc))
     per_bond = t_cpu / n_b
     n_bonds = 2 * (L - 2)
@@ -127,10 +134,43 @@ def parity_and_port(eng, args, gpu_bond_s):
             "sample": "%d centre bond updates (%d-step Lanczos + block SVD each) with the numpy oracle on the same state, "
                       "%.2f s CPU per bond, extrapolated x%d bonds; GPU same bonds %.4f s per bond"
                       % (n_b, args.lanczos_N, per_bond, n_bonds, gpu_bond_s)}
-    parity = {"sv_max_rel_err": max(sv_err), "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err),
-              "parity_sample": "centre bonds %r of the timed state: device block SVD vs LAPACK (oracle), factored device matvec "
+    parity = {"sv_max_rel_err": max(sv_err), "sv_max_rel_err_individual": max(sv_ind), "svd_isometry_defect": max(iso),
+              "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err),
+              "parity_sample": "centre bonds %r of the timed state: device block SVD vs LAPACK (oracle; sv_max_rel_err = max |dS| / S_max, "
+                               "..._individual = max |dS_i| / S_i over S_i > 1e-8 S_max, svd_isometry_defect = max(|U^H U - 1|, |VH VH^H - 1|) "
+                               "over the vectors with S > 1e-14 S_max), factored device matvec "
                                "vs oracle LHeff.theta.RHeff, %d-step Lanczos energy vs the oracle's Lanczos" % (bonds, args.lanczos_N)}
     return port, parity
+
+
+def reference_same_run(n_bonds=2, timeout=600):
+    """TeNPy ITSELF (the reference, compiled helper) timed in THIS run on this host's cores: centre-bond updates at chi = 2048
+    (scripts/cpu_reference_baseline.py bond2048: TwoSiteH + 8-step Lanczos + svd_theta + update_LP on operands with the block
+    structure of the real state), x196 bonds.  The reference comes from /root/reference or, on the GPU box, from the archive
+    oracle/_ref/tenpy_ref.zip (oracle/build_ref.py).  None if it is not available.  Bounded: ~2 bonds x ~4 s x cores-dependent."""
+    import subprocess
+    import tempfile
+    try:
+        from oracle import build_ref
+        if build_ref.reference_root() is None or not os.path.exists(build_ref.SO):
+            return None
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, 'cpu_ref.json')
+            env = dict(os.environ, TPA_CPU_REF_OUT=out, N_BONDS=str(n_bonds))
+            subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'cpu_reference_baseline.py'), 'bond2048'], env=env,
+                           capture_output=True, text=True, timeout=timeout, check=True)
+            with open(out) as f:
+                r = json.load(f)
+        b, envi = r['bond2048'], r['environment']
+        return {"value": b['s_per_sweep_extrapolated'], "unit": "s/sweep", "cores": envi.get('cores'), "kind": "reference",
+                "where": "same run: host cores of the GPU box (%s cores, %s BLAS threads)" % (envi.get('cores'), envi.get('blas_threads')),
+                "sample": "TeNPy %s with its compiled _npc_helper: best of %d centre-bond updates at chi=2048 (%.2f s each: Lanczos "
+                          "%.2f, svd_theta %.2f, H_eff %.2f, env %.2f) x 196 bonds" % (
+                              envi.get('tenpy'), n_bonds, b['s_per_bond_best'], b['best']['lanczos'], b['best']['svd'],
+                              b['best']['heff'], b['best']['env'])}
+    except Exception as e:      # the baseline must never kill the bench line
+        sys.stderr.write("reference_same_run failed: %r\n" % (e,))
+        return None
 
 
 def reference_entry(config_name, chi):
@@ -164,17 +204,29 @@ def build_dmrg(args, world, name):
                                      'profile': bool(os.environ.get('TPA_BENCH_PHASES'))})
     # ---- untimed: grow the state (two quick sweeps at small chi, then double chi per sweep)
     energies = []
+    eng.ramp_log = []       # (chi_max, seconds, Jacobi sweeps per SVD call) of every untimed sweep: the non-steady-state regime
+
+    def timed_sweep(tag):
+        import torch
+        from tenpy_amd.linalg import np_conserved as npc
+        c0, s0 = npc.svd_stats['calls'], npc.svd_stats['sweeps']
+        torch.cuda.synchronize()
+        t0 = time.time()
+        eng.sweep()
+        torch.cuda.synchronize()
+        eng.ramp_log.append({"chi_max": int(eng.trunc_params['chi_max']), "s": round(time.time() - t0, 3), "kind": tag,
+                             "jacobi_sweeps_per_call": round((npc.svd_stats['sweeps'] - s0) / max(npc.svd_stats['calls'] - c0, 1), 2)})
+        energies.append(eng.sweep_stats['E'][-1])
+    eng.timed_sweep = timed_sweep
     c = min(64, chi)
     for _ in range(2):
-        eng.sweep()
-        energies.append(eng.sweep_stats['E'][-1])
+        timed_sweep('ramp, Lanczos N<=20')
     while c < chi:
         c = min(2 * c, chi)
         eng.trunc_params['chi_max'] = c
         if c == chi:
             break
-        eng.sweep()
-        energies.append(eng.sweep_stats['E'][-1])
+        timed_sweep('ramp, Lanczos N<=20')
     eng.lanczos_params = {'N_min': args.lanczos_N, 'N_max': args.lanczos_N}
     return eng, energies
 
@@ -267,10 +319,14 @@ def main():
         eng, ramp_E = build_dmrg(args, world, args.config)
         step = eng.sweep
     sweep_E = list(ramp_E)
+    n_ramp = len(ramp_E)
     for _ in range(args.warmup):
-        step()
-        if not is_tebd:
-            sweep_E.append(eng.sweep_stats['E'][-1])
+        if is_tebd:
+            step()
+        else:
+            eng.timed_sweep('warm-up at the target chi, Lanczos N=%d' % args.lanczos_N)
+    if not is_tebd:
+        sweep_E = list(ramp_E)      # timed_sweep appends to the same list
     torch.cuda.synchronize()
     t_prep = time.time() - t_prep
 
@@ -281,6 +337,8 @@ def main():
         tm.reset()
         tm.enabled = True
     n0 = 0 if is_tebd else len(eng.update_stats['E_total'])
+    from tenpy_amd.linalg import _svd_warm as _sw
+    svd_calls0, svd_sweeps0, warm0 = npc.svd_stats['calls'], npc.svd_stats['sweeps'], dict(_sw.stats)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -352,6 +410,7 @@ def main():
             out["E"] = eng.sweep_stats['E'][-1]
             out["chi_reached"] = eng.sweep_stats['max_chi'][-1]
             out["E_sweeps"] = sweep_E
+            out["untimed_sweeps"] = eng.ramp_log
             ref, ref_all = reference_entry(args.config, chi)
             if ref is not None and L == (80 if args.config == 'hubbard1024' else 100) and args.lanczos_N == 8:
                 # the reference ran the same protocol; its sweep list starts with the same ramp
@@ -360,12 +419,19 @@ def main():
                 out["energy_err"] = abs(sweep_E[idx] - ref_E[idx]) / abs(ref_E[idx])
                 out["energy_err_note"] = ("|E - E_ref| / |E_ref| after sweep %d of the common protocol (ramp + %d sweeps at chi=%d); "
                                           "E_ref = %.13f from TeNPy (compiled helper) run offline, profiles/r02_cpu_reference.json"
-                                          % (idx + 1, idx + 1 - len(ramp_E), chi, ref_E[idx]))
+                                          % (idx + 1, idx + 1 - n_ramp, chi, ref_E[idx]))
             else:
                 out["energy_err_note"] = "no offline TeNPy run of this configuration in profiles/r02_cpu_reference.json"
             if os.environ.get('TPA_BENCH_PHASES'):   # diagnostic run only: the phase timers synchronise the device
                 out["phases_s"] = {k: round(v / max(args.steps, 1), 4) for k, v in eng.phase_time.items()}
-                out["svd_stats"] = dict(npc.svd_stats)
+            from tenpy_amd.linalg import _svd_warm
+            n_svd = max(npc.svd_stats['calls'] - svd_calls0, 1)
+            out["svd_stats"] = {"calls_timed": n_svd, "jacobi_sweeps_per_call": (npc.svd_stats['sweeps'] - svd_sweeps0) / n_svd,
+                                "max_block": npc.svd_stats['max_block'], "abs_floor": npc.SVD_ABS_FLOOR,
+                                "warm": {k: (v - warm0.get(k, 0)) for k, v in _svd_warm.stats.items() if not k.startswith('e_rel')},
+                                "note": "warm = calls started from the singular vectors this bond produced on its previous visit "
+                                        "(no pivoted QR; linalg/_svd_warm.py); the rest took the cold path; sweep counts include the "
+                                        "low-rank residual decompositions of warm calls"}
             if world == 1:
                 upd_t = eng.update_stats['time'][n0:]
                 mid = [t for i, t in zip(eng.update_stats['i0'][n0:], upd_t) if abs(i - L // 2) <= 1]
@@ -385,6 +451,12 @@ def main():
                                 "sample": "TeNPy %s, compiled helper: %.2f s per centre-bond update at chi=2048 (operands with the "
                                           "block structure of the real state) x 196 (%s)"
                                           % (envi.get('tenpy'), b['s_per_bond_best'], os.path.basename(CPU_REF))}
+                if not args.no_cpu_baseline and args.config == 'heis2048' and chi == 2048:
+                    live = reference_same_run()
+                    if live is not None:
+                        if base is not None:
+                            live["offline_full_sweep"] = {k: base[k] for k in ("value", "unit", "cores", "where", "sample")}
+                        base = live
                 if not args.no_cpu_baseline:
                     try:
                         port, parity = parity_and_port(eng, args, gpu_bond_s)

@@ -28,6 +28,7 @@ extern "C" {
 #define TPA_E_NOCONV (-2)      /* -> numpy.linalg.LinAlgError (Jacobi sweeps exhausted)  */
 #define TPA_E_NAN (-3)         /* -> ValueError("NaN ...") like np_conserved.py:4978-4982 */
 #define TPA_E_NOMEM (-4)
+#define TPA_E_RANKCAP (-5)     /* tpa_svd_batch with a rank cap: a block is not of low rank (caller falls back) */
 
 /* ---- library / device --------------------------------------------------------------- */
 int tpa_version(void);
@@ -133,7 +134,9 @@ int tpa_gemm_set_variant(int v);
 
 /* ---- K5: batched block SVD, one-sided (Hestenes) Jacobi -- replaces svd_flat / LAPACK gesdd
  *      per charge block (np_conserved.py:4970-4980 via svd_robust.py:36-75) ---------------
- * jobs : int64[n_jobs][8] = {a_off, m, n, u_off, s_off, vh_off, flags, 0}  (HOST pointer)
+ * jobs : int64[n_jobs][8] = {a_off, m, n, u_off, s_off, vh_off, flags, norm2_bits}  (HOST pointer)
+ *   norm2_bits: 0, or the IEEE-754 bit pattern of a double that replaces |A_b|_F^2 as the scale of the numerical-rank
+ *   decision and of the absolute floor (used for residual blocks E = A - P whose own norm is far below that of A).
  *   flags bit 0 (square blocks only): orthogonalise the rows of A instead of its columns (default 0).
  *   A_b is m x n row-major at a_off in a_base; on return
  *   U_b (m x k, row-major, k=min(m,n)) at u_off in u_base, S_b (k, descending) at s_off in s_dev
@@ -158,6 +161,10 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
  * to 1.4e-15 sigma_max, same orthogonality, one to two sweeps fewer): a sweep in which no rotated pair had a scaled cosine
  * above 1e-7 ends the iteration without the verification sweep (quadratic convergence leaves cosines <= 1e-14). */
 int tpa_svd_set_algorithm(int pairwise);
+/* Rank cap of the pivoted-QR stage (0 = none, default): with cap > 0 tpa_svd_batch returns TPA_E_RANKCAP as soon as some
+ * block turns out to have numerical rank above ~cap (checked every 64 columns).  Used by the warm-started SVD for the residual
+ * blocks E = A - P, which are decomposed only if they are of low rank (tenpy_amd/linalg/_svd_warm.py). */
+int tpa_svd_set_rank_cap(int cap);
 
 /* ---- K6: batched Householder QR (np.linalg.qr per block, np_conserved.py:4190) ----------
  * jobs : int64[n_jobs][8] = {a_off, m, n, q_off, r_off, 0,0,0} (HOST); reduced mode:

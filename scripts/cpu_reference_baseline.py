@@ -42,7 +42,7 @@ from tenpy.tools import optimization  # noqa: E402
 
 assert optimization.have_cython_functions, "compiled _npc_helper not active"
 optimization.set_level(3)
-OUT = os.path.join(ROOT, 'profiles', 'r02_cpu_reference.json')
+OUT = os.environ.get('TPA_CPU_REF_OUT') or os.path.join(ROOT, 'profiles', 'r02_cpu_reference.json')
 
 
 def env_info():

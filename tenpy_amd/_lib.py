@@ -13,7 +13,7 @@ import numpy as np
 from . import _build
 
 F64, C128 = 0, 1
-E_BADARG, E_NOCONV, E_NAN, E_NOMEM = -1, -2, -3, -4
+E_BADARG, E_NOCONV, E_NAN, E_NOMEM, E_RANKCAP = -1, -2, -3, -4, -5
 
 _lib = None
 
@@ -44,6 +44,7 @@ _SIGS = {
     "tpa_svd_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp]),
     "tpa_svd_set_algorithm": (ctypes.c_int, [ctypes.c_int]),
+    "tpa_svd_set_rank_cap": (ctypes.c_int, [ctypes.c_int]),
     "tpa_qr_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "tpa_qr_set_algorithm": (ctypes.c_int, [ctypes.c_int]),
     "tpa_eigh_worksize": (ctypes.c_int64, [ctypes.c_int, _vp, ctypes.c_int]),
@@ -74,12 +75,15 @@ def load(build_if_missing=True):
         # no-op unless a source under csrc/ is newer than its object: a stale .so is never loaded silently.  One process
         # at a time (N ranks of a torchrun launch all come through here).
         import fcntl
-        with open(os.path.join(_build.OUT_DIR, '.build.lock'), 'w') as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)
-            try:
-                _build.build()
-            finally:
-                fcntl.flock(lock, fcntl.LOCK_UN)
+        try:
+            with open(os.path.join(_build.OUT_DIR, '.build.lock'), 'w') as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    _build.build()
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
+        except OSError:
+            pass        # read-only install (site-packages, container image): load the library that is there
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGS.items():
         f = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure

@@ -116,11 +116,15 @@ class TwoSiteDMRGEngine:
         self._tick('lanczos')
         previous = npc.SVD_DIST_GROUP
         npc.SVD_DIST_GROUP = self._svd_group                  # scoped to this call (other SVDs in the process stay local)
+        # warm start of the block SVD: the right (left) singular vectors this bond produced on the previous visit span
+        # theta_0 = M . B_{i0+1} (A_{i0} . M) of this one (linalg/_svd_warm.py); consumed by the next npc.svd call
+        npc.svd_hint = ((id(self), i0), 'R' if move_right else 'L')
         try:
             U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[psi.get_B(i0, None).qtotal, None],
                                          inner_labels=['vR', 'vL'])
         finally:
             npc.SVD_DIST_GROUP = previous
+            npc.svd_hint = None
         self._tick('svd')
         i1 = i0 + 1
         if move_right:

@@ -29,6 +29,7 @@ constexpr int NT = 256;  // 4 wavefronts = 4 row pairs per workgroup
 struct SvdJob {  // int64[13], device copy
     int64_t w_off, g_off, R, L, Rpad, a_off, m, n, u_off, s_off, vh_off, sig_off;
     int64_t tr;   // 1: W = A^T (rows of W = columns of A), 0: W = A.  m == n: host flag bit 0 of jobs[6] selects W = A
+    int64_t fro_bits;   // jobs[7]: IEEE-754 bits of a squared norm that replaces |A|_F^2 in the rank / floor decisions (0: none)
 };
 
 template <bool CPLX>
@@ -74,10 +75,12 @@ __global__ __launch_bounds__(NT) void svd_fro_kernel(const SvdJob *__restrict__ 
     s = block_sum<NT>(s, red);
     if (threadIdx.x == 0) fpart[blockIdx.y * FRO_PARTS + blockIdx.x] = s;
 }
-__global__ __launch_bounds__(64) void svd_fro_sum_kernel(const double *__restrict__ fpart, double *__restrict__ fro2) {
+__global__ __launch_bounds__(64) void svd_fro_sum_kernel(const SvdJob *__restrict__ jobs, const double *__restrict__ fpart,
+                                                         double *__restrict__ fro2) {
     double s = fpart[blockIdx.x * FRO_PARTS + threadIdx.x];
     s = wave_sum(s);
-    if (threadIdx.x == 0) fro2[blockIdx.x] = s;
+    const int64_t ov = jobs[blockIdx.x].fro_bits;     // a NaN / Inf in the input still shows in s
+    if (threadIdx.x == 0) fro2[blockIdx.x] = (ov != 0 && s == s && s < 1.0e300) ? __longlong_as_double(ov) : s;
 }
 
 // Stopping rule for a row pair with alpha=|x|^2 >= beta=|y|^2 (either order), gamma = x.conj(y):
@@ -2529,6 +2532,7 @@ int tpa_svd_predict_convergence = 1;   // a sweep without "big" rotations (scale
 int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block pairs
                         // 32 x 32 solve dominates); kept as a tuning option, off by default
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
+int tpa_svd_rank_cap = 0;        // > 0: the pivoted QR gives up (TPA_E_RANKCAP) once a block needs more than this many columns
 int tpa_svd_b32 = 1;             // real data: 32-row blocks, three launches per round (tpa_svd_b32.inc); bit 12 of tpa_svd_set_algorithm switches it off
 
 struct Layout {
@@ -2565,6 +2569,7 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         J.s_off = j[4];
         J.vh_off = j[5];
         J.tr = (J.m > J.n || (J.m == J.n && !(j[6] & 1))) ? 1 : 0;
+        J.fro_bits = j[7];
         J.R = std::min(J.m, J.n);
         J.L = std::max(J.m, J.n);
         J.Rpad = (J.R + 1) / 2 * 2;
@@ -2739,7 +2744,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     double *fro2 = (double *)(work + lay.off_fro);
     double *fpart = (double *)(work + lay.off_fpart);
     svd_fro_kernel<CPLX><<<dim3(FRO_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)a_base, fpart);
-    svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(fpart, fro2);
+    svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(jobs, fpart, fro2);
     TPA_LAUNCH_CHECK();
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
@@ -2925,7 +2930,7 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     TPA_HIP_CHECK(hipMemcpyAsync(qjobs, q.qjobs.data(), q.qjobs.size() * sizeof(QrpJob), hipMemcpyHostToDevice, st));
     TPA_HIP_CHECK(hipMemcpyAsync(sjobs, lay.jobs.data(), lay.jobs.size() * sizeof(SvdJob), hipMemcpyHostToDevice, st));
     svd_fro_kernel<CPLX><<<dim3(FRO_PARTS, n_jobs), NT, 0, st>>>(sjobs, (const double *)a_base, fpart);
-    svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(fpart, fro2);
+    svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(sjobs, fpart, fro2);
     { const char *e = getenv("TPA_SVD_SMALL_PANEL"); if (e) tpa_svd_small_panel = atoi(e); }
     const int nmax = (int)q.n_max;
     if (CPLX)
@@ -2964,6 +2969,10 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
             bool all = true;
             for (const QrpState &s : hstate) all = all && s.done;
             if (all) break;
+            if (tpa_svd_rank_cap > 0 && k + PNB >= tpa_svd_rank_cap) {
+                snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: numerical rank above the cap %d", tpa_svd_rank_cap);
+                return TPA_E_RANKCAP;
+            }
         }
     }
     TPA_LAUNCH_CHECK();
@@ -2995,7 +3004,7 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
         }
         rmax = std::max(rmax, r);
         if (r == 0) continue;
-        const int64_t nj[8] = {J.r_off, r, J.N, J.r_off, J.c_off, J.r_off, 1, 0};   // flag 1: orthogonalise the ROWS of R
+        const int64_t nj[8] = {J.r_off, r, J.N, J.r_off, J.c_off, J.r_off, 1, lay.jobs[b].fro_bits};   // flag 1: orthogonalise the ROWS of R
         nested.insert(nested.end(), nj, nj + 8);
         ++nn;
     }
@@ -3366,6 +3375,11 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
     }
     TPA_LAUNCH_CHECK();
     TPA_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int tpa_svd_set_rank_cap(int cap) {
+    tpa_svd_rank_cap = cap > 0 ? cap : 0;
     return 0;
 }
 

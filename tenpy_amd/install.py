@@ -15,9 +15,10 @@ never consulted (``have_cython_functions`` is set to ``False``, the state the re
 ``TENPY_NO_CYTHON=1``, optimization.py:322).  The fine-grained form of the boundary -- the 16 ``use_cython`` names for
 a TeNPy that keeps its own ``np_conserved`` -- is ``tenpy_amd/_npc_helper.py``.
 
-``install(fused=True)`` additionally rebinds, after ``import tenpy``, the two callers for which the device has a
-fused form: ``LanczosGroundState`` (one fused recurrence kernel per step instead of four BLAS-1 calls) and
-``TwoSiteH`` (factored matvec LP . theta . W0 W1 . RP); see :func:`use_fused_callers`.
+``install(fused=True)`` additionally rebinds, after ``import tenpy``, the callers for which the device has a
+fused form: ``LanczosGroundState`` (one fused recurrence kernel per step instead of four BLAS-1 calls), ``TwoSiteH``
+(cached plans; factored matvec LP . theta . W0 W1 . RP for ``combine=False``) and the bond hint of the warm-started block
+SVD; see :func:`use_fused_callers`.
 """
 import importlib
 import importlib.abc
@@ -91,10 +92,27 @@ def uninstall():
 
 
 def use_fused_callers():
-    """Optional, after the hook: rebind ``LanczosGroundState`` in the reference's modules to the fused device
-    recurrence (``tenpy_amd/linalg/krylov_based.py``; same options, same results, one kernel per step)."""
+    """Optional, after the hook: rebind, in the reference's modules, the callers for which the device has a fused form.
+    The engines themselves (``algorithms/dmrg.py``, ``mps_common.py`` sweeps, mixers, ``tebd.py``) remain the reference's code.
+
+    * ``LanczosGroundState`` (``linalg/krylov_based.py:645``; constructed at ``dmrg.py:740/742``) -> the fused device recurrence
+      of ``tenpy_amd/linalg/krylov_based.py`` (same options, same results, one kernel per Krylov step);
+    * ``TwoSiteH`` (``algorithms/mps_common.py:1245``; ``TwoSiteDMRGEngine.EffectiveH``, ``dmrg.py:865``) -> the device form of
+      ``tenpy_amd/algorithms/module_form.py`` (cached plans, fused ``LHeff`` build; ``combine=False``: factored matvec), which
+      hands bonds it does not cover back to the reference's class;
+    * ``TwoSiteDMRGEngine.mixed_svd`` (``dmrg.py:876``) is wrapped to pass the bond index to the block SVD (warm start).
+    """
     import tenpy.algorithms.dmrg as ref_dmrg
+    import tenpy.algorithms.mps_common as ref_mc
     import tenpy.linalg.krylov_based as ref_kb
+    from .algorithms import module_form
     from .linalg import krylov_based as kb
     ref_kb.LanczosGroundState = kb.LanczosGroundState
     ref_dmrg.LanczosGroundState = kb.LanczosGroundState
+    if not hasattr(ref_mc.TwoSiteH, '_reference_class'):
+        dev_cls = module_form.device_two_site_h(ref_mc.TwoSiteH)
+        ref_mc.TwoSiteH = dev_cls
+        ref_dmrg.TwoSiteH = dev_cls
+        ref_dmrg.TwoSiteDMRGEngine.EffectiveH = dev_cls
+    if not getattr(ref_dmrg.TwoSiteDMRGEngine.mixed_svd, '_tpa_wrapped', False):
+        ref_dmrg.TwoSiteDMRGEngine.mixed_svd = module_form.hinted_mixed_svd(ref_dmrg.TwoSiteDMRGEngine.mixed_svd)

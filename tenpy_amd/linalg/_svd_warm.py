@@ -1,0 +1,327 @@
+"""Warm-started block SVD and isometry clean-up: host orchestration over the C-ABI (GEMM chain, block Jacobi, copies).
+
+Why.  The block SVD of a two-site wave function (reference ``svd_theta``, linalg/truncation.py:258 -> ``npc.svd``,
+np_conserved.py:3676) is a chain of dependent Jacobi rounds: 4.9 ms of pivoted QR + 6-7 sweeps on the
+chi = 2048 theta.  A DMRG sweep hands the SVD an excellent basis for free: in a right-moving sweep theta_0 = M . B_{i+1}
+where the rows of B_{i+1} are the right singular vectors this very bond produced on the way back, and theta_opt ~ theta_0
+near convergence (left-moving: the columns of A_i).  With such a basis ``Bq`` (k x len, orthonormal rows)
+
+    X  = theta (side 'R') or theta^T (side 'L')          (p x len)
+    W  = Bq X^H                                           (k x p)    rows nearly orthogonal, graded like the old S
+    E  = X - W^H Bq                                       what the basis misses; usually ~ eps |X|
+
+the one-sided Jacobi runs directly on the rows of W: no rank-revealing QR, and the iteration starts in its quadratic phase
+for the large singular values.  If E is not negligible a (cheap: low-rank) cold SVD of E supplies the missing directions,
+re-orthogonalised against ``Bq`` ("twice is enough") and appended.  The iteration still runs to the same stopping rule, so
+the result is as exact as the cold path: X = VH'^H S (U'^H Bc) with W = U' S VH'.
+
+The same file holds the first-order Loewdin clean-up ``lowdin_rows`` (V <- (3 I - V V^H) V / 2) that restores machine
+precision orthonormality of (i) the singular vectors below the absolute floor of the stopping rule, whose mutual angles are
+only converged absolutely (np_conserved.SVD_ABS_FLOOR), and (ii) the accumulated basis U'^H Bc of repeated warm starts.
+All arithmetic runs in the hand-written kernels (``tpa_gemm_chain``, ``tpa_svd_batch``, ``tpa_copy_batch``, ``tpa_axpy``).
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _device as dev
+
+COPY_MAXDIM = 6
+_tables = OrderedDict()
+_TABLES_MAX = 8192
+stats = {'warm_calls': 0, 'cold_calls': 0, 'e_handled': 0, 'fallbacks': 0, 'warm_sweeps': 0, 'cold_sweeps': 0,
+         'fb_shape': 0, 'fb_rank': 0, 'fb_svd': 0, 'fb_nomatch': 0, 'fb_stale': 0, 'mixed_calls': 0, 'e_rank_sum': 0, 'e_rel_max': 0.}
+
+
+def _gemm_tile(dtype):
+    from . import np_conserved as npc
+    return npc._gemm_tile(np.dtype(dtype), 1)
+
+
+def raw_gemm(dtype, spec, A_arena, B_arena, C_arena):
+    """Batched ``C_t = A_t B_t`` on raw arenas.  ``spec``: int64 ``[n, 12]`` rows
+    ``(c_off, m, n, ldc, a_off, a_rs, a_ks, b_off, b_ks, b_ns, k, flags)`` with ``A_t(i, l) = A[a_off + i a_rs + l a_ks]``,
+    ``B_t(l, j) = B[b_off + l b_ks + j b_ns]`` (flags bit 0 / 1: conjugate A / B).  Tables are cached by content."""
+    spec = np.ascontiguousarray(spec, dtype=np.int64)
+    spec = spec[(spec[:, 1] > 0) & (spec[:, 2] > 0)]
+    if len(spec) == 0:
+        return
+    dtype = np.dtype(dtype)
+    key = (dtype.str, spec.tobytes())
+    tab = _tables.get(key)
+    if tab is None:
+        n = len(spec)
+        tasks = np.zeros((n, 8), dtype=np.int64)
+        tasks[:, 0], tasks[:, 1], tasks[:, 2], tasks[:, 3] = spec[:, 0], spec[:, 1], spec[:, 2], spec[:, 3]
+        tasks[:, 4], tasks[:, 5] = np.arange(n), 1
+        links = np.zeros((n, 8), dtype=np.int64)
+        links[:, 0], links[:, 1], links[:, 2] = spec[:, 4], spec[:, 7], spec[:, 10]
+        links[:, 3], links[:, 4], links[:, 5], links[:, 6], links[:, 7] = spec[:, 5], spec[:, 6], spec[:, 8], spec[:, 9], spec[:, 11]
+        bm, bn = _gemm_tile(dtype)
+        tm, tn = (spec[:, 1] + bm - 1) // bm, (spec[:, 2] + bn - 1) // bn
+        ntile = tm * tn
+        t_task = np.repeat(np.arange(n), ntile)
+        local = np.arange(int(np.sum(ntile))) - np.repeat(np.cumsum(ntile) - ntile, ntile)
+        tiles = np.zeros((len(t_task), 4), dtype=np.int32)
+        order = np.argsort(-np.repeat(spec[:, 10], ntile), kind='stable')       # longest chains first
+        tiles[:, 0] = t_task[order]
+        tiles[:, 1] = (local // np.repeat(tn, ntile))[order]
+        tiles[:, 2] = (local % np.repeat(tn, ntile))[order]
+        tab = (dev.to_device(tasks), dev.to_device(links), dev.to_device(tiles), len(tiles))
+        _tables[key] = tab
+        if len(_tables) > _TABLES_MAX:
+            _tables.popitem(last=False)
+    else:
+        _tables.move_to_end(key)
+    dev.check(dev.lib().tpa_gemm_chain(dev.code(dtype), 1, tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr(), tab[3],
+                                       A_arena.data_ptr(), B_arena.data_ptr(), C_arena.data_ptr(), dev.stream()), "gemm_chain")
+
+
+def raw_copy(dtype, jobs, src_arena, dst_arena):
+    """``tpa_copy_batch`` on host-built jobs (cached upload by content)."""
+    jobs = np.ascontiguousarray(jobs, dtype=np.int64)
+    if len(jobs) == 0:
+        return
+    key = ('copy', jobs.tobytes())
+    tab = _tables.get(key)
+    if tab is None:
+        tab = (dev.to_device(jobs), int(np.max(np.prod(jobs[:, 4:4 + COPY_MAXDIM].clip(1), axis=1))))
+        _tables[key] = tab
+        if len(_tables) > _TABLES_MAX:
+            _tables.popitem(last=False)
+    dev.check(dev.lib().tpa_copy_batch(dev.code(dtype), tab[0].data_ptr(), len(jobs), tab[1], src_arena.data_ptr(),
+                                       dst_arena.data_ptr(), dev.stream()), "copy_batch")
+
+
+def copy_jobs_2d(dst_off, dst_rs, dst_cs, src_off, src_rs, src_cs, rows, cols, conj=False):
+    """Jobs ``dst[r, c] = src[r, c]`` for strided 2-D views (element strides); arrays of equal length."""
+    n = len(np.atleast_1d(rows))
+    jobs = np.zeros((n, 4 + 3 * COPY_MAXDIM), dtype=np.int64)
+    jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3] = dst_off, src_off, 2, int(bool(conj))
+    jobs[:, 4], jobs[:, 5] = rows, cols
+    jobs[:, 4 + COPY_MAXDIM], jobs[:, 5 + COPY_MAXDIM] = dst_rs, dst_cs
+    jobs[:, 4 + 2 * COPY_MAXDIM], jobs[:, 5 + 2 * COPY_MAXDIM] = src_rs, src_cs
+    return jobs[(jobs[:, 4] > 0) & (jobs[:, 5] > 0)]
+
+
+def _axpy(dtype, alpha, x, y, n=None):
+    n = x.numel() if n is None else n
+    if n > 0:
+        dev.check(dev.lib().tpa_axpy(dev.code(dtype), int(n), float(alpha), 0.0, x.data_ptr(), y.data_ptr(), dev.stream()), "axpy")
+
+
+def _scal(dtype, alpha, x):
+    if x.numel() > 0:
+        dev.check(dev.lib().tpa_scal(dev.code(dtype), int(x.numel()), float(alpha), 0.0, x.data_ptr(), dev.stream()), "scal")
+
+
+def lowdin_rows(dtype, arena, off, nvec, length, vs, cs, iterations=1):
+    """In place ``V <- (3 I - V V^H) V / 2`` for sets of vectors ``V_t[i][j] = arena[off_t + i vs_t + j cs_t]`` (``i < nvec_t``,
+    ``j < length_t``): first-order symmetric orthonormalisation; a defect d = |V V^H - 1| becomes 3 d^2 / 8.
+    The vectors are gathered into a contiguous buffer T, then per iteration G = T T^H, T2 = G T (matrix cores),
+    T <- 1.5 T - 0.5 T2, and scattered back."""
+    off, nvec, length, vs, cs = (np.asarray(x, dtype=np.int64) for x in (off, nvec, length, vs, cs))
+    keep = nvec > 0
+    off, nvec, length, vs, cs = off[keep], nvec[keep], length[keep], vs[keep], cs[keep]
+    if len(off) == 0:
+        return
+    dtype = np.dtype(dtype)
+    cplx = dtype.kind == 'c'
+    g_off = np.concatenate([[0], np.cumsum(nvec * nvec)])
+    t_off = np.concatenate([[0], np.cumsum(nvec * length)])
+    z = np.zeros(len(off), dtype=np.int64)
+    one = z + 1
+    T = dev.empty(int(t_off[-1]), dtype)
+    raw_copy(dtype, copy_jobs_2d(t_off[:-1], length, one, off, vs, cs, nvec, length), arena, T)
+    for _ in range(iterations):
+        G = dev.empty(int(g_off[-1]), dtype)
+        raw_gemm(dtype, np.stack([g_off[:-1], nvec, nvec, nvec, t_off[:-1], length, one, t_off[:-1], one, length, length,
+                                  z + (2 if cplx else 0)], axis=1), T, T, G)
+        T2 = dev.empty(int(t_off[-1]), dtype)
+        raw_gemm(dtype, np.stack([t_off[:-1], nvec, length, length, g_off[:-1], nvec, one, t_off[:-1], length, one, nvec, z], axis=1), G, T, T2)
+        _scal(dtype, 1.5, T)
+        _axpy(dtype, -0.5, T2, T)
+    raw_copy(dtype, copy_jobs_2d(off, vs, cs, t_off[:-1], length, one, nvec, length), T, arena)
+
+
+class Basis:
+    """Orthonormal row bases of the charge sectors of one leg: block b holds ``k[b] x length[b]`` row-major at ``off[b]``."""
+    __slots__ = ('arena', 'off', 'k', 'length', 'sectors', 'dtype', 'age')
+
+    def __init__(self, arena, off, k, length, sectors, dtype):
+        self.arena, self.off, self.k, self.length, self.sectors, self.dtype = arena, off, k, length, sectors, np.dtype(dtype)
+        self.age = 0
+
+
+_cache = OrderedDict()
+ages = {}                 # key -> number of consecutive warm generations of its bases
+cooldown = {}             # key -> visits to skip before the next warm attempt (after a stale basis)
+CACHE_MAX = 4096
+# |E|_F <= E_TOL |A|_F (per charge block): the part of theta outside the span of the basis is dropped.  Measured on the converged
+# chi = 2048 state (profiles/r03_svd_warm_residuals.txt): forming E = A - (A Bq^H) Bq with k ~ 570-term dot products leaves
+# 1e-14 ... 4e-14 |A|_F of pure rounding noise (full rank: extending the basis does not reduce it), so the threshold sits just
+# above that.  The cold path drops the same order: its rank-revealing QR stops at residual COLUMN norms of 1e-15 |A|_F
+# (QRP_RANK_TOL), i.e. up to sqrt(n) 1e-15 |A|_F ~ 3e-14 |A|_F of Frobenius mass.  Singular values move by <= E_TOL sigma_max.
+E_TOL = 1.e-13
+E_RANK_TOL = 1.e-15       # singular vectors with values above this fraction of |A|_F are remembered as warm-start basis
+
+
+def cache_clear():
+    _cache.clear()
+    ages.clear()
+    cooldown.clear()
+
+
+def cache_get(key, side):
+    ent = _cache.get((key, side))
+    if ent is not None:
+        _cache.move_to_end((key, side))
+    return ent
+
+
+def cache_put(key, side, basis):
+    _cache[(key, side)] = basis
+    _cache.move_to_end((key, side))
+    while len(_cache) > CACHE_MAX:
+        _cache.popitem(last=False)
+
+
+def _row_norms_sq(dtype, arena, off, rows, cols):
+    """Host float64 array of ``|block_b|_F^2`` (one wavefront per row, summed on the host).  Synchronises."""
+    L = dev.lib()
+    nb = len(off)
+    o_off = np.concatenate([[0], np.cumsum(rows)])
+    jobs = np.zeros((nb, 6), dtype=np.int64)
+    jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3], jobs[:, 4] = off, 1, rows, cols, o_off[:-1]
+    tab = np.zeros(((int(o_off[-1]) + 3) // 4 * 4, 2), dtype=np.int32) - 1
+    tab[:int(o_off[-1]), 0] = np.repeat(np.arange(nb), rows)
+    tab[:int(o_off[-1]), 1] = np.arange(int(o_off[-1])) - np.repeat(o_off[:-1], rows)
+    key = ('rn', jobs.tobytes())
+    t = _tables.get(key)
+    if t is None:
+        t = (dev.to_device(jobs), dev.to_device(tab))
+        _tables[key] = t
+    out = dev.empty(int(o_off[-1]), np.float64)
+    dev.check(L.tpa_axis_sqnorm_batch(dev.code(dtype), t[0].data_ptr(), t[1].data_ptr(), len(tab), arena.data_ptr(),
+                                      out.data_ptr(), dev.stream()), "axis_sqnorm")
+    h = dev.to_host(out)
+    return np.add.reduceat(h, o_off[:-1]) if nb else np.zeros(0)
+
+
+DEBUG = bool(os.environ.get('TPA_SVD_WARM_DEBUG'))      # print the residuals |E_b| / |A_b| of every attempt
+
+
+def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, side, run_svd, out, lowdin_basis=True):
+    """Warm-started SVD of the blocks ``A_b`` (``ms[b] x ns[b]`` row-major at ``offs[b]``, packed back to back) with row
+    bases ``Bq_b`` (``b_k[b] x b_len[b]`` row-major at ``b_off[b]`` in ``b_arena``; ``b_k[b] = 0``: no basis for block b).
+
+    ``run_svd(jobs, a_arena, U, S, VH, qrp)`` runs the batched device Jacobi and returns S on the host or None;
+    ``out = (U_arena, V_arena, u_off, v_off)`` are the zero-initialised result arenas in the standard layout (``U_b``
+    ``m x kk``, ``VH_b`` ``kk x n``, ``kk = min(m, n)``).  Returns ``(done, S)``: ``done[b]`` says whether block b has been
+    decomposed here (``S[b]`` = its singular values, zero-padded to ``kk``); the caller runs the cold path for the other blocks.
+    A block is left to the cold path when it has no (fitting) basis or when the residual E = X - (X Bq^H) Bq exceeds
+    ``E_TOL |A_b|_F``.
+
+    Tried and dropped (round 3, evidence in profiles/r03_svd_warm_residuals.txt): appending the row space of E to the basis
+    (cold SVD of E, or QR of a random sketch Omega E) so that a still-converging state could start warm as well.  On the
+    chi = 2048 runs E is either rounding noise (1e-14 ... 4e-14 |A|, full rank) or the ~1e-9 change of the state between two
+    visits, which (i) has no low numerical rank at the 1e-13 level in the large sectors and (ii) cannot be appended at all in
+    the full-rank sectors away from the centre (basis rows = min(m, n) already); every failed attempt cost 5 - 12 ms.
+    """
+    dtype = np.dtype(dtype)
+    cplx = dtype.kind == 'c'
+    nb = len(ms)
+    offs, ms, ns, b_off, b_k, b_len = (np.asarray(x, dtype=np.int64) for x in (offs, ms, ns, b_off, b_k, b_len))
+    R = side == 'R'
+    ps_all = ms if R else ns                  # rows of X
+    ls_all = ns if R else ms                  # length of the basis vectors
+    kk_all = np.minimum(ms, ns)
+    done = np.zeros(nb, dtype=bool)
+    S_out = [None] * nb
+    act = np.nonzero((b_k > 0) & (b_k <= kk_all) & (b_len == ls_all))[0]
+    stats['fb_shape'] += int(nb - len(act))
+    if len(act) == 0:
+        return done, S_out
+    if not (np.array_equal(offs, np.concatenate([[0], np.cumsum(ms * ns)[:-1]])) and int(np.sum(ms * ns)) == a_arena.numel()):
+        return done, S_out                   # blocks not packed back to back (E = A - P is formed on the flat arena)
+    U_arena, V_arena, u_off_all, v_off_all = out
+    conjB, conjA = (2 if cplx else 0), (1 if cplx else 0)
+    o, m, n, p, l, kk = offs[act], ms[act], ns[act], ps_all[act], ls_all[act], kk_all[act]
+    z = np.zeros(len(act), dtype=np.int64)
+    one = z + 1
+    x_rs, x_cs = (n, one) if R else (one, n)      # X(j, l) = A[o + j x_rs + l x_cs]
+
+    def residual(bar, boff, bk, sel):
+        """W = Bq X^H for all active blocks;  E = A - (part spanned by the basis) and |E_b|_F^2 for the blocks ``sel``."""
+        w_off = np.concatenate([[0], np.cumsum(bk * p)])
+        W = dev.empty(int(w_off[-1]), dtype)
+        # A(i, l) = Bq[i][l];  B(l, j) = conj(X[j][l])
+        raw_gemm(dtype, np.stack([w_off[:-1], bk, p, p, boff, l, one, o, x_cs, x_rs, l, z + conjB], axis=1), bar, a_arena, W)
+        P = dev.zeros(a_arena.numel(), dtype)
+        t = sel
+        if R:       # A = W^H Bq
+            raw_gemm(dtype, np.stack([o[t], m[t], n[t], n[t], w_off[:-1][t], one[t], p[t], boff[t], l[t], one[t], bk[t], z[t] + conjA], axis=1),
+                     W, bar, P)
+        else:       # A = X^T = Bq^T conj(W)
+            raw_gemm(dtype, np.stack([o[t], m[t], n[t], n[t], boff[t], one[t], l[t], w_off[:-1][t], p[t], one[t], bk[t], z[t] + conjB], axis=1),
+                     bar, W, P)
+        E = dev.clone(a_arena)
+        _axpy(dtype, -1.0, P, E)
+        return W, w_off, E, _row_norms_sq(dtype, E, o[t], m[t], n[t])
+
+    kq = b_k[act].copy()
+    bq_arena, bq_off = b_arena, b_off[act].copy()
+    everyone = np.arange(len(act))
+    W, w_off, E, nrm = residual(bq_arena, bq_off, kq, everyone)
+    nrmA = _row_norms_sq(dtype, a_arena, o, m, n)
+    ok = np.isfinite(nrm) & np.isfinite(nrmA) & (nrmA > 0.)
+    e_rel = np.where(ok, np.sqrt(np.where(ok, nrm, 0.) / np.where(ok, nrmA, 1.)), np.inf)
+    stats['e_rel_last'] = float(np.max(np.where(np.isfinite(e_rel), e_rel, 1.)))
+    stats['e_rel_max'] = max(stats['e_rel_max'], stats['e_rel_last'])
+    if DEBUG:
+        print('warm level -1 e_rel', np.array2string(e_rel, precision=1), 'kq', kq, 'kk', kk, flush=True)
+    keep = e_rel <= E_TOL
+    stats['fb_stale'] += int(np.sum(~keep))
+    # ---- Jacobi on the rows of W (k x p, k <= p), no rank-revealing QR, for the blocks that are still warm
+    sel = np.nonzero(keep)[0]
+    if len(sel) == 0:
+        return done, S_out
+    idx = act[sel]
+    o, m, n, p, l, kk, z, one = o[sel], m[sel], n[sel], p[sel], l[sel], kk[sel], z[sel], one[sel]
+    kq = kq[sel]
+    ju_off = np.concatenate([[0], np.cumsum(kq * kq)])
+    js_off = np.concatenate([[0], np.cumsum(kq)])
+    jv_off = np.concatenate([[0], np.cumsum(kq * p)])
+    jjobs = np.zeros((len(sel), 8), dtype=np.int64)
+    jjobs[:, 0], jjobs[:, 1], jjobs[:, 2] = w_off[:-1][sel], kq, p
+    jjobs[:, 3], jjobs[:, 4], jjobs[:, 5] = ju_off[:-1], js_off[:-1], jv_off[:-1]
+    jjobs[:, 6] = 1                       # square blocks: orthogonalise the rows
+    JU = dev.empty(int(ju_off[-1]), dtype)
+    JV = dev.empty(int(jv_off[-1]), dtype)
+    JS = dev.empty(int(js_off[-1]), np.float64)
+    S_J = run_svd(jjobs, W, JU, JS, JV, False)
+    if S_J is None:
+        stats['fb_svd'] += len(sel)
+        return done, S_out
+    # ---- outputs.  W = U' S VH'  ->  X = VH'^H S (U'^H Bc);  Z = U'^H Bc (k x len) is the accumulated basis
+    zb_off = np.concatenate([[0], np.cumsum(kq * l)])
+    Z = dev.empty(int(zb_off[-1]), dtype)
+    raw_gemm(dtype, np.stack([zb_off[:-1], kq, l, l, ju_off[:-1], one, kq, bq_off[sel], l, one, kq, z + conjA], axis=1), JU, bq_arena, Z)
+    if lowdin_basis:
+        lowdin_rows(dtype, Z, zb_off[:-1], kq, l, l, one, iterations=1)
+    u_off, v_off = u_off_all[idx], v_off_all[idx]
+    if R:
+        # VH_A rows = Z ;  U_A[j][i] = conj(VH'[i][j])
+        raw_copy(dtype, copy_jobs_2d(v_off, n, one, zb_off[:-1], l, one, kq, n), Z, V_arena)
+        raw_copy(dtype, copy_jobs_2d(u_off, kk, one, jv_off[:-1], one, p, m, kq, conj=cplx), JV, U_arena)
+    else:
+        # A = X^T = Z^T S conj(VH'):  U_A[l][i] = Z[i][l] ;  VH_A[i][j] = conj(VH'[i][j])
+        raw_copy(dtype, copy_jobs_2d(u_off, kk, one, zb_off[:-1], one, l, m, kq), Z, U_arena)
+        raw_copy(dtype, copy_jobs_2d(v_off, n, one, jv_off[:-1], p, one, kq, n, conj=cplx), JV, V_arena)
+    for t, b in enumerate(idx):
+        sb = np.zeros(int(kk[t]), dtype=np.float64)
+        sb[:kq[t]] = S_J[js_off[t]:js_off[t + 1]]
+        S_out[b] = sb
+        done[b] = True
+    return done, S_out

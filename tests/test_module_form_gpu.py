@@ -1,0 +1,114 @@
+"""UNMODIFIED TeNPy engines on the device mirror with the fused callers (``tenpy_amd.install.install(fused=True)``):
+``tenpy.algorithms.dmrg.TwoSiteDMRGEngine`` incl. the density-matrix mixer ramp (``mps_common.py:1903-2079``,
+``dmrg.py:207-212``), ``combine=True`` and ``combine=False``, against the SAME script run on the plain reference (its own
+numpy ``np_conserved``, no hook) in a second process: sweep energies to 1e-10, final Schmidt spectrum of the centre bond.
+Also the reference's ``TEBDEngine`` (``tebd.py:416``) real-time quench.  'mock': numpy emulation of the device entry points
+(CPU container); 'gpu': the real kernels on the MI355X, where the reference comes from the archive oracle/_ref/tenpy_ref.zip.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import build_ref  # noqa: E402
+
+REF = build_ref.reference_root()
+pytestmark = pytest.mark.skipif(REF is None, reason="reference tree / archive not available")
+WHERE = ["mock", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+DMRG = r"""
+import json, sys, warnings
+warnings.simplefilter('ignore')
+DEVICE, COMBINE = %(device)r, %(combine)r
+if DEVICE:
+    import refsuite_plugin                    # import hook (+ numpy emulation when no GPU is visible)
+    import tenpy_amd.install as ti
+    ti.use_fused_callers()
+    import tenpy_amd.algorithms.module_form as mf
+    mf.MIN_SECTOR = 4                         # small test system: use the device TwoSiteH wherever it applies
+import numpy as np
+from tenpy.algorithms import dmrg
+from tenpy.models.xxz_chain import XXZChain
+from tenpy.networks.mps import MPS
+L = 24
+M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'conserve': 'Sz', 'sort_charge': True})
+psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': True, 'mixer_params': {'amplitude': 1e-5, 'decay': 2., 'disable_after': 4},
+                                      'combine': COMBINE, 'max_N_for_ED': 0,
+                                      'trunc_params': {'chi_max': 48, 'svd_min': 1e-12},
+                                      'lanczos_params': {'N_min': 4, 'N_max': 12, 'reortho': False}})
+E = []
+for sweep in range(8):
+    eng.sweep()
+    E.append(float(eng.update_stats['E_total'][-1]))
+used = None
+if DEVICE:
+    from tenpy_amd.linalg import _svd_warm
+    used = {'eff_H': dict(mf.stats), 'warm_calls': _svd_warm.stats['warm_calls'] + _svd_warm.stats['fallbacks'] + _svd_warm.stats.get('skipped', 0)}
+print('RESULT ' + json.dumps({'E': E, 'S': [float(x) for x in psi.get_SL(L // 2)], 'used': used}))
+"""
+
+TEBD = r"""
+import json, sys, warnings
+warnings.simplefilter('ignore')
+DEVICE = %(device)r
+if DEVICE:
+    import refsuite_plugin
+import numpy as np
+from tenpy.algorithms import tebd
+from tenpy.models.tf_ising import TFIChain
+from tenpy.networks.mps import MPS
+L = 16
+M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': 'parity', 'sort_charge': True})
+psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 4, 'trunc_params': {'chi_max': 40, 'svd_min': 1e-12}})
+out = []
+for k in range(5):
+    eng.run()
+    out.append([float(x) for x in psi.entanglement_entropy()])
+print('RESULT ' + json.dumps({'S': out}))
+"""
+
+
+def _run(code, device):
+    env = dict(os.environ)
+    env['PYTHONPATH'] = os.pathsep.join([HERE, ROOT, REF, env.get('PYTHONPATH', '')])
+    if not device:
+        env['TENPY_NO_CYTHON'] = '1'           # plain reference, pure numpy path (no compiled helper needed)
+    res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=3000)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    return json.loads([l for l in res.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
+
+
+def _needs(where):
+    import torch
+    if where == "mock" and torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the 'gpu' variant runs instead")
+
+
+@pytest.mark.parametrize("where", WHERE)
+@pytest.mark.parametrize("combine", [False, True])
+def test_tenpy_dmrg_engine_with_mixer_on_the_device(where, combine):
+    _needs(where)
+    got = _run(DMRG % {'device': True, 'combine': combine}, True)
+    ref = _run(DMRG % {'device': False, 'combine': combine}, False)
+    assert got['used']['eff_H']['device'] > 100, got['used']                            # the device TwoSiteH really ran
+    assert got['used']['warm_calls'] > 0                                               # ... and the SVD hint arrived
+    for a, b in zip(got['E'], ref['E']):
+        assert abs(a - b) <= 1e-10 * abs(b), (got['E'], ref['E'])
+    import numpy as np
+    np.testing.assert_allclose(got['S'], ref['S'], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_tenpy_tebd_engine_on_the_device(where):
+    _needs(where)
+    got = _run(TEBD % {'device': True}, True)
+    ref = _run(TEBD % {'device': False}, False)
+    import numpy as np
+    np.testing.assert_allclose(got['S'], ref['S'], rtol=0, atol=1e-10)

@@ -1,0 +1,129 @@
+"""Warm-started block SVD (tenpy_amd/linalg/_svd_warm.py) and the Loewdin clean-up of the small singular vectors:
+results against numpy's LAPACK SVD per charge block (reference semantics: np_conserved.py:3676-3760, svd_flat :4970),
+on the emulated device and on the GPU."""
+import numpy as np
+import pytest
+
+from tenpy_amd.linalg import _svd_warm
+from tenpy_amd.linalg import np_conserved as npc
+from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
+
+
+def _blocked(rng, sizes_l, sizes_r, rank_frac=0.6, cplx=False, decay=12.):
+    """Block-diagonal matrix with graded singular values (like a DMRG theta): sector q of the left leg pairs with sector q
+    of the right leg."""
+    ch = ChargeInfo([1])
+    legL = LegCharge.from_qind(ch, np.concatenate([[0], np.cumsum(sizes_l)]), np.arange(len(sizes_l))[:, None], 1)
+    legR = LegCharge.from_qind(ch, np.concatenate([[0], np.cumsum(sizes_r)]), np.arange(len(sizes_r))[:, None], -1)
+    dense = np.zeros((sum(sizes_l), sum(sizes_r)), dtype=complex if cplx else float)
+    for q, (m, n) in enumerate(zip(sizes_l, sizes_r)):
+        r = max(1, int(rank_frac * min(m, n)))
+        def rnd(*sh):
+            x = rng.standard_normal(sh)
+            return x + 1j * rng.standard_normal(sh) if cplx else x
+        u, _ = np.linalg.qr(rnd(m, r))
+        v, _ = np.linalg.qr(rnd(n, r))
+        dense[legL.slices[q]:legL.slices[q + 1], legR.slices[q]:legR.slices[q + 1]] = (u * np.logspace(0, -decay, r)) @ v.conj().T
+    return dense, legL, legR
+
+
+def _check(a_dense, legL, legR, U, S, VH, tol=2e-13):
+    Ud, Vd = U.to_ndarray(), VH.to_ndarray()
+    rec = (Ud * S) @ Vd
+    scale = np.abs(a_dense).max()
+    assert np.abs(rec - a_dense).max() <= tol * scale
+    # per block singular values
+    off = 0
+    for q in range(legL.block_number):
+        blk = a_dense[legL.slices[q]:legL.slices[q + 1], legR.slices[q]:legR.slices[q + 1]]
+        ref = np.linalg.svd(blk, compute_uv=False)
+        k = min(blk.shape)
+        np.testing.assert_allclose(S[off:off + k], ref, rtol=0, atol=1e-13 * ref.max())
+        off += k
+    keep = S > 1e-14 * S.max()
+    assert np.abs(Ud[:, keep].conj().T @ Ud[:, keep] - np.eye(keep.sum())).max() < 1e-12
+    assert np.abs(Vd[keep] @ Vd[keep].conj().T - np.eye(keep.sum())).max() < 1e-12
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("side", ['R', 'L'])
+def test_warm_start_matches_lapack(backend, side, cplx):
+    rng = np.random.RandomState(5)
+    sizes_l, sizes_r = [40, 70, 9, 33], [52, 70, 17, 20]
+    dense, legL, legR = _blocked(rng, sizes_l, sizes_r, cplx=cplx)
+    a = npc.Array.from_ndarray(dense, [legL, legR])
+    _svd_warm.cache_clear()
+    for k in _svd_warm.stats:
+        _svd_warm.stats[k] = 0
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(a)
+    _check(dense, legL, legR, U, S, VH)
+    assert _svd_warm.stats['cold_calls'] == 1 and _svd_warm.stats['warm_calls'] == 0
+    # (1) tiny perturbation inside the old row / column space: basis complete, no E handling
+    d2 = dense.copy()
+    for q in range(legL.block_number):
+        sl = (slice(legL.slices[q], legL.slices[q + 1]), slice(legR.slices[q], legR.slices[q + 1]))
+        blk = dense[sl]
+        mix = np.eye(blk.shape[0]) + 1e-6 * rng.standard_normal((blk.shape[0],) * 2)
+        mixr = np.eye(blk.shape[1]) + 1e-6 * rng.standard_normal((blk.shape[1],) * 2)
+        d2[sl] = (mix @ blk) if side == 'R' else (blk @ mixr)
+    a2 = npc.Array.from_ndarray(d2, [legL, legR])
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(a2)
+    _check(d2, legL, legR, U, S, VH)
+    assert _svd_warm.stats['warm_calls'] == 1 and _svd_warm.stats['e_handled'] == 0
+    # (2) perturbation that leaves the span of the basis (new directions at 1e-7): stale basis -> cold path, still exact
+    d3 = d2.copy()
+    for q in range(legL.block_number):
+        sl = (slice(legL.slices[q], legL.slices[q + 1]), slice(legR.slices[q], legR.slices[q + 1]))
+        m, n = d2[sl].shape
+        x = rng.standard_normal((m, 2)) @ rng.standard_normal((2, n))
+        d3[sl] = d2[sl] + 1e-7 * x / np.abs(x).max()
+    a3 = npc.Array.from_ndarray(d3, [legL, legR])
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(a3)
+    _check(d3, legL, legR, U, S, VH)
+    assert _svd_warm.stats['warm_calls'] == 1 and _svd_warm.stats['fallbacks'] == 1 and _svd_warm.stats['fb_stale'] > 0
+    assert _svd_warm.cooldown.get('bond', 0) > 0       # the next visits do not even try
+    _svd_warm.cooldown.clear()
+    # the decomposition of d3 is the new basis: d3 again starts warm
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(a3)
+    _check(d3, legL, legR, U, S, VH)
+    assert _svd_warm.stats['warm_calls'] == 2
+    # (3) a different matrix under the same key: the basis is useless -> falls back to the cold path, still exact
+    d4, _, _ = _blocked(np.random.RandomState(77), sizes_l, sizes_r, rank_frac=1.0, cplx=cplx, decay=3.)
+    a4 = npc.Array.from_ndarray(d4, [legL, legR])
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(a4)
+    _check(d4, legL, legR, U, S, VH)
+    assert _svd_warm.stats['fallbacks'] == 2
+    _svd_warm.cooldown.clear()
+    # (4) other leg structure under the same key: no basis
+    d5, l5, r5 = _blocked(rng, [30, 21], [30, 40], cplx=cplx)
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(npc.Array.from_ndarray(d5, [l5, r5]))
+    _check(d5, l5, r5, U, S, VH)
+    assert npc.svd_hint is None
+    _svd_warm.cache_clear()
+
+
+def test_lowdin_rows(backend):
+    from tenpy_amd.linalg import _device as dev
+    rng = np.random.RandomState(3)
+    for cplx in (False, True):
+        dt = np.complex128 if cplx else np.float64
+        q, _ = np.linalg.qr(rng.standard_normal((60, 24)) + (1j * rng.standard_normal((60, 24)) if cplx else 0))
+        V = q.T.copy()                                   # 24 orthonormal rows of length 60
+        V = V + 1e-5 * (rng.standard_normal(V.shape))    # defect ~1e-5
+        flat = np.concatenate([np.zeros(7, dt), V.reshape(-1).astype(dt)])
+        arena = dev.to_device(flat)
+        _svd_warm.lowdin_rows(dt, arena, [7], [24], [60], [60], [1], iterations=2)
+        out = dev.to_host(arena)[7:].reshape(24, 60)
+        assert np.abs(out @ out.conj().T - np.eye(24)).max() < 1e-14
+        assert np.abs(out - V).max() < 1e-4
+        # the same vectors stored as columns (stride 1 between vectors)
+        arena = dev.to_device(np.ascontiguousarray(V.T).reshape(-1).astype(dt))
+        _svd_warm.lowdin_rows(dt, arena, [0], [24], [60], [1], [24], iterations=2)
+        out = dev.to_host(arena).reshape(60, 24)
+        assert np.abs(out.conj().T @ out - np.eye(24)).max() < 1e-14
