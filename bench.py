@@ -339,6 +339,8 @@ def main():
     n0 = 0 if is_tebd else len(eng.update_stats['E_total'])
     from tenpy_amd.linalg import _svd_warm as _sw
     svd_calls0, svd_sweeps0, warm0 = npc.svd_stats['calls'], npc.svd_stats['sweeps'], dict(_sw.stats)
+    from tenpy_amd.linalg import krylov_based as _kb
+    lanczos0 = dict(_kb.stats)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -432,6 +434,10 @@ def main():
                                 "note": "warm = calls started from the singular vectors this bond produced on its previous visit "
                                         "(no pivoted QR; linalg/_svd_warm.py); the rest took the cold path; sweep counts include the "
                                         "low-rank residual decompositions of warm calls"}
+            out["lanczos_stats"] = {k: _kb.stats[k] - lanczos0[k] for k in _kb.stats}
+            out["lanczos_stats"]["note"] = ("timed sweeps only; n_ill_conditioned = results whose norm differed from 1 by more than 1e-5 before the "
+                                            "final normalisation (the forced N_min = N_max = %d runs past convergence), n_degenerate = results that "
+                                            "cancelled to zero and were replaced by the start vector" % args.lanczos_N)
             if world == 1:
                 upd_t = eng.update_stats['time'][n0:]
                 mid = [t for i, t in zip(eng.update_stats['i0'][n0:], upd_t) if abs(i - L // 2) <= 1]

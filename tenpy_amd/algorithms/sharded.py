@@ -474,6 +474,9 @@ def lanczos_row_panels(H, theta0, options):
     decisions because every decision is made on all-reduced numbers."""
     from ..linalg.krylov_based import LanczosGroundState
     ctl = LanczosGroundState(H, theta0, options)         # option parsing, tridiagonal bookkeeping, stopping rule
+    if ctl.E_shift is not None or ctl.reortho or ctl.N_cache < ctl.N_max:
+        # this variant keeps every Krylov panel and implements the plain three-term recurrence (ADVICE r2: do not ignore silently)
+        raise ValueError("lanczos_row_panels does not support the options E_shift, reortho, N_cache < N_max")
     ops = RowPanelOps(H, theta0)
     v = ops.pack(ops.embed(theta0))
     (n0,) = ops.dots(v, [v])

@@ -491,13 +491,16 @@ def _eq(self, other, eps=1.e-14):
 
 def _save_hdf5(self, hdf5_saver, h5gr, subpath):
     """HDF5 layout of the reference (:350): ``chinfo, legs, dtype, total_charge, labels, blocks, block_inds`` and the
-    attributes ``block_inds_sorted, rank, shape``; the blocks are downloaded for it."""
+    attributes ``block_inds_sorted, rank, shape``; the blocks are downloaded for it.  The class is recorded under the REFERENCE's
+    module name (``hdf5_io`` writes ``obj.__class__.__module__`` before calling this): a file written on the device must load
+    in a plain TeNPy and vice versa (tests/test_hdf5_format.py)."""
+    h5gr.attrs['module'] = 'tenpy.linalg.np_conserved'
     hdf5_saver.save(self.chinfo, subpath + 'chinfo')
     hdf5_saver.save(list(self.legs), subpath + 'legs')
     hdf5_saver.save(self.dtype, subpath + 'dtype')
     hdf5_saver.save(self.qtotal, subpath + 'total_charge')
     hdf5_saver.save(list(self._labels), subpath + 'labels')
-    hdf5_saver.save(list(self._data), subpath + 'blocks')
+    hdf5_saver.save([np.array(b) for b in self._data], subpath + 'blocks')      # plain ndarrays (not write-through views)
     hdf5_saver.save(self._qdata, subpath + 'block_inds')
     h5gr.attrs['block_inds_sorted'] = bool(self._qdata_sorted)
     h5gr.attrs['rank'] = self.rank

@@ -78,6 +78,7 @@ class ChargeInfo:
 
     def save_hdf5(self, hdf5_saver, h5gr, subpath):
         """HDF5 layout of the reference (charges.py:111): attribute ``num_charges``, datasets ``U1_ZN`` and ``names``."""
+        h5gr.attrs['module'] = 'tenpy.linalg.charges'     # the file names the reference's module (hdf5_io ATTR_MODULE), not the mirror
         h5gr.attrs['num_charges'] = self._qnumber
         hdf5_saver.save(self._mod, subpath + 'U1_ZN')
         hdf5_saver.save(self.names, subpath + 'names')
@@ -371,6 +372,7 @@ class LegCharge:
     # ---- HDF5 (layout of the reference, charges.py:649-755) -------------------------------------------------
     def save_hdf5(self, hdf5_saver, h5gr, subpath):
         fmt = hdf5_saver.format_selection.get('LegCharge', 'blocks')
+        h5gr.attrs['module'] = 'tenpy.linalg.charges'
         h5gr.attrs['format'] = fmt
         h5gr.attrs['ind_len'] = self.ind_len
         h5gr.attrs['qconj'] = self.qconj

@@ -25,6 +25,9 @@ PIPELINED = _os.environ.get('TPA_LANCZOS_PIPELINED', '1') != '0'     # device-re
 __all__ = ['LanczosGroundState', 'LanczosEvolution', 'Arnoldi', 'lanczos', 'gram_schmidt', 'iscale_prefactor', 'iadd_prefactor_other']
 
 
+stats = {'runs': 0, 'n_matvec': 0, 'n_ill_conditioned': 0, 'n_degenerate': 0}
+
+
 class LanczosGroundState:
     """Lanczos algorithm for the ground state of a hermitian ``H`` given through ``H.matvec(vec)``.
 
@@ -58,6 +61,7 @@ class LanczosGroundState:
     # ---- public -----------------------------------------------------------------------------------------
     def run(self):
         """Returns ``(E0, psi0, N)``: energy estimate, normalised ground state estimate, iterations."""
+        stats['runs'] += 1
         N = self._build_krylov()
         E0 = self.Es[N - 1, 0]
         if self.E_shift is not None:
@@ -68,6 +72,7 @@ class LanczosGroundState:
 
     # ---- internals ------------------------------------------------------------------------------------------
     def _matvec(self, w):
+        stats['n_matvec'] += 1
         r = self.H.matvec(w)
         if self.E_shift is not None:
             r.iadd_prefactor_other(self.E_shift, w)
@@ -119,6 +124,7 @@ class LanczosGroundState:
             w = self._matvec(v1)
             v0 = self._cache[-2] if k > 0 else None
             if self._flat_ok(w, v1, *([v0] if v0 is not None else [])):
+                w._own_arena()          # copy-on-write: a matvec may hand back a shallow copy of its input
                 dev.check(L.tpa_lanczos_step(code, w._arena.numel(), w._arena.data_ptr(), v1._arena.data_ptr(),
                                              v0._arena.data_ptr() if v0 is not None else None,
                                              pipe.ptr(k - 1, 1) if v0 is not None else None, pipe.ptr(k), scr.data_ptr(),
@@ -163,6 +169,7 @@ class LanczosGroundState:
             beta_prev = beta
             if self._flat_ok(w, v1, *([v0] if v0 is not None else [])):
                 out, scr = dev.reduction_buffers()
+                w._own_arena()
                 dev.check(dev.lib().tpa_lanczos_update(
                     dev.code(w.dtype), w._arena.numel(), w._arena.data_ptr(), alpha, 0., v1._arena.data_ptr(),
                     beta_prev, 0., v0._arena.data_ptr() if v0 is not None else None, out.data_ptr(), scr.data_ptr(),
@@ -235,7 +242,15 @@ class LanczosGroundState:
         self._rebuild_krylov_for_result_full(psif, N - len_cache - 1)
         nrm = npc.norm(psif)
         if abs(1. - nrm) > 1.e-5:
+            stats['n_ill_conditioned'] += 1
             logger.warning("poorly conditioned H matrix in KrylovBased! |psi_0| = %f", nrm)
+        if not (nrm > 1.e-8) or not np.isfinite(nrm):
+            # The Krylov vectors of a run that was forced past convergence (N_min beyond the point where beta hits rounding
+            # level) are noise, and their combination can cancel to (numerically) nothing; the reference divides by that norm
+            # (krylov_based.py:236-239) and hands NaNs to the SVD.  The start vector is the best available answer then.
+            stats['n_degenerate'] += 1
+            psif = self.psi0.copy(deep=True)
+            nrm = npc.norm(psif)
         psif.iscale_prefactor(1. / nrm)
         return psif
 

@@ -2325,13 +2325,24 @@ def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, swee
     group, rank, world = SVD_DIST_GROUP
     owner = svd_block_owners(ms, ns, world)
     mine = np.nonzero(owner == rank)[0]
+    failed, err = 0., None
     if len(mine):
         lj = np.ascontiguousarray(jobs[mine])
-        wb = L.tpa_svd_worksize(code, lj.ctypes.data, len(mine))
-        work = dev.empty((int(wb) + 7) // 8, np.float64)        # wb bytes
-        dev.check(L.tpa_svd_batch(code, lj.ctypes.data, len(mine), a._arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
-                                  V_arena.data_ptr(), work.data_ptr(), int(wb), 80, SVD_ABS_FLOOR, dev.byref(sweeps), dev.stream()),
-                  "svd_batch")
+        ls_off = np.concatenate([[0], np.cumsum(ks[mine])])
+        try:      # same fallback chain as the single-GPU path; a failure is agreed on below, BEFORE the collective
+            S_loc = dev.empty(int(ls_off[-1]), np.float64)
+            lj2 = lj.copy()
+            lj2[:, 4] = ls_off[:-1]
+            _svd_batch_robust(L, code, lj2, len(mine), a._arena, U_arena, S_loc, V_arena, sweeps)
+            for t, b in enumerate(mine):
+                S_dev[int(jobs[b, 4]):int(jobs[b, 4]) + int(ks[b])].copy_(S_loc[int(ls_off[t]):int(ls_off[t + 1])])
+        except (np.linalg.LinAlgError, ValueError) as e:
+            failed, err = 1., e
+    flag = dev.zeros(1, np.float64)
+    flag.fill_(failed)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if float(flag.item()) > 0.:       # every rank raises, none is left waiting in the all-gather
+        raise err if err is not None else np.linalg.LinAlgError("tenpy_amd svd: the block SVD failed on another rank")
     cplx = 2 if np.dtype(a.dtype).kind == 'c' else 1
     Uf = U_arena.view(torch.float64) if cplx == 2 else U_arena     # interleaved (re, im)
     Vf = V_arena.view(torch.float64) if cplx == 2 else V_arena

@@ -628,7 +628,127 @@ def gen_midsize():
     save('midsize.pkl', out)
 
 
-GENERATORS = dict(midsize=gen_midsize, percall=gen_percall, percall2048=gen_percall2048, api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
+def _scaled_leg(leg, factor):
+    """Same charge sectors, every sector `factor` times as wide (structure of a larger bond dimension)."""
+    sizes = np.diff(leg.slices) * factor
+    return npc.LegCharge.from_qind(leg.chinfo, np.concatenate([[0], np.cumsum(sizes)]), np.array(leg.charges), qconj=leg.qconj)
+
+
+def gen_percall_hubbard():
+    """per-call fixtures in the many-small-blocks regime (BASELINE config 4): Fermi-Hubbard ladder, charges (N, Sz).
+    Record 0: legs of a REAL two-site DMRG state of a 2 x 8 ladder at chi = 256 (centre bond); record 1: the same charge
+    sectors with every bond sector 4 times as wide = the block structure of chi = 1024.  Seeded operands, fingerprints."""
+    from tenpy.algorithms import dmrg
+    from tenpy.algorithms.mps_common import TwoSiteH
+    from tenpy.models.hubbard import FermiHubbardModel
+    from tenpy.networks.mpo import MPOEnvironment
+    from tenpy.networks.mps import MPS
+    Lx = 8
+    M = FermiHubbardModel({'lattice': 'Ladder', 'L': Lx, 't': 1., 'U': 8., 'mu': 0., 'cons_N': 'N', 'cons_Sz': 'Sz',
+                           'bc_MPS': 'finite', 'sort_charge': True})
+    psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * Lx, bc='finite')
+    eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'combine': True, 'max_N_for_ED': 0,
+                                          'trunc_params': {'chi_max': 256, 'svd_min': 1.e-12}, 'lanczos_params': {'N_min': 2, 'N_max': 6}})
+    for _ in range(5):
+        eng.sweep()
+    L = 2 * Lx
+    i0 = L // 2 - 1
+    out = []
+    eff = TwoSiteH(eng.env, i0, combine=True)
+    theta0 = eff.combine_theta(psi.get_theta(i0, n=2))
+    out.append(_percall_record(eff, theta0, L, int(max(psi.chi))))
+    # chi = 1024 structure: widen the bond legs of LP / RP / theta, rebuild the effective Hamiltonian on seeded environments
+    vL = _scaled_leg(eng.env.get_LP(i0).get_leg('vR*'), 4)
+    vR = _scaled_leg(eng.env.get_RP(i0 + 1).get_leg('vL*'), 4)
+    W0, W1 = M.H_MPO.get_W(i0), M.H_MPO.get_W(i0 + 1)
+    site0, site1 = M.lat.mps_sites()[i0], M.lat.mps_sites()[i0 + 1]
+    LP = seeded_array([vL, W0.get_leg('wL').conj(), vL.conj()], 21, labels=['vR*', 'wR', 'vR'])
+    RP = seeded_array([vR.conj(), W1.get_leg('wR').conj(), vR], 22, labels=['vL', 'wL', 'vL*'])
+    theta = seeded_array([vL, site0.leg, site1.leg, vR], 23, labels=['vL', 'p0', 'p1', 'vR'])
+
+    class Env:
+        H = M.H_MPO
+        get_LP = staticmethod(lambda i, store=True: LP)
+        get_RP = staticmethod(lambda i, store=True: RP)
+    Env._contract_LHeff = lambda i, label_p='p0', pipe=None: MPOEnvironment._contract_LHeff(Env, i, label_p, pipe)
+    Env._contract_RHeff = lambda i, label_p='p1', pipe=None: MPOEnvironment._contract_RHeff(Env, i, label_p, pipe)
+    eff = TwoSiteH(Env, i0, combine=True)
+    out.append(_percall_record(eff, eff.combine_theta(theta), L, int(vL.ind_len)))
+    save('percall_hubbard.pkl', out)
+
+
+def gen_percall_tebd():
+    """complex blocks of BASELINE config 5 (real-time TEBD, TFI chain with parity): the calls of one bond update
+    of ``TEBDEngine.update_bond`` (algorithms/tebd.py:416-470) on seeded complex operands -- gate application
+    ``tensordot(U_bond, theta)``, ``combine_legs``, complex block ``svd`` (singular values), the new-B contraction --
+    record 0 on the legs of a REAL quench state at chi = 64, record 1 with every bond sector 16 times as wide (chi = 1024:
+    two 1024 x 1024 complex blocks, the block-SVD-bound case)."""
+    from tenpy.algorithms import tebd
+    from tenpy.models.tf_ising import TFIChain
+    from tenpy.networks.mps import MPS
+    L = 16
+    M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': 'parity', 'sort_charge': True})
+    psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
+    eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 30, 'trunc_params': {'chi_max': 64, 'svd_min': 1.e-12}})
+    eng.run()
+    i = L // 2
+    th_real = psi.get_theta(i - 1, n=2)                      # vL, p0, p1, vR
+    site = M.lat.mps_sites()[i]
+    out = []
+    for factor in (1, 16):
+        vL = _scaled_leg(th_real.get_leg('vL'), factor)
+        vR = _scaled_leg(th_real.get_leg('vR'), factor)
+        theta = seeded_array([vL, site.leg, site.leg, vR], 31, cplx=True, labels=['vL', 'p0', 'p1', 'vR'])
+        gate = seeded_array([site.leg, site.leg, site.leg.conj(), site.leg.conj()], 32, cplx=True, labels=['p0', 'p1', 'p0*', 'p1*'])
+        rec = dict(chi=int(vL.ind_len), legs_theta=[dump_leg(l) for l in theta.legs], labels_theta=theta.get_leg_labels(),
+                   legs_gate=[dump_leg(l) for l in gate.legs], labels_gate=gate.get_leg_labels(),
+                   operands=dict(theta=probe_array(theta, 1), gate=probe_array(gate, 2)))
+        t = npc.tensordot(gate, theta, axes=(['p0*', 'p1*'], ['p0', 'p1']))          # tebd.py:441
+        rec['gate_theta'] = probe_array(t, 3)
+        tc = t.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])              # tebd.py:442
+        rec['combined'] = probe_array(tc, 4)
+        rec['norm'] = float(npc.norm(tc))
+        U, S, VH = npc.svd(tc, inner_labels=['vR', 'vL'])
+        rec['svd_S'] = np.array(S)
+        rec['svd_U_qdata'], rec['svd_VH_qdata'] = np.array(U._qdata), np.array(VH._qdata)
+        rec['inner'] = complex(npc.inner(tc, tc, axes='range', do_conj=True))
+        Bn = npc.tensordot(theta.conj(), t, axes=(['vL*', 'p0*'], ['vL', 'p0']))       # a contraction with conj(), as in tebd.py:463
+        rec['conj_contract'] = probe_array(Bn, 5)
+        print('percall_tebd', rec['chi'], [l['slices'][-1] for l in rec['legs_theta']], len(S))
+        out.append(rec)
+    save('percall_tebd.pkl', out)
+
+
+def gen_eig_svd():
+    """``truncation._eig_based_svd`` (linalg/truncation.py:473-530, the reference's "performs better on GPU" route used by the
+    QR-based TEBD, tebd.py:685): singular values, truncation error, renormalisation and the projectors U U^dagger / Vd^dagger Vd
+    (the phases of U / Vd are arbitrary) for real and complex block matrices, with and without truncation."""
+    out = []
+    ch = charges.ChargeInfo([1], ['2Sz'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for cplx in (False, True):
+            for seed, (m, n) in enumerate(((24, 30), (40, 17), (33, 33))):
+                lL, lR = rand_leg(ch, m, 1), rand_leg(ch, n, -1)
+                A = rand_array([lL, lR], cplx=cplx, labels=['a', 'b'])
+                # (need_U = need_Vd = False contracts the wrong axes in the reference, truncation.py:511/:513, and raises: not pinned)
+                for need_U, need_Vd in ((True, False), (False, True)):
+                    for tp in (None, {'chi_max': 9, 'svd_min': 1.e-8}):
+                        U, S, Vd, err, ren = truncation._eig_based_svd(A, need_U=need_U, need_Vd=need_Vd, inner_labels=['x', 'y'],
+                                                                       trunc_params=tp)
+                        rec = dict(A=dump_array(A), need_U=need_U, need_Vd=need_Vd, trunc=tp, S=np.array(S), eps=float(err.eps),
+                                   renormalize=float(ren))
+                        if U is not None:
+                            rec['UUh'] = npc.tensordot(U, U.conj(), axes=['x', 'x*']).to_ndarray()
+                            rec['U_labels'] = U.get_leg_labels()
+                        if Vd is not None:
+                            rec['VhV'] = npc.tensordot(Vd.conj(), Vd, axes=['y*', 'y']).to_ndarray()
+                            rec['Vd_labels'] = Vd.get_leg_labels()
+                        out.append(rec)
+    save('eig_svd.pkl', out)
+
+
+GENERATORS = dict(percall_hubbard=gen_percall_hubbard, percall_tebd=gen_percall_tebd, eig_svd=gen_eig_svd, midsize=gen_midsize, percall=gen_percall, percall2048=gen_percall2048, api2=gen_api2, krylov2=gen_krylov2, hubbard=gen_hubbard, charges=gen_charges, tensordot=gen_tensordot,
                   reshape=gen_reshape, linalg=gen_linalg, truncate=gen_truncate, lanczos=gen_lanczos, dmrg=gen_dmrg, tebd=gen_tebd,
                   qr_theta=gen_qr_theta)
 

@@ -12,9 +12,13 @@ from helpers import golden, load_leg
 from tenpy_amd.linalg import np_conserved as npc
 
 
-def seeded_array(legs, seed, labels):
+def seeded_array(legs, seed, labels, cplx=False):
     r = np.random.RandomState(seed)
-    a = npc.Array.from_func(lambda size: r.standard_normal(size), legs, dtype=np.float64, qtotal=None, shape_kw='size')
+
+    def f(size):
+        x = r.standard_normal(size)
+        return x + 1.j * r.standard_normal(size) if cplx else x
+    a = npc.Array.from_func(f, legs, dtype=np.complex128 if cplx else np.float64, qtotal=None, shape_kw='size')
     return a.iset_leg_labels(labels)
 
 
@@ -38,6 +42,59 @@ def check(a, fp, tol=1e-12):
 @pytest.mark.parametrize("idx", [0, 1], ids=['chi64', 'chi512'])
 def test_percall_vs_reference(backend, idx):
     _percall(golden('percall.pkl')[idx])
+
+
+def test_percall_hubbard_chi256(backend):
+    """BASELINE config 4 regime: legs of a real Fermi-Hubbard-ladder state (charges (N, Sz)) at chi = 256: 23 bond
+    sectors, ~300 blocks per H_eff half, ~10^3 GEMMs per tensordot."""
+    _percall(golden('percall_hubbard.pkl')[0])
+
+
+@pytest.mark.gpu
+def test_percall_hubbard_chi1024_structure():
+    """The same charge sectors 4 times as wide (block structure of the chi = 1024 ladder, fused theta 4096 x 4096)."""
+    from tenpy_amd import _lib
+    _lib.require_gpu()
+    npc._plan_cache.clear()
+    _percall(golden('percall_hubbard.pkl')[1])
+    npc._plan_cache.clear()
+
+
+def test_percall_tebd_complex_chi64(backend):
+    """BASELINE config 5 (complex128): one TEBD bond update on seeded complex operands, legs of a real quench state."""
+    _percall_tebd(golden('percall_tebd.pkl')[0])
+
+
+@pytest.mark.gpu
+def test_percall_tebd_complex_chi1024_structure():
+    """Bond sectors 16 times as wide: two ~800 x 800 complex blocks per theta (the block-SVD-bound case of config 5)."""
+    from tenpy_amd import _lib
+    _lib.require_gpu()
+    npc._plan_cache.clear()
+    _percall_tebd(golden('percall_tebd.pkl')[1])
+    npc._plan_cache.clear()
+
+
+def _percall_tebd(rec):
+    theta = seeded_array([load_leg(l) for l in rec['legs_theta']], 31, rec['labels_theta'], cplx=True)
+    gate = seeded_array([load_leg(l) for l in rec['legs_gate']], 32, rec['labels_gate'], cplx=True)
+    check(theta, rec['operands']['theta'], tol=1e-15)
+    check(gate, rec['operands']['gate'], tol=1e-15)
+    t = npc.tensordot(gate, theta, axes=(['p0*', 'p1*'], ['p0', 'p1']))
+    check(t, rec['gate_theta'])
+    tc = t.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])
+    check(tc, rec['combined'])
+    assert abs(npc.norm(tc) - rec['norm']) <= 1e-13 * rec['norm']
+    U, S, VH = npc.svd(tc, inner_labels=['vR', 'vL'])
+    np.testing.assert_array_equal(U._qdata, rec['svd_U_qdata'])
+    np.testing.assert_array_equal(VH._qdata, rec['svd_VH_qdata'])
+    assert len(S) == len(rec['svd_S'])
+    np.testing.assert_allclose(S, rec['svd_S'], rtol=0, atol=1e-10 * rec['svd_S'].max())
+    rebuilt = npc.tensordot(U.scale_axis(S, 'vR'), VH, axes=['vR', 'vL'])
+    assert npc.norm(rebuilt - tc) <= 1e-12 * rec['norm']
+    assert abs(npc.inner(tc, tc, axes='range', do_conj=True) - rec['inner']) <= 1e-12 * abs(rec['inner'])
+    Bn = npc.tensordot(theta.conj(), t, axes=(['vL*', 'p0*'], ['vL', 'p0']))
+    check(Bn, rec['conj_contract'])
 
 
 @pytest.mark.gpu
