@@ -61,6 +61,9 @@ def parse():
     ap.add_argument('--lanczos-N', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-bonds', type=int, default=2)
+    ap.add_argument('--qr', action='store_true', help="tebd1024: QR-based truncation (decompose_theta_qr_based, reference "
+                    "algorithms/tebd.py:685) instead of the block SVD of theta")
+    ap.add_argument('--eig-svd', action='store_true', help="with --qr: _eig_based_svd for the bond matrix (truncation.py:473)")
     return ap.parse_args()
 
 
@@ -234,7 +237,7 @@ def build_dmrg(args, world, name):
 def build_tebd(args):
     """Random right-canonical MPS at the full bond dimension (two parity sectors of chi/2 each, complex128) so that the
     timed evolve_step runs at saturated chi from the first step, as BASELINE config 5 specifies."""
-    from tenpy_amd.algorithms.tebd import TEBDEngine
+    from tenpy_amd.algorithms.tebd import QRBasedTEBDEngine, TEBDEngine
     from tenpy_amd.models.spin_chains import spin_half_leg
     from tenpy_amd.networks.mps import MPS
     L, chi = args.L, args.chi
@@ -247,6 +250,9 @@ def build_tebd(args):
         gr = g if i == L - 1 else g / 2
         h_bonds.append((-J * np.kron(sx, sx) - gl * np.kron(sz, I2) - gr * np.kron(I2, sz)).reshape(2, 2, 2, 2))
     psi = random_right_canonical_mps(p, L, chi, np.complex128, seed=1)
+    if args.qr:     # the reference's GPU-motivated route -- QR of theta Y0 instead of the SVD of theta
+        return QRBasedTEBDEngine(psi, h_bonds, {'dt': 0.05, 'compute_err': True, 'cbe_expand': 0.1, 'use_eig_based_svd': bool(args.eig_svd),
+                                                'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
     return TEBDEngine(psi, h_bonds, {'dt': 0.05, 'compute_err': False, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
 
 
@@ -408,6 +414,12 @@ def main():
                           "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge "
                                                                     "blocks distributed (LPT + all-gather), env update replicated" % world},
                "prep_s": t_prep, "roofline": roof_svd, "roofline_gemm": roof_gemm, "energy_err": None}
+        if is_tebd:
+            out["tebd_route"] = ("QR-based truncation (decompose_theta_qr_based%s)" % (" + _eig_based_svd" if args.eig_svd else "")) if args.qr \
+                else "block SVD of theta (svd_theta)"
+            out["trunc_err_eps"] = float(eng.trunc_err.eps)
+            out["norm"] = float(eng.norm)
+            out["S_mid_entropy"] = float(-np.sum(np.asarray(eng.psi.get_SL(L // 2)) ** 2 * np.log(np.asarray(eng.psi.get_SL(L // 2)) ** 2 + 1e-300)))
         if not is_tebd:
             out["E"] = eng.sweep_stats['E'][-1]
             out["chi_reached"] = eng.sweep_stats['max_chi'][-1]

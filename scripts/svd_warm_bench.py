@@ -43,8 +43,14 @@ if os.environ.get('STAGES'):
     wrap(npc, '_svd_clean_small')
     wrap(npc, '_svd_warm_store')
 rng = np.random.RandomState(0)
+ALWAYS = bool(os.environ.get('ALWAYS_PERTURB'))
+base_arena = a._arena.clone()
 for rep in range(int(os.environ.get('REPS', 4))):
-    if rep == 2 and os.environ.get('PERTURB'):      # a slightly different matrix in the same row space
+    if ALWAYS and rep > 0:      # a different full-rank perturbation before every call: every warm attempt finds a stale basis
+        a = a.copy()
+        a._arena = base_arena * (1. + float(os.environ.get('PERTURB', 1e-9)) * torch.randn_like(base_arena))
+        sw.cooldown.clear()
+    if rep == 2 and os.environ.get('PERTURB') and not ALWAYS:      # a slightly different matrix in the same row space
         eps = float(os.environ['PERTURB'])
         a2 = a.copy()
         rk = int(os.environ.get('PRANK', 0))
@@ -61,6 +67,13 @@ for rep in range(int(os.environ.get('REPS', 4))):
     for k in sw.stats:
         sw.stats[k] = 0
     npc.svd_hint = ('bench', os.environ.get('SIDE', 'R'))
+    if os.environ.get('BURST'):      # a burst of MFMA work before the (latency-bound) SVD: does the clock / power state matter?
+        n = 4096
+        if 'bx' not in globals():
+            bx = torch.randn(n * n, dtype=torch.float64, device='cuda')
+            by = torch.empty(n * n, dtype=torch.float64, device='cuda')
+        for _ in range(int(os.environ['BURST'])):
+            sw.raw_gemm(np.float64, np.array([[0, n, n, n, 0, n, 1, 0, n, 1, n, 0]]), bx, bx, by)
     torch.cuda.synchronize()
     t0 = time.time()
     U, S, VH = npc.svd(a)

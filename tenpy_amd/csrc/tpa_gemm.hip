@@ -23,10 +23,9 @@ struct Task {  // int64[8]
     int64_t c_off, m, n, ldc, link_begin, link_count, accumulate, pad;
 };
 
-constexpr int BK = 16;
-
-template <bool CPLX, int BM, int BN, int TM, int TN>
+template <bool CPLX, int BM, int BN, int TM, int TN, int BK_>
 struct Cfg {
+    static constexpr int BK = BK_;
     static constexpr int WM = BM / (TM * 16);
     static constexpr int WN = BN / (TN * 16);
     static constexpr int NT = WM * WN * 64;
@@ -37,14 +36,25 @@ struct Cfg {
     static constexpr int PLANES = CPLX ? 2 : 1;
     static constexpr int EA = BM * BK / NT;  // elements of A staged per thread per k-tile
     static constexpr int EB = BN * BK / NT;
+    static_assert(NT % BK == 0 && NT % BM == 0 && NT % BN == 0, "staging offsets must be affine in the element index");
 };
 
-template <bool CPLX, int BM, int BN, int TM, int TN>
-__global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN>::NT)) void gemm_chain_kernel(
+// What a thread needs to stage its share of one k-tile of one link: element r of the thread sits at
+// (global) base + r * gstep (+ k0 * kstep), (LDS) lbase + r * lstep; its k index inside the tile is kk0 + r * kkstep.
+// NT is a multiple of BK, BM and BN, so these are affine in r -- no per-element address arrays.
+struct Stage {
+    const double *p;      // advances by kstep per k-tile
+    int64_t gstep, kstep;
+    int lbase, lstep, kk0, kkstep;
+    int i0, istep, lim;   // row (A) / column (B) index of element r = i0 + r * istep, valid while < lim
+};
+
+template <bool CPLX, int BM, int BN, int TM, int TN, int BK_>
+__global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN, BK_>::NT)) void gemm_chain_kernel(
     const Task *__restrict__ tasks, const Link *__restrict__ links, const int4 *__restrict__ tiles,
     const double *__restrict__ Abase, const double *__restrict__ Bbase, double *__restrict__ Cbase) {
-    using C = Cfg<CPLX, BM, BN, TM, TN>;
-    constexpr int NT = C::NT, EA = C::EA, EB = C::EB, PL = C::PLANES;
+    using C = Cfg<CPLX, BM, BN, TM, TN, BK_>;
+    constexpr int NT = C::NT, EA = C::EA, EB = C::EB, PL = C::PLANES, BK = C::BK;
     constexpr int ES = CPLX ? 2 : 1;  // doubles per element
     __shared__ double lds[PL * (C::A_LDS + C::B_LDS)];
     double *As = lds;
@@ -69,114 +79,152 @@ __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN>::NT)) void gemm_chain_ke
     const int nl = (int)tk.link_count;
     const Link *lk = links + tk.link_begin;
 
-    for (int li = 0; li < nl; ++li) {
+    // ---- link state: `cur` is being multiplied out of LDS, `nxt` is what the register prefetch belongs to (the next k-tile
+    //      of the same link or the FIRST k-tile of the next link: the chain never drains its load pipeline at a link boundary)
+    struct LinkView {
+        Stage a, b;
+        int K, sa_i, sa_k, sb_j, sb_k;
+        double sgn_a, sgn_b;
+        int64_t oa[EA], ob[EB];      // element offsets (doubles) relative to a.p / b.p, fixed per link
+    };
+    auto open_link = [&](int li, LinkView &v) {
         const Link L = lk[li];
-        const int K = (int)L.k;
-        if (K <= 0) continue;
-        // ---- per-link setup: everything that does not depend on k0 ----------------------------
+        v.K = (int)L.k;
         const bool a_kfast = (L.a_ks == 1);
         const bool b_kfast = (L.b_ks == 1) && (L.b_ns != 1);
-        const double sgn_a = (CPLX && (L.flags & 1)) ? -1.0 : 1.0;
-        const double sgn_b = (CPLX && (L.flags & 2)) ? -1.0 : 1.0;
-        const int sa_i = a_kfast ? (BK + 1) : 1, sa_k = a_kfast ? 1 : (BM + C::PADA);
-        const int sb_j = b_kfast ? (BK + 1) : 1, sb_k = b_kfast ? 1 : (BN + C::PADB);
-        const double *Ap = Abase + ES * (L.a_off + (int64_t)row0 * L.a_rs);
-        const double *Bp = Bbase + ES * (L.b_off + (int64_t)col0 * L.b_ns);
-        const int64_t a_kstep = ES * (int64_t)BK * L.a_ks, b_kstep = ES * (int64_t)BK * L.b_ks;
-        int64_t offA[EA], offB[EB];   // element offsets (in doubles) of this thread's staged elements
-        int ldA[EA], ldB[EB];         // LDS positions
-        int kkA[EA], kkB[EB];         // k index inside the tile (for the tail k-tile)
-        bool okA[EA], okB[EB];        // row / column inside the block
+        v.sgn_a = (CPLX && (L.flags & 1)) ? -1.0 : 1.0;
+        v.sgn_b = (CPLX && (L.flags & 2)) ? -1.0 : 1.0;
+        v.sa_i = a_kfast ? (BK + 1) : 1;
+        v.sa_k = a_kfast ? 1 : (BM + C::PADA);
+        v.sb_j = b_kfast ? (BK + 1) : 1;
+        v.sb_k = b_kfast ? 1 : (BN + C::PADB);
+        {   // A: element e = tid + r NT;  k-fast: (i, kk) = (e / BK, e % BK);  else (e % BM, e / BM)
+            const int i = a_kfast ? (tid / BK) : (tid % BM), kk = a_kfast ? (tid % BK) : (tid / BM);
+            const int di = a_kfast ? (NT / BK) : 0, dk = a_kfast ? 0 : (NT / BM);
+            v.a.p = Abase + ES * (L.a_off + (int64_t)(row0 + i) * L.a_rs + (int64_t)kk * L.a_ks);
+            v.a.gstep = ES * ((int64_t)di * L.a_rs + (int64_t)dk * L.a_ks);
+            v.a.kstep = ES * (int64_t)BK * L.a_ks;
+            v.a.lbase = i * v.sa_i + kk * v.sa_k;
+            v.a.lstep = di * v.sa_i + dk * v.sa_k;
+            v.a.kk0 = kk;
+            v.a.kkstep = dk;
+            v.a.i0 = row0 + i;
+            v.a.istep = di;
+            v.a.lim = m;
+#pragma unroll
+            for (int r = 0; r < EA; ++r) v.oa[r] = r * v.a.gstep;
+        }
+        {
+            const int j = b_kfast ? (tid / BK) : (tid % BN), kk = b_kfast ? (tid % BK) : (tid / BN);
+            const int dj = b_kfast ? (NT / BK) : 0, dk = b_kfast ? 0 : (NT / BN);
+            v.b.p = Bbase + ES * (L.b_off + (int64_t)kk * L.b_ks + (int64_t)(col0 + j) * L.b_ns);
+            v.b.gstep = ES * ((int64_t)dk * L.b_ks + (int64_t)dj * L.b_ns);
+            v.b.kstep = ES * (int64_t)BK * L.b_ks;
+            v.b.lbase = kk * v.sb_k + j * v.sb_j;
+            v.b.lstep = dk * v.sb_k + dj * v.sb_j;
+            v.b.kk0 = kk;
+            v.b.kkstep = dk;
+            v.b.i0 = col0 + j;
+            v.b.istep = dj;
+            v.b.lim = n;
+#pragma unroll
+            for (int r = 0; r < EB; ++r) v.ob[r] = r * v.b.gstep;
+        }
+    };
+    double ra[PL][EA], rb[PL][EB];
+    auto load_tile = [&](LinkView &v, int k0) {      // registers <- k-tile k0 of link v; advances the link's pointers
+        const int krem = v.K - k0;  // >= 1
+        const bool full = (krem >= BK);
 #pragma unroll
         for (int r = 0; r < EA; ++r) {
-            const int e = tid + r * NT;
-            const int i = a_kfast ? (e / BK) : (e % BM);
-            const int kk = a_kfast ? (e % BK) : (e / BM);
-            offA[r] = ES * ((int64_t)i * L.a_rs + (int64_t)kk * L.a_ks);
-            ldA[r] = i * sa_i + kk * sa_k;
-            kkA[r] = kk;
-            okA[r] = (row0 + i < m);
+            const bool ok = (v.a.i0 + r * v.a.istep < v.a.lim) && (full || v.a.kk0 + r * v.a.kkstep < krem);
+            const double *q = v.a.p + v.oa[r];
+            if (CPLX) {
+                double2 x = ok ? *reinterpret_cast<const double2 *>(q) : double2{0, 0};
+                ra[0][r] = x.x;
+                ra[PL - 1][r] = v.sgn_a * x.y;
+            } else {
+                ra[0][r] = ok ? *q : 0.0;
+            }
         }
 #pragma unroll
         for (int r = 0; r < EB; ++r) {
-            const int e = tid + r * NT;
-            const int j = b_kfast ? (e / BK) : (e % BN);
-            const int kk = b_kfast ? (e % BK) : (e / BN);
-            offB[r] = ES * ((int64_t)kk * L.b_ks + (int64_t)j * L.b_ns);
-            ldB[r] = kk * sb_k + j * sb_j;
-            kkB[r] = kk;
-            okB[r] = (col0 + j < n);
+            const bool ok = (v.b.i0 + r * v.b.istep < v.b.lim) && (full || v.b.kk0 + r * v.b.kkstep < krem);
+            const double *q = v.b.p + v.ob[r];
+            if (CPLX) {
+                double2 x = ok ? *reinterpret_cast<const double2 *>(q) : double2{0, 0};
+                rb[0][r] = x.x;
+                rb[PL - 1][r] = v.sgn_b * x.y;
+            } else {
+                rb[0][r] = ok ? *q : 0.0;
+            }
         }
-        const double *Aw = As + (wr * TM * 16 + l15) * sa_i + l4 * sa_k;
-        const double *Bw = Bs + (wc * TN * 16 + l15) * sb_j + l4 * sb_k;
+        v.a.p += v.a.kstep;
+        v.b.p += v.b.kstep;
+    };
 
-        double ra[PL][EA], rb[PL][EB];
-        auto load_tile = [&](int k0) {
-            const int krem = K - k0;  // >= 1
-            const bool full = (krem >= BK);
+    int li = 0;
+    while (li < nl && lk[li].k <= 0) ++li;
+    if (li < nl) {
+        LinkView cur, nxt;
+        open_link(li, cur);
+        load_tile(cur, 0);
+        while (true) {
+            // the next non-empty link is opened BEFORE the k loop of this one, so that the last k-tile of this link can
+            // prefetch the first k-tile of the next (no drained load pipeline at a link boundary) while everything the k loop
+            // uses from `cur` (LDS strides, fragment addresses) stays loop-invariant
+            int lj = li + 1;
+            while (lj < nl && lk[lj].k <= 0) ++lj;
+            const bool has_next = lj < nl;
+            if (has_next) open_link(lj, nxt);
+            const int K = cur.K;
+            const int sa_i = cur.sa_i, sa_k = cur.sa_k, sb_j = cur.sb_j, sb_k = cur.sb_k;
+            const int la0 = cur.a.lbase, las = cur.a.lstep, lb0 = cur.b.lbase, lbs = cur.b.lstep;
+            const double *Aw = As + (wr * TM * 16 + l15) * sa_i + l4 * sa_k;
+            const double *Bw = Bs + (wc * TN * 16 + l15) * sb_j + l4 * sb_k;
+            for (int k0 = 0; k0 < K; k0 += BK) {
 #pragma unroll
-            for (int r = 0; r < EA; ++r) {
-                const bool ok = okA[r] && (full || kkA[r] < krem);
-                if (CPLX) {
-                    double2 v = ok ? *reinterpret_cast<const double2 *>(Ap + offA[r]) : double2{0, 0};
-                    ra[0][r] = v.x;
-                    ra[PL - 1][r] = sgn_a * v.y;
-                } else {
-                    ra[0][r] = ok ? Ap[offA[r]] : 0.0;
-                }
-            }
+                for (int r = 0; r < EA; ++r)
 #pragma unroll
-            for (int r = 0; r < EB; ++r) {
-                const bool ok = okB[r] && (full || kkB[r] < krem);
-                if (CPLX) {
-                    double2 v = ok ? *reinterpret_cast<const double2 *>(Bp + offB[r]) : double2{0, 0};
-                    rb[0][r] = v.x;
-                    rb[PL - 1][r] = sgn_b * v.y;
-                } else {
-                    rb[0][r] = ok ? Bp[offB[r]] : 0.0;
-                }
-            }
-            Ap += a_kstep;
-            Bp += b_kstep;
-        };
-
-        load_tile(0);
-        for (int k0 = 0; k0 < K; k0 += BK) {
+                    for (int p = 0; p < PL; ++p) As[p * C::A_LDS + la0 + r * las] = ra[p][r];
 #pragma unroll
-            for (int r = 0; r < EA; ++r)
+                for (int r = 0; r < EB; ++r)
 #pragma unroll
-                for (int p = 0; p < PL; ++p) As[p * C::A_LDS + ldA[r]] = ra[p][r];
+                    for (int p = 0; p < PL; ++p) Bs[p * C::B_LDS + lb0 + r * lbs] = rb[p][r];
+                __syncthreads();
+                if (k0 + BK < K)
+                    load_tile(cur, k0 + BK);      // prefetch the next k-tile into registers
+                else if (has_next)
+                    load_tile(nxt, 0);            // ... or the first k-tile of the next link
 #pragma unroll
-            for (int r = 0; r < EB; ++r)
+                for (int ks = 0; ks < BK / 4; ++ks) {
+                    double a[PL][TM], b[PL][TN];
 #pragma unroll
-                for (int p = 0; p < PL; ++p) Bs[p * C::B_LDS + ldB[r]] = rb[p][r];
-            __syncthreads();
-            if (k0 + BK < K) load_tile(k0 + BK);  // prefetch the next k-tile into registers
+                    for (int p = 0; p < PL; ++p) {
 #pragma unroll
-            for (int ks = 0; ks < BK / 4; ++ks) {
-                double a[PL][TM], b[PL][TN];
+                        for (int i = 0; i < TM; ++i) a[p][i] = Aw[p * C::A_LDS + i * 16 * sa_i + ks * 4 * sa_k];
 #pragma unroll
-                for (int p = 0; p < PL; ++p) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[p][i] = Aw[p * C::A_LDS + i * 16 * sa_i + ks * 4 * sa_k];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[p][j] = Bw[p * C::B_LDS + j * 16 * sb_j + ks * 4 * sb_k];
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (CPLX) {
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[PL - 1][i], b[PL - 1][j], acc[0][i][j], 0, 0, 0);
-                            acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[PL - 1][j], acc[PL - 1][i][j], 0, 0, 0);
-                            acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[PL - 1][i], b[0][j], acc[PL - 1][i][j], 0, 0, 0);
-                        } else {
-                            acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
-                        }
+                        for (int j = 0; j < TN; ++j) b[p][j] = Bw[p * C::B_LDS + j * 16 * sb_j + ks * 4 * sb_k];
                     }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if (CPLX) {
+                                acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
+                                acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[PL - 1][i], b[PL - 1][j], acc[0][i][j], 0, 0, 0);
+                                acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[PL - 1][j], acc[PL - 1][i][j], 0, 0, 0);
+                                acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[PL - 1][i], b[0][j], acc[PL - 1][i][j], 0, 0, 0);
+                            } else {
+                                acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
+                            }
+                        }
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            if (!has_next) break;
+            cur = nxt;
+            li = lj;
         }
     }
 
@@ -233,11 +281,11 @@ extern "C" int tpa_gemm_tile_shape(int dtype, int cfg, int *bm, int *bn) {
     return 0;
 }
 
-template <bool CPLX, int BM, int BN, int TM, int TN>
+template <bool CPLX, int BM, int BN, int TM, int TN, int BK_>
 static void launch(const int64_t *tasks_dev, const int64_t *links_dev, const int32_t *tiles_dev, int n_tiles,
                    const void *Abase, const void *Bbase, void *Cbase, hipStream_t st) {
-    using C = Cfg<CPLX, BM, BN, TM, TN>;
-    gemm_chain_kernel<CPLX, BM, BN, TM, TN><<<n_tiles, C::NT, 0, st>>>(
+    using C = Cfg<CPLX, BM, BN, TM, TN, BK_>;
+    gemm_chain_kernel<CPLX, BM, BN, TM, TN, BK_><<<n_tiles, C::NT, 0, st>>>(
         (const Task *)tasks_dev, (const Link *)links_dev, (const int4 *)tiles_dev, (const double *)Abase,
         (const double *)Bbase, (double *)Cbase);
 }
@@ -250,17 +298,19 @@ extern "C" int tpa_gemm_chain(int dtype, int cfg, const int64_t *tasks_dev, cons
     if (n_tiles <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == TPA_F64) {
-        if (cfg == 1)
-            launch<false, 64, 64, 2, 2>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
-        else if (g_large_variant == 1)
-            launch<false, 128, 128, 4, 2>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        if (cfg == 1 && (g_large_variant & 2))
+            launch<false, 64, 64, 2, 2, 32>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (cfg == 1)
+            launch<false, 64, 64, 2, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (g_large_variant & 1)
+            launch<false, 128, 128, 4, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else
-            launch<false, 128, 128, 4, 4>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+            launch<false, 128, 128, 4, 4, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
     } else {
         if (cfg == 1)
-            launch<true, 64, 32, 2, 1>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+            launch<true, 64, 32, 2, 1, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else
-            launch<true, 128, 64, 4, 2>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+            launch<true, 128, 64, 4, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
     }
     TPA_LAUNCH_CHECK();
     return 0;

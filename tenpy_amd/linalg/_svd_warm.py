@@ -132,13 +132,13 @@ def lowdin_rows(dtype, arena, off, nvec, length, vs, cs, iterations=1):
     t_off = np.concatenate([[0], np.cumsum(nvec * length)])
     z = np.zeros(len(off), dtype=np.int64)
     one = z + 1
-    T = dev.empty(int(t_off[-1]), dtype)
+    T = dev.scratch('lowdin_T', int(t_off[-1]), dtype)
     raw_copy(dtype, copy_jobs_2d(t_off[:-1], length, one, off, vs, cs, nvec, length), arena, T)
     for _ in range(iterations):
-        G = dev.empty(int(g_off[-1]), dtype)
+        G = dev.scratch('lowdin_G', int(g_off[-1]), dtype)
         raw_gemm(dtype, np.stack([g_off[:-1], nvec, nvec, nvec, t_off[:-1], length, one, t_off[:-1], one, length, length,
                                   z + (2 if cplx else 0)], axis=1), T, T, G)
-        T2 = dev.empty(int(t_off[-1]), dtype)
+        T2 = dev.scratch('lowdin_T2', int(t_off[-1]), dtype)
         raw_gemm(dtype, np.stack([t_off[:-1], nvec, length, length, g_off[:-1], nvec, one, t_off[:-1], length, one, nvec, z], axis=1), G, T, T2)
         _scal(dtype, 1.5, T)
         _axpy(dtype, -0.5, T2, T)
@@ -255,10 +255,11 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
     def residual(bar, boff, bk, sel):
         """W = Bq X^H for all active blocks;  E = A - (part spanned by the basis) and |E_b|_F^2 for the blocks ``sel``."""
         w_off = np.concatenate([[0], np.cumsum(bk * p)])
-        W = dev.empty(int(w_off[-1]), dtype)
+        W = dev.scratch('warm_W', int(w_off[-1]), dtype)
         # A(i, l) = Bq[i][l];  B(l, j) = conj(X[j][l])
         raw_gemm(dtype, np.stack([w_off[:-1], bk, p, p, boff, l, one, o, x_cs, x_rs, l, z + conjB], axis=1), bar, a_arena, W)
-        P = dev.zeros(a_arena.numel(), dtype)
+        P = dev.scratch('warm_P', a_arena.numel(), dtype)
+        dev.check(dev.lib().tpa_fill_zero(P.data_ptr(), int(P.numel()) * P.element_size(), dev.stream()), "fill_zero")
         t = sel
         if R:       # A = W^H Bq
             raw_gemm(dtype, np.stack([o[t], m[t], n[t], n[t], w_off[:-1][t], one[t], p[t], boff[t], l[t], one[t], bk[t], z[t] + conjA], axis=1),
@@ -266,7 +267,8 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
         else:       # A = X^T = Bq^T conj(W)
             raw_gemm(dtype, np.stack([o[t], m[t], n[t], n[t], boff[t], one[t], l[t], w_off[:-1][t], p[t], one[t], bk[t], z[t] + conjB], axis=1),
                      bar, W, P)
-        E = dev.clone(a_arena)
+        E = dev.scratch('warm_E', a_arena.numel(), dtype)
+        E.copy_(a_arena)
         _axpy(dtype, -1.0, P, E)
         return W, w_off, E, _row_norms_sq(dtype, E, o[t], m[t], n[t])
 
@@ -297,16 +299,16 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
     jjobs[:, 0], jjobs[:, 1], jjobs[:, 2] = w_off[:-1][sel], kq, p
     jjobs[:, 3], jjobs[:, 4], jjobs[:, 5] = ju_off[:-1], js_off[:-1], jv_off[:-1]
     jjobs[:, 6] = 1                       # square blocks: orthogonalise the rows
-    JU = dev.empty(int(ju_off[-1]), dtype)
-    JV = dev.empty(int(jv_off[-1]), dtype)
-    JS = dev.empty(int(js_off[-1]), np.float64)
+    JU = dev.scratch('warm_JU', int(ju_off[-1]), dtype)
+    JV = dev.scratch('warm_JV', int(jv_off[-1]), dtype)
+    JS = dev.scratch('warm_JS', int(js_off[-1]), np.float64)
     S_J = run_svd(jjobs, W, JU, JS, JV, False)
     if S_J is None:
         stats['fb_svd'] += len(sel)
         return done, S_out
     # ---- outputs.  W = U' S VH'  ->  X = VH'^H S (U'^H Bc);  Z = U'^H Bc (k x len) is the accumulated basis
     zb_off = np.concatenate([[0], np.cumsum(kq * l)])
-    Z = dev.empty(int(zb_off[-1]), dtype)
+    Z = dev.scratch('warm_Z', int(zb_off[-1]), dtype)
     raw_gemm(dtype, np.stack([zb_off[:-1], kq, l, l, ju_off[:-1], one, kq, bq_off[sel], l, one, kq, z + conjA], axis=1), JU, bq_arena, Z)
     if lowdin_basis:
         lowdin_rows(dtype, Z, zb_off[:-1], kq, l, l, one, iterations=1)

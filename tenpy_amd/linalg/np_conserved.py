@@ -2389,7 +2389,7 @@ def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, swe
     """One batched device SVD with the fallback chain; returns the singular values on the host."""
     chain = SVD_ALGORITHM_CHAIN if chain is None else chain
     wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
-    work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
+    work = dev.scratch('svd_work', int(wb), np.uint8)
     tried = []
     last_err = None
     for hop, alg in enumerate(chain):
@@ -2548,7 +2548,7 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
         _svd_warm.stats['fallbacks'] += 1
         # try again after a few visits: the residual of a converging state shrinks by roughly a decade per sweep
         e = _svd_warm.stats.get('e_rel_last', 1.)
-        _svd_warm.cooldown[key] = int(min(6, max(0, np.ceil(np.log10(max(e, 1e-300) / _svd_warm.E_TOL) / 1.5))))
+        _svd_warm.cooldown[key] = int(min(3, max(0, np.ceil(np.log10(max(e, 1e-300) / _svd_warm.E_TOL) / 2.5) - 1)))
         svd_timer.end(ev, _Work(0., 0.) if ev is not None else None)
         return None
     S_host = np.zeros(int(s_offs[-1]), dtype=np.float64)
