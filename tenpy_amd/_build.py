@@ -16,7 +16,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["tpa_gemm.hip", "tpa_vec.hip", "tpa_copy.hip", "tpa_svd.hip", "tpa_qr.hip", "tpa_util.hip",
            "tpa_plan.cpp"]
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("TPA_BUILD_FLAGS", "").split()
 
 
 def _newer(src_list, target):
