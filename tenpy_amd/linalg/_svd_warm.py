@@ -11,9 +11,10 @@ near convergence (left-moving: the columns of A_i).  With such a basis ``Bq`` (k
     E  = X - W^H Bq                                       what the basis misses; usually ~ eps |X|
 
 the one-sided Jacobi runs directly on the rows of W: no rank-revealing QR, and the iteration starts in its quadratic phase
-for the large singular values.  If E is not negligible a (cheap: low-rank) cold SVD of E supplies the missing directions,
-re-orthogonalised against ``Bq`` ("twice is enough") and appended.  The iteration still runs to the same stopping rule, so
-the result is as exact as the cold path: X = VH'^H S (U'^H Bc) with W = U' S VH'.
+for the large singular values.  The warm path is taken only when EVERY charge block of the call has |E|_F <= E_TOL |X|_F
+(rounding level: the cold path's rank cut discards as much); otherwise the whole call goes the cold way (see
+``svd_blocks_warm`` for what was tried to rescue such calls).  The iteration runs to the same stopping rule, so the result
+is as exact as the cold path: X = VH'^H S (U'^H Bq) with W = U' S VH'.
 
 The same file holds the first-order Loewdin clean-up ``lowdin_rows`` (V <- (3 I - V V^H) V / 2) that restores machine
 precision orthonormality of (i) the singular vectors below the absolute floor of the stopping rule, whose mutual angles are

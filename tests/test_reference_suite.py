@@ -71,7 +71,7 @@ def test_reference_linalg_tests_on_mirror(args, where):
         # (test_truncation.py:91).  With sigma = sqrt(|eigh(A A^dagger)|) that saturation is produced by the rounding noise of
         # LAPACK's eigenvalues of the null space (~1e-8 after the square root, above svd_min = 1e-12); the device eigh leaves a
         # different noise pattern and chi reaches 25 in the same 15 steps (scripts/dbg_qr_eig.py).  The decomposition itself is
-        # pinned by tests/test_eig_svd.py[gpu] and tests/test_qr_theta.py[gpu]; on the device the SVD flavour of the case runs.
+        # pinned by tests/test_eig_svd.py[gpu] and tests/test_qr_theta_golden.py[gpu]; on the device the SVD flavour of the case runs.
         args = ['test_truncation.py', '-k', 'truncate or (decompose and 45-True-parity-False)']
     out = run_reference_tests(args)
     assert ' passed' in out and ' failed' not in out
