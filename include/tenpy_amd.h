@@ -87,6 +87,29 @@ int tpa_lanczos_update(int dtype, int64_t n, void *w_dev, double alpha_re, doubl
 int tpa_lanczos_step(int dtype, int64_t n, void *w_dev, const void *v1_dev, const void *v0_dev,
                      const double *bsq_prev_dev, double *ab_out_dev, double *scratch_dev, void *stream);
 
+/* LanczosGroundState.run as ONE host call (krylov_based.py:645-700 `_build_krylov`; the caller keeps the reference's host
+ * logic -- tridiagonal eigh :702, `_converged` :713 -- in `cb`).  The matvec is a replayed "program" of cached launches:
+ *   ops : HOST int64[n_ops][12] = {kind, cfg, p0, p1, p2, count, a_slot, b_slot, c_slot, max_elems, 0, 0}
+ *         kind 0: tpa_gemm_chain(dtype, cfg, tasks = p0, links = p1, tiles = p2, n_tiles = count, A, B, C)
+ *         kind 1: tpa_lincomb_batch(dtype, jobs = p0, n_jobs = count, terms = p1, max_elems, src = A, dst = C)
+ *         slots: >= 0 -> bufs[slot] (HOST array of n_bufs device pointers: fixed operands and temporaries), -1 -> the input
+ *         vector v_k, -2 -> the output vector w of this matvec.  (p0..p2 are device pointers stored as integers.)
+ *   krylov_dev : (N_max + 1) * n elements; on return vectors 0 .. N-1 are the orthonormal Krylov basis (v_0 = psi0 / |psi0|).
+ *   scalars_dev: 2 * (N_max + 2) doubles.  Per step k:  w = matvec(v_k) [+ E_shift v_k];  tpa_lanczos_step;  (alpha_k, beta_k^2)
+ *   are posted to mapped host memory and `cb(k, alpha_k, beta_k^2, user)` is called ONE STEP LATE, while step k + 1 already runs
+ *   on the device; a nonzero return stops the iteration after step k (N = k + 1; the step in flight is discarded).
+ *   info (HOST double[4]) = {N, number of matvecs launched, summed GEMM time in ms if time_gemms else 0, |psi0|};
+ *   N = 0 <=> |psi0| < cutoff (nothing useful was computed).                                                          */
+typedef int (*tpa_lanczos_callback)(int step, double alpha, double beta_sq, void *user);
+int tpa_lanczos_run(int dtype, int64_t n, const int64_t *ops, int n_ops, void *const *bufs, int n_bufs,
+                    void *krylov_dev, const void *psi0_dev, int N_max, double cutoff, int has_shift, double E_shift,
+                    double *scalars_dev, double *scratch_dev, tpa_lanczos_callback cb, void *user,
+                    int time_gemms, double *info, void *stream);
+/* out = sum_{k < N} coeff[k] v_k over the Krylov basis of tpa_lanczos_run (N <= 64, real coefficients: the eigenvector of
+ * the tridiagonal matrix), norm_host[0] = |out| (blocking): `_calc_result_full`, krylov_based.py:223-236, in one pass. */
+int tpa_krylov_combine(int dtype, int64_t n, const void *krylov_dev, int N, const double *coeff, void *out_dev,
+                       double *red_out_dev, double *scratch_dev, double *norm_host, void *stream);
+
 /* ---- K8/K9/K10: data movement ---------------------------------------------------------
  * Generic strided N-d block copy (N <= TPA_COPY_MAXDIM), batched.  Replaces
  * _sliced_strided_copy/_sliced_copy (_npc_helper.pyx:368, :754; combine/split legs :1112-1123,

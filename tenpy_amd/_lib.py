@@ -19,6 +19,7 @@ _lib = None
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
+LANCZOS_CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p)
 _SIGS = {
     "tpa_version": (ctypes.c_int, []),
     "tpa_last_error": (ctypes.c_char_p, []),
@@ -33,6 +34,9 @@ _SIGS = {
     "tpa_lanczos_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_double, ctypes.c_double, _vp,
                                           ctypes.c_double, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "tpa_lanczos_step": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tpa_lanczos_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_int, ctypes.c_double, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
+    "tpa_krylov_combine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpa_copy_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]),
     "tpa_lincomb_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     "tpa_scale_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp]),

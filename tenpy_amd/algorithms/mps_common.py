@@ -322,13 +322,15 @@ class MpoApplyPlan:
         self.x_key = X._struct_key()
         self.bytes = 8 * (2 if self.dtype.kind == 'c' else 1) * (self.total + int(np.sum(sizes_x[ib])))
 
-    def apply(self, X):
+    def apply(self, X, launch=True):
         res = npc.Array(self.legs, self.dtype, self.qtotal, self.labels)
         if self.empty:
             return res
         if X.dtype != self.dtype:
             X = X.astype(self.dtype)
         res._set_blocks(self.qdata, arena=dev.empty(self.total, self.dtype), qdata_sorted=True)
+        if not launch:
+            return res
         dev.check(dev.lib().tpa_lincomb_batch(dev.code(self.dtype), self.jobs_dev.data_ptr(), self.n_jobs, self.terms_dev.data_ptr(),
                                               self.max_elems, X._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "lincomb")
         return res
@@ -518,6 +520,79 @@ class TwoSiteH:
             tmp = p1.apply(self.LHeff, theta)
             res = p2.apply(tmp, self.RHeff)
         res.iset_leg_labels(['(vL.p0)', '(p1.vR)'])
+        return res
+
+    def matvec_program(self, theta):
+        """The matvec as a replayable launch program for ``tpa_lanczos_run`` (include/tenpy_amd.h): ``(ops, bufs)`` with ``ops``
+        int64 ``[n_ops, 12]`` rows ``(kind, cfg, p0, p1, p2, count, a_slot, b_slot, c_slot, max_elems, 0, 0)`` and ``bufs`` the
+        list of device tensors the non-negative slots refer to (operands first, then temporaries from the scratch pool);
+        slot -1 = input vector, -2 = output vector.  ``None`` when the matvec cannot be replayed on raw arenas: vector not
+        in the operator's own leg order, mixed dtypes, or an output block structure different from the input's (the first
+        steps from a product state, where H creates blocks)."""
+        want = ['vL', 'p0', 'p1', 'vR'] if self.factored else ['(vL.p0)', '(p1.vR)']
+        if list(theta.get_leg_labels()) != want or theta.stored_blocks == 0 or not theta._is_packed():
+            return None
+        key = (theta._struct_key(), theta.dtype)
+        prog = self.__dict__.get('_program')
+        if prog is not None and prog[0] == key:
+            return prog[1]
+        res = None
+        if self.factored:
+            fp = self._fplans
+            if fp is None or fp['key'] != theta._struct_key() or fp['dtype'] != theta.dtype:
+                p1, l_use, t_use = npc.plan_tensordot(self._LPf, theta, axes=['vR', 'vL'])
+                if l_use is not self._LPf or t_use is not theta or p1.empty:
+                    return None
+                T1 = p1.apply(self._LPf, theta, launch=False)
+                a01 = MpoApplyPlan.get(T1, self.W0, 'wR', 'p0', 'wL', 'wR', 'p0', 'p0*', ('vR*', 'p0', 'p1', 'wR', 'vR'),
+                                       W2=self.W1, x_p2='p1', p2_out='p1', p2_in='p1*')
+                if a01.empty:
+                    return None
+                T3 = a01.apply(T1, launch=False)
+                p2, t3_use, r_use = npc.plan_tensordot(T3, self._RPf, axes=(['wR', 'vR'], ['wL', 'vL']))
+                if t3_use is not T3 or r_use is not self._RPf or p2.empty:
+                    return None
+                self._fplans = fp = dict(key=theta._struct_key(), dtype=theta.dtype, p1=p1, a01=a01, p2=p2)
+                self.flops_per_matvec = p1.flops + p2.flops
+                self.bytes_per_matvec = p1.bytes_min + p2.bytes_min + a01.bytes
+                self.gemm_shapes = (p1.gemm_shapes, p2.gemm_shapes)
+            p1, a01, p2 = fp['p1'], fp['a01'], fp['p2']
+            ok = (p1.dtype == a01.dtype == p2.dtype == theta.dtype == self._LPf.dtype == self._RPf.dtype and not p1.empty and
+                  not p2.empty and not a01.empty)
+            if ok:
+                bufs = [self._LPf._arena, self._RPf._arena, dev.scratch('lanczos_t1', p1.res_total, p1.dtype),
+                        dev.scratch('lanczos_t3', a01.total, a01.dtype)]
+                ops = np.zeros((3, 12), dtype=np.int64)
+                ops[0, :9] = [0, p1.cfg, p1.tasks_dev.data_ptr(), p1.links_dev.data_ptr(), p1.tiles_dev.data_ptr(), p1.n_tiles, 0, -1, 2]
+                ops[1, :10] = [1, 0, a01.jobs_dev.data_ptr(), a01.terms_dev.data_ptr(), 0, a01.n_jobs, 2, 0, 3, a01.max_elems]
+                ops[2, :9] = [0, p2.cfg, p2.tasks_dev.data_ptr(), p2.links_dev.data_ptr(), p2.tiles_dev.data_ptr(), p2.n_tiles, 3, 1, -2]
+                res = (ops, bufs, (p1, p2))
+                last = p2
+        else:
+            if self._plans is None or not self._plan_matches(theta):
+                p1, l_use, t_use = npc.plan_tensordot(self.LHeff, theta, axes=['(vR.p0*)', '(vL.p0)'])
+                if l_use is not self.LHeff or t_use is not theta or p1.empty:
+                    return None
+                tmp = p1.apply(self.LHeff, theta, launch=False)
+                p2, t2_use, r_use = npc.plan_tensordot(tmp, self.RHeff, axes=(['wR', '(p1.vR)'], ['wL', '(p1*.vL)']))
+                if t2_use is not tmp or r_use is not self.RHeff or p2.empty:
+                    return None
+                self._plans = (p1, p2, theta._struct_key(), theta.dtype)
+                self.flops_per_matvec = p1.flops + p2.flops
+                self.bytes_per_matvec = p1.bytes_min + p2.bytes_min
+                self.gemm_shapes = (p1.gemm_shapes, p2.gemm_shapes)
+            p1, p2 = self._plans[0], self._plans[1]
+            if p1.dtype == p2.dtype == theta.dtype == self.LHeff.dtype == self.RHeff.dtype and not p1.empty and not p2.empty:
+                bufs = [self.LHeff._arena, self.RHeff._arena, dev.scratch('lanczos_t1', p1.res_total, p1.dtype)]
+                ops = np.zeros((2, 12), dtype=np.int64)
+                ops[0, :9] = [0, p1.cfg, p1.tasks_dev.data_ptr(), p1.links_dev.data_ptr(), p1.tiles_dev.data_ptr(), p1.n_tiles, 0, -1, 2]
+                ops[1, :9] = [0, p2.cfg, p2.tasks_dev.data_ptr(), p2.links_dev.data_ptr(), p2.tiles_dev.data_ptr(), p2.n_tiles, 2, 1, -2]
+                res = (ops, bufs, (p1, p2))
+                last = p2
+        if res is not None and not (last.res_total == theta._arena.numel() and np.array_equal(last.res_qdata, theta._qdata)
+                                    and np.array_equal(last.res_offsets, theta._offsets)):
+            res = None
+        self.__dict__['_program'] = (key, res)
         return res
 
     def _plan_matches(self, theta):

@@ -7,6 +7,7 @@
 // Reductions are deterministic: pass 1 writes one partial per workgroup, pass 2 (one workgroup)
 // sums them in a fixed order.
 #include "tpa_common.h"
+#include <vector>
 
 namespace {
 
@@ -312,5 +313,211 @@ extern "C" int tpa_lanczos_step(int dtype, int64_t n, void *w, const void *v1, c
     const int64_t nd = cplx ? 2 * n : n;
     scal_rsqrt_dev_kernel<<<grid_for(nd, 8), NT, 0, st>>>(nd, (double *)w, ab_out + 1);
     TPA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ================================================================================================================
+// LanczosGroundState.run as ONE host call (reference krylov_based.py:645-700 `_build_krylov`, :223-240 `_calc_result_full`).
+//
+// Why: at chi <= 512 a bond update is bounded by host time, not by the kernels -- every Krylov step costs ~0.5 ms of
+// interpreter work (Array objects, argument checks, ctypes marshalling for the 2-3 launches of a matvec and the 5 of
+// the recurrence) against ~0.1 ms of kernels.  Here the host side of a step is a C++ loop: replay the matvec "program"
+// (the cached plans of TwoSiteH: grouped GEMM / block linear combination / grouped GEMM) on raw arenas, run the fused
+// recurrence with alpha, beta kept on the device, and hand (alpha, beta^2) of the PREVIOUS step to a callback that does
+// the reference's tridiagonal eigen-solve and stopping test (numpy.linalg.eigh, so that iteration counts and signs are
+// those of the reference) while the device is already busy with the next matvec.
+// ================================================================================================================
+namespace {
+
+constexpr int LZ_MAX_COMBINE = 64;
+struct LzCoeff {
+    double c[LZ_MAX_COMBINE];
+};
+
+// out = sum_k c_k V_k (V_k = krylov + k n), partial |out|^2 per workgroup: one pass over N + 1 vectors instead of N axpys
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void krylov_combine_kernel(int64_t nd, int N, LzCoeff C, const double *__restrict__ V, int64_t stride,
+                                                            double *__restrict__ out, double *__restrict__ partial) {
+    __shared__ double red[NT / 64];
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nd; i += (int64_t)gridDim.x * NT) {
+        double t = 0;
+        for (int k = 0; k < N; ++k) t = fma(C.c[k], V[k * stride + i], t);
+        out[i] = t;
+        s = fma(t, t, s);
+    }
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = 0.;
+    }
+}
+
+__global__ void lz_post_scalars_kernel(const double *__restrict__ src, double *__restrict__ dst_host) {
+    dst_host[0] = src[0];
+    dst_host[1] = src[1];
+    __threadfence_system();
+}
+
+__global__ __launch_bounds__(NT) void lz_copy_scaled_kernel(int64_t nd, const double *__restrict__ x, const double *__restrict__ nrm2,
+                                                            double *__restrict__ y) {
+    const double f = 1. / sqrt(nrm2[0]);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nd; i += (int64_t)gridDim.x * NT) y[i] = f * x[i];
+}
+
+struct LzHost {          // per-thread persistent host resources
+    double *pinned = nullptr;        // mapped host memory: 2 doubles per step
+    int capacity = 0;
+    std::vector<hipEvent_t> ev;      // one per step (no timing)
+    std::vector<hipEvent_t> tev;     // timing events for the GEMM launches (only when asked for)
+};
+thread_local LzHost lz_host;
+
+int lz_reserve(int steps) {
+    LzHost &H = lz_host;
+    if (H.capacity < steps + 2) {
+        if (H.pinned) TPA_HIP_CHECK(hipHostFree(H.pinned));
+        H.capacity = 2 * (steps + 2);
+        TPA_HIP_CHECK(hipHostMalloc((void **)&H.pinned, sizeof(double) * 2 * H.capacity, hipHostMallocDefault));
+    }
+    while ((int)H.ev.size() < steps + 2) {
+        hipEvent_t e;
+        TPA_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        H.ev.push_back(e);
+    }
+    return 0;
+}
+
+inline void *lz_slot(int64_t s, void *const *bufs, int n_bufs, const void *in, void *out) {
+    if (s == -1) return const_cast<void *>(in);
+    if (s == -2) return out;
+    return (s >= 0 && s < n_bufs) ? bufs[s] : nullptr;
+}
+
+}  // namespace
+
+extern "C" int tpa_lanczos_run(int dtype, int64_t n, const int64_t *ops, int n_ops, void *const *bufs, int n_bufs,
+                               void *krylov_dev, const void *psi0_dev, int N_max, double cutoff, int has_shift, double E_shift,
+                               double *scalars_dev, double *scratch_dev, tpa_lanczos_callback cb, void *user,
+                               int time_gemms, double *info, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    TPA_ARG_CHECK(n > 0 && N_max >= 1 && n_ops >= 1 && ops != nullptr && krylov_dev != nullptr && psi0_dev != nullptr);
+    TPA_ARG_CHECK(scalars_dev != nullptr && scratch_dev != nullptr && cb != nullptr && info != nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    const bool cplx = (dtype == TPA_C128);
+    const int64_t nd = cplx ? 2 * n : n;
+    double *V = (double *)krylov_dev;
+    if (int rc = lz_reserve(N_max)) return rc;
+    LzHost &H = lz_host;
+    // beta_0 = |psi0| ; V_0 = psi0 / beta_0     (reference :650-653)
+    double *sc0 = scalars_dev + 2 * (N_max + 1);        // |psi0|^2 lives behind the per-step scalars
+    if (int rc = tpa_nrm2sq(dtype, n, psi0_dev, sc0, scratch_dev, stream)) return rc;
+    lz_copy_scaled_kernel<<<grid_for(nd, 8), NT, 0, st>>>(nd, (const double *)psi0_dev, sc0, V);
+    lz_post_scalars_kernel<<<1, 1, 0, st>>>(sc0, H.pinned + 2 * (N_max + 1));
+    TPA_HIP_CHECK(hipEventRecord(H.ev[N_max + 1], st));
+    size_t n_tev = 0;
+    int n_matvec = 0, N = 0;
+    bool stopped = false;
+    for (int k = 0; k < N_max; ++k) {
+        const double *vin = V + (int64_t)k * nd;
+        double *w = V + (int64_t)(k + 1) * nd;
+        for (int o = 0; o < n_ops; ++o) {
+            const int64_t *op = ops + 12 * o;
+            void *a = lz_slot(op[6], bufs, n_bufs, vin, w), *b = lz_slot(op[7], bufs, n_bufs, vin, w), *c = lz_slot(op[8], bufs, n_bufs, vin, w);
+            if (op[0] == 0) {
+                TPA_ARG_CHECK(a != nullptr && b != nullptr && c != nullptr);
+                if (time_gemms) {
+                    while (H.tev.size() < n_tev + 2) {
+                        hipEvent_t e;
+                        TPA_HIP_CHECK(hipEventCreate(&e));
+                        H.tev.push_back(e);
+                    }
+                    TPA_HIP_CHECK(hipEventRecord(H.tev[n_tev], st));
+                }
+                if (int rc = tpa_gemm_chain(dtype, (int)op[1], (const int64_t *)op[2], (const int64_t *)op[3], (const int32_t *)op[4], (int)op[5],
+                                            a, b, c, stream))
+                    return rc;
+                if (time_gemms) {
+                    TPA_HIP_CHECK(hipEventRecord(H.tev[n_tev + 1], st));
+                    n_tev += 2;
+                }
+            } else if (op[0] == 1) {
+                TPA_ARG_CHECK(a != nullptr && c != nullptr);
+                if (int rc = tpa_lincomb_batch(dtype, (const int64_t *)op[2], (int)op[5], (const int64_t *)op[3], op[9], a, c, stream)) return rc;
+            } else {
+                TPA_ARG_CHECK(false && "unknown op kind");
+            }
+        }
+        ++n_matvec;
+        if (has_shift)
+            if (int rc = tpa_axpy(dtype, n, E_shift, 0., vin, w, stream)) return rc;
+        if (int rc = tpa_lanczos_step(dtype, n, w, vin, k > 0 ? (const void *)(V + (int64_t)(k - 1) * nd) : nullptr,
+                                      k > 0 ? scalars_dev + 2 * (k - 1) + 1 : nullptr, scalars_dev + 2 * k, scratch_dev, stream))
+            return rc;
+        lz_post_scalars_kernel<<<1, 1, 0, st>>>(scalars_dev + 2 * k, H.pinned + 2 * k);
+        TPA_HIP_CHECK(hipEventRecord(H.ev[k], st));
+        if (k == 0) {       // |psi0| (reference :650: "norm of psi0 too small" is the caller's error; step 0 is in flight meanwhile)
+            TPA_HIP_CHECK(hipEventSynchronize(H.ev[N_max + 1]));
+            info[3] = sqrt(H.pinned[2 * (N_max + 1)]);
+            if (!(info[3] >= cutoff)) {
+                info[0] = 0.;
+                info[1] = 1.;
+                info[2] = 0.;
+                TPA_HIP_CHECK(hipStreamSynchronize(st));
+                return 0;
+            }
+        }
+        if (k > 0) {
+            TPA_HIP_CHECK(hipEventSynchronize(H.ev[k - 1]));
+            if (cb(k - 1, H.pinned[2 * (k - 1)], H.pinned[2 * (k - 1) + 1], user)) {
+                N = k;      // step k in flight is not part of the result (same Krylov space as the step-by-step loop)
+                stopped = true;
+                break;
+            }
+        }
+        N = k + 1;
+    }
+    if (!stopped) {
+        TPA_HIP_CHECK(hipEventSynchronize(H.ev[N_max - 1]));
+        cb(N_max - 1, H.pinned[2 * (N_max - 1)], H.pinned[2 * (N_max - 1) + 1], user);
+    }
+    double ms = 0.;
+    if (time_gemms && n_tev) {
+        TPA_HIP_CHECK(hipEventSynchronize(H.tev[n_tev - 1]));
+        for (size_t i = 0; i < n_tev; i += 2) {
+            float t = 0.f;
+            TPA_HIP_CHECK(hipEventElapsedTime(&t, H.tev[i], H.tev[i + 1]));
+            ms += t;
+        }
+    }
+    info[0] = (double)N;
+    info[1] = (double)n_matvec;
+    info[2] = ms;
+    return 0;
+}
+
+// psi = sum_k coeff_k V_k, then |psi| (returned in out_host[0], blocking) -- the first half of `_calc_result_full`
+// (krylov_based.py:223-236); the caller decides about the ill-conditioned / degenerate cases and scales.
+extern "C" int tpa_krylov_combine(int dtype, int64_t n, const void *krylov_dev, int N, const double *coeff, void *out_dev,
+                                  double *red_out_dev, double *scratch_dev, double *norm_host, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    TPA_ARG_CHECK(n > 0 && N >= 1 && N <= LZ_MAX_COMBINE && coeff != nullptr && out_dev != nullptr && norm_host != nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    const bool cplx = (dtype == TPA_C128);
+    const int64_t nd = cplx ? 2 * n : n;
+    LzCoeff C;
+    for (int k = 0; k < LZ_MAX_COMBINE; ++k) C.c[k] = k < N ? coeff[k] : 0.;
+    const int g = grid_for(nd, 4);
+    if (cplx)
+        krylov_combine_kernel<true><<<g, NT, 0, st>>>(nd, N, C, (const double *)krylov_dev, nd, (double *)out_dev, scratch_dev);
+    else
+        krylov_combine_kernel<false><<<g, NT, 0, st>>>(nd, N, C, (const double *)krylov_dev, nd, (double *)out_dev, scratch_dev);
+    reduce_pass2<<<1, NT, 0, st>>>(g, scratch_dev, red_out_dev);
+    TPA_LAUNCH_CHECK();
+    if (int rc = lz_reserve(1)) return rc;
+    lz_post_scalars_kernel<<<1, 1, 0, st>>>(red_out_dev, lz_host.pinned);
+    TPA_HIP_CHECK(hipEventRecord(lz_host.ev[0], st));
+    TPA_HIP_CHECK(hipEventSynchronize(lz_host.ev[0]));
+    norm_host[0] = sqrt(lz_host.pinned[0]);
     return 0;
 }

@@ -20,6 +20,7 @@ from . import np_conserved as npc
 logger = logging.getLogger(__name__)
 
 import os as _os
+NATIVE = _os.environ.get('TPA_LANCZOS_NATIVE', '1') != '0'       # the whole run as one C-ABI call (tpa_lanczos_run) where the operator offers a launch program
 PIPELINED = _os.environ.get('TPA_LANCZOS_PIPELINED', '1') != '0'     # device-resident alpha / beta in LanczosGroundState (off: one host read per scalar, as in round 1)
 
 __all__ = ['LanczosGroundState', 'LanczosEvolution', 'Arnoldi', 'lanczos', 'gram_schmidt', 'iscale_prefactor', 'iadd_prefactor_other']
@@ -62,6 +63,9 @@ class LanczosGroundState:
     def run(self):
         """Returns ``(E0, psi0, N)``: energy estimate, normalised ground state estimate, iterations."""
         stats['runs'] += 1
+        prog = self._native_program()
+        if prog is not None:
+            return self._run_native(prog)
         N = self._build_krylov()
         E0 = self.Es[N - 1, 0]
         if self.E_shift is not None:
@@ -69,6 +73,95 @@ class LanczosGroundState:
         if N == 1:
             return E0, self.psi0.copy(deep=True), N
         return E0, self._calc_result_full(N), N
+
+    # ---- the whole run as one host call (tpa_lanczos_run) ---------------------------------------------------------
+    def _native_program(self):
+        """``(ops, bufs, gemm_plans)`` if the operator can hand its matvec over as a launch program (``TwoSiteH.matvec_program``)
+        and the options are the ones the native loop covers (no re-orthogonalisation, all Krylov vectors cached)."""
+        if not (NATIVE and PIPELINED) or self.reortho or self.N_cache < self.N_max or self.N_max + 1 > 64:
+            return None
+        make = getattr(self.H, 'matvec_program', None)
+        if make is None:
+            return None
+        w = self.psi0
+        if w.stored_blocks == 0 or not w._is_packed():
+            return None
+        return make(w)
+
+    def _run_native(self, prog):
+        """``_build_krylov`` + ``_calc_result_full`` through ``tpa_lanczos_run`` / ``tpa_krylov_combine``: the device side of every
+        step is enqueued by a C++ loop, the reference's host side of a step (tridiagonal ``eigh``, ``_converged``) runs in the
+        callback one step late -- the same numbers as :meth:`_build_krylov_pipelined`, without ~0.5 ms of interpreter time per step."""
+        from .. import _lib
+        ops, bufs, gemm_plans = prog
+        w = self.psi0
+        n, dtype = w._arena.numel(), w.dtype
+        code, L = dev.code(dtype), dev.lib()
+        N_max = self.N_max
+        krylov = dev.scratch('lanczos_krylov', (N_max + 1) * n, dtype)
+        scal = dev.scratch('lanczos_scalars', 2 * (N_max + 2) + 4, np.float64)
+        _, scr = dev.reduction_buffers()
+        h = self._h_krylov
+        err = []
+
+        def record(j, alpha, bsq, user):
+            try:
+                b = float(np.sqrt(bsq))
+                h[j, j] = alpha
+                self._calc_result_krylov(j)
+                h[j, j + 1] = h[j + 1, j] = b
+                return int(abs(b) < self._cutoff or (j + 1 >= self.N_min and self._converged(j)))
+            except BaseException as e:       # an exception must not unwind through the C frame
+                err.append(e)
+                return 1
+        cb = _lib.LANCZOS_CALLBACK(record)
+        ptrs = np.array([t.data_ptr() for t in bufs], dtype=np.int64)
+        info = np.zeros(4, dtype=np.float64)
+        timed = npc.gemm_timer.enabled
+        dev.check(L.tpa_lanczos_run(code, n, ops.ctypes.data, len(ops), ptrs.ctypes.data, len(ptrs), krylov.data_ptr(),
+                                    w._arena.data_ptr(), N_max, float(self._cutoff), int(self.E_shift is not None),
+                                    float(self.E_shift or 0.), scal.data_ptr(), scr.data_ptr(), cb, None, int(timed),
+                                    info.ctypes.data, dev.stream()), "lanczos_run")
+        if err:
+            raise err[0]
+        N, n_mv = int(info[0]), int(info[1])
+        stats['n_matvec'] += n_mv
+        if timed:
+            gt = npc.gemm_timer
+            gt.n_launch += n_mv * len(gemm_plans)
+            gt.flops += n_mv * sum(p.flops for p in gemm_plans)
+            gt.bytes_min += n_mv * sum(p.bytes_min for p in gemm_plans)
+            gt.ms += float(info[2])
+        if N == 0:
+            raise ValueError("Norm of self.psi0 too small: {0}".format(info[3]))
+        if self._psi0_norm is None:
+            self._psi0_norm = float(info[3])
+        E0 = self.Es[N - 1, 0]
+        if self.E_shift is not None:
+            E0 -= self.E_shift
+        psif = w.copy(deep=False)
+        out = dev.empty(n, dtype)
+        if N == 1:
+            out.copy_(krylov[:n])
+            psif._arena = out
+            return E0, psif, N
+        vf = np.ascontiguousarray(self._result_krylov, dtype=np.float64)
+        assert len(vf) == N
+        nrm = np.zeros(1, dtype=np.float64)
+        dev.check(L.tpa_krylov_combine(code, n, krylov.data_ptr(), N, vf.ctypes.data, out.data_ptr(), scal.data_ptr() + 8 * 2 * (N_max + 2),
+                                       scr.data_ptr(), nrm.ctypes.data, dev.stream()), "krylov_combine")
+        nrm = float(nrm[0])
+        psif._arena = out
+        if abs(1. - nrm) > 1.e-5:
+            stats['n_ill_conditioned'] += 1
+            logger.warning("poorly conditioned H matrix in KrylovBased! |psi_0| = %f", nrm)
+        if not (nrm > 1.e-8) or not np.isfinite(nrm):      # see _calc_result_full
+            stats['n_degenerate'] += 1
+            out.copy_(krylov[:n])
+            nrm = 1.
+        if nrm != 1.:
+            dev.check(L.tpa_scal(code, n, 1. / nrm, 0., out.data_ptr(), dev.stream()), "scal")
+        return E0, psif, N
 
     # ---- internals ------------------------------------------------------------------------------------------
     def _matvec(self, w):

@@ -1810,7 +1810,9 @@ class TensordotPlan:
     def __init__(self):
         self.empty = True
 
-    def apply(self, a, b, out_arena=None):
+    def apply(self, a, b, out_arena=None, launch=True):
+        """``launch=False``: only the result's bookkeeping and allocation (callers that replay the plan themselves,
+        ``TwoSiteH.matvec_program``)."""
         # legs / labels / qtotal come from the actual operands: the plan only depends on block structure
         legs = [a.legs[x] for x in self.keep_a] + [b.legs[x] for x in self.keep_b]
         la, lb = [a._labels[x] for x in self.keep_a], [b._labels[x] for x in self.keep_b]
@@ -1826,6 +1828,8 @@ class TensordotPlan:
         if out_arena is None:
             out_arena = dev.empty(self.res_total, self.dtype)
         res._arena = out_arena
+        if not launch:
+            return res
         a_arena, b_arena = a._arena, b._arena
         if a.dtype != self.dtype:
             a_arena = a.astype(self.dtype)._arena

@@ -186,6 +186,65 @@ class MockLib:
             w *= 1. / np.sqrt(bsq)
         return 0
 
+    def tpa_lanczos_run(self, code, n, ops_p, n_ops, bufs_p, n_bufs, krylov_p, psi0_p, N_max, cutoff, has_shift, E_shift,
+                        scal_p, scr_p, cb, user, time_gemms, info_p, stream):
+        """Emulation of the C++ loop of tpa_lanczos_run (tenpy_amd/csrc/tpa_vec.hip): same order of device calls, the callback
+        one step late."""
+        dt = _npdt(code)
+        isz = np.dtype(dt).itemsize
+        ops = _host(ops_p, (n_ops, 12))
+        bufs = _host(bufs_p, (n_bufs,)) if n_bufs else np.zeros(0, np.int64)
+        info = _host(info_p, (4,), np.float64)
+        psi0 = REG.view(psi0_p, dt)[:n]
+        V = lambda k: krylov_p + k * n * isz
+        beta0 = float(np.sqrt(np.real(np.vdot(psi0, psi0))))
+        info[3] = beta0
+        if not beta0 >= cutoff:
+            info[0], info[1], info[2] = 0., 1., 0.
+            return 0
+        REG.view(V(0), dt)[:n] = psi0 / beta0
+        hist = {}
+
+        def slot(s, vin, w):
+            return vin if s == -1 else (w if s == -2 else int(bufs[s]))
+        N, n_mv, stopped = 0, 0, False
+        for k in range(N_max):
+            vin, w = V(k), V(k + 1)
+            for op in ops:
+                a, b, c = slot(op[6], vin, w), slot(op[7], vin, w), slot(op[8], vin, w)
+                if op[0] == 0:
+                    self.tpa_gemm_chain(code, int(op[1]), int(op[2]), int(op[3]), int(op[4]), int(op[5]), a, b, c, stream)
+                else:
+                    assert op[0] == 1
+                    self.tpa_lincomb_batch(code, int(op[2]), int(op[5]), int(op[3]), int(op[9]), a, c, stream)
+            n_mv += 1
+            if has_shift:
+                self.tpa_axpy(code, n, E_shift, 0., vin, w, stream)
+            self.tpa_lanczos_step(code, n, w, vin, V(k - 1) if k > 0 else None, scal_p + 8 * (2 * (k - 1) + 1) if k > 0 else None,
+                                  scal_p + 8 * 2 * k, scr_p, stream)
+            ab = REG.view(scal_p + 8 * 2 * k, np.float64)
+            hist[k] = (float(ab[0]), float(ab[1]))
+            if k > 0 and cb(k - 1, hist[k - 1][0], hist[k - 1][1], user):
+                N, stopped = k, True
+                break
+            N = k + 1
+        if not stopped:
+            cb(N_max - 1, hist[N_max - 1][0], hist[N_max - 1][1], user)
+        info[0], info[1], info[2] = N, n_mv, 0.
+        return 0
+
+    def tpa_krylov_combine(self, code, n, krylov_p, N, coeff_p, out_p, red_p, scr_p, norm_p, stream):
+        dt = _npdt(code)
+        coeff = _host(coeff_p, (N,), np.float64)
+        V = REG.view(krylov_p, dt)
+        out = REG.view(out_p, dt)[:n]
+        acc = np.zeros(n, dtype=dt)
+        for k in range(N):
+            acc += coeff[k] * V[k * n:(k + 1) * n]
+        out[:] = acc
+        _host(norm_p, (1,), np.float64)[0] = float(np.sqrt(np.real(np.vdot(acc, acc))))
+        return 0
+
     def tpa_copy_batch(self, code, jobs_p, n_jobs, max_elems, src_p, dst_p, stream):
         dt = _npdt(code)
         W = 4 + 3 * MAXD
