@@ -64,9 +64,19 @@ class Dataset(_Node):
 
 
 class Group(_Node):
-    def __init__(self, name='/'):
+    def __init__(self, name='/', root=None):
         _Node.__init__(self, name)
         self.children = {}
+        self._root = root
+
+    @property
+    def file(self):
+        return self._root if self._root is not None else self
+
+    def __delitem__(self, path):
+        parts = [p for p in path.split('/') if p]
+        parent = self._walk('/'.join(parts[:-1]))
+        del parent.children[parts[-1]]
 
     def _walk(self, path, create=False):
         node = self
@@ -75,7 +85,7 @@ class Group(_Node):
             if p not in node.children:
                 if not create:
                     raise KeyError(path)
-                node.children[p] = Group((node.name.rstrip('/') + '/' + p))
+                node.children[p] = Group((node.name.rstrip('/') + '/' + p), self.file)
             node = node.children[p]
         return node
 
@@ -84,7 +94,7 @@ class Group(_Node):
         parent = self._walk('/'.join(parts[:-1]), create=True)
         if parts[-1] in parent.children:
             raise ValueError("group exists: " + path)
-        g = Group(parent.name.rstrip('/') + '/' + parts[-1])
+        g = Group(parent.name.rstrip('/') + '/' + parts[-1], self.file)
         parent.children[parts[-1]] = g
         return g
 
@@ -118,14 +128,28 @@ class File(Group):
     def __init__(self, filename, mode='r'):
         Group.__init__(self, '/')
         self.filename, self.mode = filename, mode
+        self._open = True
+        if mode in ('w-', 'x'):
+            import os
+            if os.path.exists(filename):
+                raise FileExistsError(filename)
         if mode in ('r', 'r+', 'a'):
             try:
                 with open(filename, 'rb') as f:
                     root = pickle.load(f)
                 self.children, self.attrs = root.children, root.attrs
+                todo = list(self.children.values())
+                while todo:                      # the loaded groups belong to THIS file object
+                    g = todo.pop()
+                    if isinstance(g, Group):
+                        g._root = self
+                        todo.extend(g.children.values())
             except FileNotFoundError:
                 if mode == 'r':
                     raise
+
+    def __bool__(self):
+        return self._open
 
     def __enter__(self):
         return self
@@ -135,6 +159,7 @@ class File(Group):
         return False
 
     def close(self):
+        self._open = False
         if self.mode != 'r':
             root = Group('/')
             root.children, root.attrs = self.children, self.attrs

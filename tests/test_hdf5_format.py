@@ -81,3 +81,61 @@ def test_hdf5_layout_round_trip_between_mirror_and_reference(tmp_path, writer, w
             np.testing.assert_allclose(np.array(a), np.array(b), rtol=0, atol=1e-15)
         np.testing.assert_allclose(np.array(got['theta']), np.array(wrote['theta']), rtol=0, atol=1e-15)
         np.testing.assert_allclose(np.array(got['W']), np.array(wrote['W']), rtol=0, atol=0)
+
+
+CACHE_CODE = r"""
+import json, sys, warnings
+warnings.simplefilter('ignore')
+STORAGE, THREADS, DIR = %(storage)r, %(threads)r, %(dir)r
+import refsuite_plugin                        # the mirror modules (+ numpy emulation of the device when no GPU is visible)
+import numpy as np
+from tenpy.tools.cache import CacheFile
+from tenpy.algorithms import dmrg
+from tenpy.models.xxz_chain import XXZChain
+from tenpy.networks.mps import MPS
+import tenpy.linalg.np_conserved as npc
+L = 12
+M = XXZChain({'L': L, 'Jxx': 1., 'Jz': 1., 'hz': 0., 'bc_MPS': 'finite', 'conserve': 'Sz', 'sort_charge': True})
+psi = MPS.from_product_state(M.lat.mps_sites(), ['up', 'down'] * (L // 2), bc='finite')
+kw = {} if STORAGE == 'Storage' else ({'directory': DIR + '/pkl'} if STORAGE == 'PickleStorage' else {'filename': DIR + '/cache.h5'})
+with CacheFile.open(storage_class=STORAGE, use_threading=THREADS, **kw) as cache:
+    eng = dmrg.TwoSiteDMRGEngine(psi, M, {'mixer': None, 'max_N_for_ED': 0, 'trunc_params': {'chi_max': 24, 'svd_min': 1e-12},
+                                         'cache_threshold_chi': 0}, cache=cache)
+    E = []
+    for s in range(4):
+        eng.sweep()
+        E.append(float(eng.update_stats['E_total'][-1] if hasattr(eng, 'update_stats') else 0.))
+    # the environments went through the storage: fetch one back and check it is a device-backed Array of the mirror
+    LP = eng.env.get_LP(L // 2)
+    assert type(LP).__module__ == 'tenpy_amd.linalg.np_conserved', type(LP).__module__
+    n_stored = len(eng.env.cache.long_term_keys)          # (the environments live in the sub-cache 'env', mps_common.py:261)
+print('RESULT ' + json.dumps({'E': E, 'n_stored': n_stored, 'S': [float(x) for x in psi.get_SL(L // 2)]}))
+"""
+
+
+@pytest.mark.parametrize("where", ["mock", pytest.param("gpu", marks=pytest.mark.gpu)])
+def test_cache_storages_hold_device_arrays(tmp_path, where):
+    """The reference's ``tools/cache.py`` storages (``PickleStorage`` :479, threaded :552-700, ``Hdf5Storage`` :517 on the stand-in
+    h5py) under the reference's DMRG engine with environments of the mirror: every environment tensor goes to disk through
+    ``Array.__getstate__`` / ``save_hdf5`` and comes back as a device Array; energies and Schmidt values equal the run that keeps
+    everything in RAM (VERDICT r2 'storages untested on device arrays')."""
+    import numpy as np
+    import torch
+    if where == "mock" and torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the 'gpu' variant runs instead")
+
+    def run(storage, threads, sub):
+        d = tmp_path / sub
+        d.mkdir()
+        env = dict(os.environ)
+        env['PYTHONPATH'] = os.pathsep.join([os.path.join(HERE, 'fake_h5py'), HERE, ROOT, REF, env.get('PYTHONPATH', '')])
+        res = subprocess.run([sys.executable, '-c', CACHE_CODE % {'storage': storage, 'threads': threads, 'dir': str(d)}], env=env,
+                             capture_output=True, text=True, timeout=1200)
+        assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+        return json.loads([l for l in res.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
+    ram = run('Storage', False, 'ram')
+    for storage, threads in (('PickleStorage', False), ('PickleStorage', True), ('Hdf5Storage', False)):
+        got = run(storage, threads, storage + str(int(threads)))
+        assert got['n_stored'] > 0, "nothing was handed to the storage"
+        np.testing.assert_allclose(got['E'], ram['E'], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(got['S'], ram['S'], rtol=0, atol=1e-13)
