@@ -257,39 +257,14 @@ def build_tebd(args):
 
 
 def random_right_canonical_mps(p, L, chi, dtype, seed):
-    """Random MPS in right-canonical ('B') form whose bonds have min(chi, d**i, d**(L-i)) states spread evenly over the charge
-    sectors that the fusion rules allow: built from the right edge, site tensor = the isometric factor of an LQ
-    decomposition (device block QR) of a random (vL) x (p.vR) block matrix."""
+    """Random MPS in right-canonical ('B') form (scripts/tebd_state.py: the generator is shared with the offline TeNPy run of the same
+    quench, scripts/cpu_reference_tebd.py, so that both start from the same state)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scripts'))
+    import tebd_state
     from tenpy_amd.linalg import np_conserved as npc
     from tenpy_amd.linalg.charges import LegCharge, LegPipe
     from tenpy_amd.networks.mps import MPS
-    rng = np.random.default_rng(seed)
-    chinfo = p.chinfo
-    d = p.ind_len
-    cplx = np.dtype(dtype).kind == 'c'
-
-    def rnd(size):
-        x = rng.standard_normal(size)
-        return x + 1.j * rng.standard_normal(size) if cplx else x
-    vR = LegCharge.from_qflat(chinfo, [chinfo.make_valid()], qconj=-1)
-    Bs, Ss = [None] * L, [None] * (L + 1)
-    Ss[L] = np.ones(1)
-    for i in reversed(range(L)):
-        pipe = LegPipe([p, vR], qconj=-1)
-        n_q = pipe.get_block_sizes()
-        total = int(min(chi, d ** min(i, 30), int(np.sum(n_q))))
-        sizes = np.minimum(n_q, total // len(n_q))
-        for q in np.argsort(-n_q):                  # hand the remainder to the sectors that still have room
-            room = min(int(n_q[q] - sizes[q]), total - int(np.sum(sizes)))
-            sizes[q] += max(room, 0)
-        keep = sizes > 0
-        vL = LegCharge.from_qind(chinfo, np.concatenate([[0], np.cumsum(sizes[keep])]), pipe.charges[keep], qconj=+1)
-        M = npc.Array.from_func(rnd, [vL, pipe], dtype=dtype, qtotal=None, shape_kw='size', labels=['vL', '(p.vR)'])
-        _, Q = npc.lq(M, inner_labels=['vR', 'vL'])
-        Bs[i] = Q.split_legs(1)
-        vR = Bs[i].get_leg('vL').conj()
-        s = np.abs(rng.standard_normal(vR.ind_len)) + 0.1
-        Ss[i] = s / np.linalg.norm(s)
+    Bs, Ss = tebd_state.random_right_canonical_tensors(npc, LegCharge, LegPipe, p, L, chi, dtype, seed)
     return MPS([p] * L, Bs, Ss, form='B')
 
 
@@ -422,6 +397,31 @@ def main():
             out["trunc_err_eps"] = float(eng.trunc_err.eps)
             out["norm"] = float(eng.norm)
             out["S_mid_entropy"] = float(-np.sum(np.asarray(eng.psi.get_SL(L // 2)) ** 2 * np.log(np.asarray(eng.psi.get_SL(L // 2)) ** 2 + 1e-300)))
+            tref_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_cpu_reference_tebd.json')
+            n_done = args.warmup + args.steps
+            if os.path.exists(tref_file) and world == 1:
+                with open(tref_file) as f:
+                    tref = json.load(f)
+                if tref.get('L') == L and tref.get('chi') == chi:
+                    out["cpu_baseline"] = {"value": tref['s_per_step_best'], "unit": "s/step", "cores": tref.get('cores'), "kind": "reference",
+                                           "where": "offline: build container, %s host cores" % tref.get('cores'),
+                                           "sample": "TeNPy's own TEBDEngine (order 2, compiled _npc_helper) on the same synthetic state: best of "
+                                                     "%d full steps (%s)" % (len(tref['steps']), os.path.basename(tref_file))}
+                    rs = [r for r in tref['steps'] if r['step'] == n_done]
+                    if rs:          # the reference has the state after exactly this many steps: compare what the line reports
+                        r = rs[0]
+                        Sd = np.sort(np.asarray(eng.psi.get_SL(L // 2)))[::-1]
+                        out["tebd_parity"] = {
+                            "after_steps": n_done, "reference": os.path.basename(tref_file),
+                            "S_mid_entropy_abs_err": abs(out["S_mid_entropy"] - r['S_mid_entropy']),
+                            "trunc_err_eps_rel_err": abs(out["trunc_err_eps"] - r['trunc_err_eps']) / max(abs(r['trunc_err_eps']), 1e-300),
+                            "schmidt_top8_max_abs_err": float(np.max(np.abs(Sd[:8] - np.asarray(r['schmidt_top8'])))),
+                            "chi_mid": [int(len(Sd)), int(r['chi_mid'])],
+                            "note": "TeNPy's TEBDEngine run offline on the same seeded state (scripts/cpu_reference_tebd.py); the QR-based routes are "
+                                    "different truncations and are expected to agree only to the size of the truncation error"}
+                    else:
+                        out["tebd_parity"] = {"after_steps": n_done, "note": "the offline reference holds steps %s only: run with --warmup W --steps K, "
+                                              "W + K among them, for the comparison" % [r['step'] for r in tref['steps']]}
         if not is_tebd:
             out["E"] = eng.sweep_stats['E'][-1]
             out["chi_reached"] = eng.sweep_stats['max_chi'][-1]

@@ -20,9 +20,11 @@ from . import mps_common as dev_mc
 
 __all__ = ['device_two_site_h', 'hinted_mixed_svd']
 
-# device form only where it pays: the largest bond sector decides (same rule as the stand-alone driver); below it the
-# reference's class runs on the mirror (its npc calls are device calls as well)
-MIN_SECTOR = 64
+# Smallest "largest bond sector" for which the device form is used.  Round 3 measurement (module form on the MI355X, Heisenberg
+# L = 100, mixer ramp): with the reference's own class below 64 -- four generic tensordots with transposed copies per matvec,
+# ~20 device calls and ~1 ms of interpreter time each -- a chi <= 256 sweep took 4.4 - 4.9 s against 0.9 - 1.5 s with the
+# device form everywhere, so the threshold is 1 (kept as a knob for A/B runs).
+MIN_SECTOR = 1
 stats = {'device': 0, 'reference': 0}      # bonds handled by the device form / handed back to the reference's class
 
 
@@ -50,8 +52,8 @@ def device_two_site_h(Ref):
                     return False
                 if sorted(LP.get_leg_labels()) != sorted(['vR*', 'wR', 'vR']) or sorted(RP.get_leg_labels()) != sorted(['wL', 'vL', 'vL*']):
                     return False
-                if not combine:         # factored form: every block of W0, W1 a single number
-                    return dev_mc._mpo_entries(env.H.get_W(i0)) is not None and dev_mc._mpo_entries(env.H.get_W(i0 + 1)) is not None
+                if not combine:         # factored form: every block of W0, W1 a single number, no transposed copies needed
+                    return dev_mc.factored_matvec_possible(LP, RP, env.H.get_W(i0), env.H.get_W(i0 + 1))
                 return True
             except Exception:
                 return False

@@ -336,6 +336,19 @@ class MpoApplyPlan:
         return res
 
 
+def factored_matvec_possible(LP, RP, W0, W1):
+    """Whether ``LP . theta . (W0 W1) . RP`` can run as GEMM / block linear combination / GEMM on the tensors as they are stored:
+    every MPO block a single number, MPO bond legs of the environments resolved into 1-wide blocks, leg orders that need no
+    transposed copy.  ``W0`` / ``W1`` with labels ``p`` or ``p0`` / ``p1``."""
+    lp, rp = list(LP.get_leg_labels()), list(RP.get_leg_labels())
+    w0, w1 = list(W0.get_leg_labels()), list(W1.get_leg_labels())
+    return (_mpo_entries(W0) is not None and _mpo_entries(W1) is not None and
+            sorted(lp) == sorted(['vR*', 'wR', 'vR']) and lp.index('vR*') < lp.index('vR') and
+            sorted(rp) == sorted(['wL', 'vL', 'vL*']) and rp.index('vL') < rp.index('vL*') and
+            bool(np.all(LP.get_leg('wR').get_block_sizes() == 1)) and bool(np.all(RP.get_leg('wL').get_block_sizes() == 1)) and
+            w0 in (['wL', 'wR', 'p0', 'p0*'], ['wL', 'wR', 'p', 'p*']) and w1 in (['wL', 'wR', 'p1', 'p1*'], ['wL', 'wR', 'p', 'p*']))
+
+
 class TwoSiteH:
     length = 2
     acts_on = ['(vL.p0)', '(p1.vR)']
@@ -382,12 +395,7 @@ class TwoSiteH:
         self.bytes_per_matvec = None
 
     def _factored_possible(self):
-        lp, rp = list(self.LP.get_leg_labels()), list(self.RP.get_leg_labels())
-        return (_mpo_entries(self.W0) is not None and _mpo_entries(self.W1) is not None and
-                sorted(lp) == sorted(['vR*', 'wR', 'vR']) and lp.index('vR*') < lp.index('vR') and
-                sorted(rp) == sorted(['wL', 'vL', 'vL*']) and rp.index('vL') < rp.index('vL*') and
-                np.all(self.LP.get_leg('wR').get_block_sizes() == 1) and np.all(self.RP.get_leg('wL').get_block_sizes() == 1) and
-                list(self.W0.get_leg_labels()) == ['wL', 'wR', 'p0', 'p0*'] and list(self.W1.get_leg_labels()) == ['wL', 'wR', 'p1', 'p1*'])
+        return factored_matvec_possible(self.LP, self.RP, self.W0, self.W1)
 
     # LHeff / RHeff: attributes in the fused mode, built lazily in the factored mode (mixer, tests)
     @property
