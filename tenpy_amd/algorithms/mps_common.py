@@ -72,9 +72,9 @@ def _lincomb_into(dst, src, jobs, terms, max_elems):
     if len(jobs) == 0:
         return
     L = dev.lib()
-    terms_d = dev.to_device(np.ascontiguousarray(terms))
+    terms_d = dev.table(terms)
     for s0 in range(0, len(jobs), 60000):
-        jd = dev.to_device(np.ascontiguousarray(jobs[s0:s0 + 60000]))
+        jd = dev.table(jobs[s0:s0 + 60000])
         dev.check(L.tpa_lincomb_batch(dev.code(dst.dtype), jd.data_ptr(), len(jobs[s0:s0 + 60000]), terms_d.data_ptr(),
                                       int(max_elems), src._arena.data_ptr(), dst._arena.data_ptr(), dev.stream()), "lincomb")
 

@@ -2914,6 +2914,46 @@ constexpr int64_t QRP_MIN_DIM = 32;        // below this the plain Jacobi path i
 constexpr double QRP_RANK_TOL = 1.0e-15;   // residual column norm <= tol * ||A||_F  ->  numerical rank reached
 constexpr int QRP_POLL = 8;                // steps between host polls of the "all blocks finished" state
 
+// pinned ring of state snapshots for the non-blocking "all blocks finished?" test of svd_run_qrp (one per host thread)
+struct QrpPoll {
+    static constexpr int SLOTS = 2;      // the host runs at most SLOTS * QRP_POLL (+ QRP_POLL) steps ahead of the device: superfluous steps stay few
+    QrpState *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev[SLOTS] = {};
+    bool have_ev = false, busy[SLOTS] = {};
+    int at_step[SLOTS] = {}, next = 0;
+    int reserve(int n_jobs) {
+        if (!have_ev) {
+            for (int i = 0; i < SLOTS; ++i) TPA_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            have_ev = true;
+        }
+        if (cap < (size_t)n_jobs) {
+            drain();
+            if (host) TPA_HIP_CHECK(hipHostFree(host));
+            cap = (size_t)n_jobs * 2 + 16;
+            TPA_HIP_CHECK(hipHostMalloc((void **)&host, sizeof(QrpState) * cap * SLOTS, hipHostMallocDefault));
+        }
+        return 0;
+    }
+    bool all_done(int slot, int n_jobs) const {
+        for (int b = 0; b < n_jobs; ++b)
+            if (!host[(size_t)slot * cap + b].done) return false;
+        return true;
+    }
+    void drain() {      // forget outstanding snapshots (their copies are ordered before anything enqueued later on the stream)
+        for (int i = 0; i < SLOTS; ++i)
+            if (busy[i]) {
+                (void)hipEventSynchronize(ev[i]);
+                busy[i] = false;
+            }
+        next = 0;
+    }
+};
+inline QrpPoll &qrp_poll() {
+    static thread_local QrpPoll p;
+    return p;
+}
+
 template <bool CPLX>
 int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a_base, void *u_base, double *s_dev,
                 void *vh_base, char *work, int max_sweeps, int *sweeps_done, hipStream_t st, double rho) {
@@ -2941,6 +2981,7 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     std::vector<QrpState> hstate(n_jobs);
     const double tol2 = QRP_RANK_TOL * QRP_RANK_TOL;
     void *Tpan = work + q.off_tpan;
+    bool finished = false;
     for (int k = 0, step = 0;; k += PNB, ++step) {
         if (CPLX) {
             if (q.m_max <= 4 * 256)
@@ -2963,18 +3004,43 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
             qrp_update_kernel_c<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, (cd *)X, (const cd *)Vall, cn, state, (const cd *)Tpan);
         else
             qrp_update_kernel<<<dim3(tiles, n_jobs), NTR, 0, st>>>(qjobs, k, (double *)X, (const double *)Vall, cn, state, (const double *)Tpan);
+        // "all blocks finished?" without draining the queue: every QRP_POLL steps the states are copied to pinned memory behind
+        // the launches and the host only LOOKS at a copy once its event has fired, while it keeps enqueueing steps.  Steps that
+        // turn out to be superfluous return at their first instruction (state.done).  (Round 3: the blocking poll left the GPU
+        // idle for a host round trip ten times per chi = 2048 call.)
         if ((step % QRP_POLL) == QRP_POLL - 1) {
-            TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
-            TPA_HIP_CHECK(hipStreamSynchronize(st));
-            bool all = true;
-            for (const QrpState &s : hstate) all = all && s.done;
-            if (all) break;
-            if (tpa_svd_rank_cap > 0 && k + PNB >= tpa_svd_rank_cap) {
-                snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: numerical rank above the cap %d", tpa_svd_rank_cap);
-                return TPA_E_RANKCAP;
+            QrpPoll &P = qrp_poll();
+            if (int rc = P.reserve(n_jobs)) return rc;
+            const int slot = P.next;
+            if (P.busy[slot]) {      // ring full: the oldest copy must have landed before its slot is reused
+                TPA_HIP_CHECK(hipEventSynchronize(P.ev[slot]));
+                P.busy[slot] = false;
+                if (P.all_done(slot, n_jobs)) { finished = true; }
+            }
+            if (!finished) {
+                TPA_HIP_CHECK(hipMemcpyAsync(P.host + (size_t)slot * P.cap, state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
+                TPA_HIP_CHECK(hipEventRecord(P.ev[slot], st));
+                P.busy[slot] = true;
+                P.at_step[slot] = k + PNB;
+                P.next = (slot + 1) % QrpPoll::SLOTS;
             }
         }
+        {
+            QrpPoll &P = qrp_poll();
+            for (int sl = 0; sl < QrpPoll::SLOTS && !finished; ++sl)
+                if (P.busy[sl] && hipEventQuery(P.ev[sl]) == hipSuccess) {
+                    P.busy[sl] = false;
+                    if (P.all_done(sl, n_jobs)) finished = true;
+                    else if (tpa_svd_rank_cap > 0 && P.at_step[sl] >= tpa_svd_rank_cap) {
+                        P.drain();
+                        snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: numerical rank above the cap %d", tpa_svd_rank_cap);
+                        return TPA_E_RANKCAP;
+                    }
+                }
+        }
+        if (finished) break;
     }
+    qrp_poll().drain();
     TPA_LAUNCH_CHECK();
     qrp_finish_perm_kernel<<<n_jobs, NT, 0, st>>>(qjobs, state, cn, cperm);
     if (CPLX)

@@ -95,6 +95,34 @@ def to_device(arr):
     return torch().from_numpy(arr).to('cuda')
 
 
+_table_cache = None
+TABLE_CACHE_MAX_ENTRIES = 32768
+TABLE_CACHE_MAX_BYTES = 1 << 18       # per table; larger ones are uploaded every time (hashing them would cost more than the copy)
+
+
+def table(arr):
+    """Device copy of a small READ-ONLY host table (job / index tables of the copy, scale, gather and combination kernels), cached
+    by content.  A saturated DMRG / TEBD run issues the same few thousand tables again and again (one per reshaping operation and
+    bond); each upload from pageable memory is a blocking ~40 us host call in front of a ~5 us kernel, and the round-3 idle-gap
+    analysis (scripts/gap_analysis.py) attributes 0.3 of the 4.0 s of a chi = 2048 sweep to the GPU waiting for exactly these."""
+    global _table_cache
+    arr = np.ascontiguousarray(arr)
+    if arr.nbytes > TABLE_CACHE_MAX_BYTES:
+        return to_device(arr)
+    if _table_cache is None:
+        from collections import OrderedDict
+        _table_cache = OrderedDict()
+    key = (arr.dtype.str, arr.shape, arr.tobytes())
+    t = _table_cache.get(key)
+    if t is None:
+        t = _table_cache[key] = to_device(arr)
+        if len(_table_cache) > TABLE_CACHE_MAX_ENTRIES:
+            _table_cache.popitem(last=False)
+    else:
+        _table_cache.move_to_end(key)
+    return t
+
+
 def clone(tensor):
     return tensor.clone()
 

@@ -1093,7 +1093,7 @@ class Array:
         jobs[:, 2] = shapes[:, axis]
         jobs[:, 3] = np.prod(shapes[:, axis + 1:], axis=1)
         jobs[:, 4] = self.legs[axis].slices[self._qdata[:, axis]]
-        jd = dev.to_device(jobs)
+        jd = dev.table(jobs)
         dev.check(dev.lib().tpa_scale_axis_batch(dev.code(self.dtype), jd.data_ptr(), len(jobs),
                                                  int(np.max(np.prod(shapes, axis=1))), self._arena.data_ptr(),
                                                  s_dev.data_ptr(), int(s_cplx), dev.stream()), "scale_axis")
@@ -1191,7 +1191,7 @@ class Array:
         if pad:
             rows = np.concatenate([rows, np.full((pad, 2), -1)], axis=0)
         out = dev.zeros(int(o_offs[-1]), np.float64)
-        jd, rd = dev.to_device(jobs), dev.to_device(rows.astype(np.int32))
+        jd, rd = dev.table(jobs), dev.table(rows.astype(np.int32))
         dev.check(dev.lib().tpa_axis_sqnorm_batch(dev.code(self.dtype), jd.data_ptr(), rd.data_ptr(), len(rows),
                                                   self._arena.data_ptr(), out.data_ptr(), dev.stream()), "axis_sqnorm")
         host = dev.to_host(out)
@@ -1380,7 +1380,7 @@ class Array:
         jobs[:, 4] = new_shapes[:, axis]
         jobs[:, 5] = np.prod(old_shapes[:, axis + 1:], axis=1)
         jobs[:, 6] = [idx_off[int(q)] for q in old_q[:, axis]]
-        jd, idd = dev.to_device(jobs), dev.to_device(idx if len(idx) else np.zeros(1, np.int64))
+        jd, idd = dev.table(jobs), dev.table(idx if len(idx) else np.zeros(1, np.int64))
         dev.check(dev.lib().tpa_gather_axis_batch(dev.code(self.dtype), jd.data_ptr(), len(jobs),
                                                   int(np.max(np.prod(new_shapes, axis=1))), idd.data_ptr(),
                                                   self._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "gather")
@@ -1594,7 +1594,7 @@ def _run_copy(dtype, jobs, max_elems, src_arena, dst_arena):
     L = dev.lib()
     for s in range(0, len(jobs), 60000):
         chunk = jobs[s:s + 60000]
-        jd = dev.to_device(chunk)
+        jd = dev.table(chunk)
         dev.check(L.tpa_copy_batch(dev.code(dtype), jd.data_ptr(), len(chunk), int(max_elems), src_arena.data_ptr(),
                                    dst_arena.data_ptr(), dev.stream()), "copy_batch")
 
@@ -3028,7 +3028,7 @@ def _permute_within_blocks(a, perm_flat, axis):
     local = np.asarray(perm_flat, dtype=np.int64).copy()
     for q in range(leg.block_number):
         local[leg.slices[q]:leg.slices[q + 1]] -= leg.slices[q]
-    jd, idd = dev.to_device(jobs), dev.to_device(local)
+    jd, idd = dev.table(jobs), dev.table(local)
     dev.check(dev.lib().tpa_gather_axis_batch(dev.code(a.dtype), jd.data_ptr(), len(jobs), int(np.max(sizes)), idd.data_ptr(),
                                               a._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "gather")
     res._skey = None
