@@ -15,6 +15,7 @@
 // which is what the 1e-10 parity bound on singular values needs.
 #include "tpa_common.h"
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -2544,7 +2545,7 @@ struct Layout {
     std::vector<B32Entry> b32_entries;   // (job, pair, part) of the 32-row-block rounds
     std::vector<B32Pair> b32_pairs;
     int64_t nb32_max_pad = 0;
-    int64_t off_b32e = 0, off_b32p = 0, off_b32g = 0, off_b32q = 0, off_b32f = 0;
+    int64_t off_b32e = 0, off_b32p = 0, off_b32g = 0, off_b32q = 0, off_b32f = 0, off_tab_end = 0;
     bool wide_ok = true;           // every job has <= FIT * NTW / 64 column chunks of [W | G]
     int64_t nb_max_pad = 0;
     int64_t max_part_chunks = 0;   // largest number of (W + G) column chunks of one part (fused round: <= 4 * FIT)
@@ -2658,6 +2659,11 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.bentries.size() * sizeof(BEntry), 256);
     lay.off_wpairs = o;
     o = align_up(o + (int64_t)lay.wpairs.size() * sizeof(int2), 256);
+    lay.off_b32e = o;            // (the host-built tables off_jobs .. off_tab_end are contiguous: ONE staged upload, svd_upload_tables)
+    o = align_up(o + (int64_t)lay.b32_entries.size() * sizeof(B32Entry), 256);
+    lay.off_b32p = o;
+    o = align_up(o + (int64_t)lay.b32_pairs.size() * sizeof(B32Pair), 256);
+    lay.off_tab_end = o;
     lay.off_pcnt = o;
     o = align_up(o + (int64_t)lay.bentries.size() * 4 + 64, 256);   // per-entry pair counters + error flag
     lay.off_gpart = o;
@@ -2668,10 +2674,6 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.jobs.size() * 8, 256);
     lay.off_fpart = o;
     o = align_up(o + (int64_t)lay.jobs.size() * 64 * 8, 256);
-    lay.off_b32e = o;
-    o = align_up(o + (int64_t)lay.b32_entries.size() * sizeof(B32Entry), 256);
-    lay.off_b32p = o;
-    o = align_up(o + (int64_t)lay.b32_pairs.size() * sizeof(B32Pair), 256);
     lay.off_b32f = o;
     o = align_up(o + (int64_t)lay.b32_pairs.size() * 4, 256);
     if (dtype != TPA_C128) {
@@ -2713,6 +2715,61 @@ int64_t fused_round_capacity_c() {
     return cap;
 }
 
+// ---- pinned staging of the host-built tables and of the few words the host reads back ----------------------------------------
+// hipMemcpyAsync from / to PAGEABLE memory is a blocking host call (the runtime stages the data and waits), and the block SVD
+// issued 8 - 10 of them per call in front of its launch chains: the round-3 idle-gap analysis (scripts/gap_analysis.py) shows
+// ~18 of them per bond update with the GPU idle for ~45 us each.  Now every upload goes through ONE pinned arena per host
+// thread (bump allocation, reset at the entry of tpa_svd_batch / tpa_eigh_batch, whose previous call ended with a stream
+// synchronisation), all tables of a run in ONE copy, and the convergence counters are posted by a 1-thread kernel into mapped
+// pinned memory.
+struct PinStage {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+    void reset() { used = 0; }
+    char *take(size_t bytes, hipStream_t st) {
+        const size_t need = (used + 255) / 256 * 256;
+        if (base == nullptr || need + bytes > cap) {
+            if (base != nullptr) {
+                if (hipStreamSynchronize(st) != hipSuccess) return nullptr;   // copies out of the old arena may still be queued
+                (void)hipHostFree(base);
+                base = nullptr;
+            }
+            cap = std::max<size_t>(2 * (need + bytes), (size_t)4 << 20);
+            if (hipHostMalloc((void **)&base, cap, hipHostMallocDefault) != hipSuccess) {
+                base = nullptr;
+                cap = 0;
+                return nullptr;
+            }
+            used = 0;
+            return take(bytes, st);
+        }
+        used = need + bytes;
+        return base + need;
+    }
+};
+inline PinStage &pin_stage() {
+    static thread_local PinStage p;
+    return p;
+}
+#define TPA_STAGE_CHECK(ptr)                                                                         \
+    do {                                                                                             \
+        if ((ptr) == nullptr) {                                                                      \
+            snprintf(tpa_errbuf, sizeof(tpa_errbuf), "%s:%d: pinned staging allocation failed", __FILE__, __LINE__); \
+            return TPA_E_NOMEM;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+__global__ void post_words_kernel(const unsigned int *__restrict__ a, int na, const int *__restrict__ b, unsigned int *__restrict__ host) {
+    for (int i = 0; i < na; ++i) host[i] = a[i];
+    if (b != nullptr) host[na] = (unsigned int)b[0];
+    __threadfence_system();
+}
+
+template <class T>
+inline void stage_put(char *stage, int64_t off0, int64_t off, const std::vector<T> &v) {
+    if (!v.empty()) memcpy(stage + (off - off0), v.data(), v.size() * sizeof(T));
+}
+
 template <bool CPLX>
 int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, double *s_dev,
             void *vh_base, char *work, int max_sweeps, int *sweeps_done, hipStream_t st, double rho) {
@@ -2724,15 +2781,22 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     int2 *rows = (int2 *)(work + lay.off_rows);
     int2 *pairs = (int2 *)(work + lay.off_pairs);
     unsigned int *cnt = (unsigned int *)(work + lay.off_cnt);
-    TPA_HIP_CHECK(hipMemcpyAsync(jobs, lay.jobs.data(), lay.jobs.size() * sizeof(SvdJob), hipMemcpyHostToDevice, st));
-    TPA_HIP_CHECK(hipMemcpyAsync(rows, lay.rows.data(), lay.rows.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-    TPA_HIP_CHECK(hipMemcpyAsync(pairs, lay.pairs.data(), lay.pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     BEntry *bent = (BEntry *)(work + lay.off_bent);
     double *gpart = (double *)(work + lay.off_gpart);
-    TPA_HIP_CHECK(hipMemcpyAsync(bent, lay.bentries.data(), lay.bentries.size() * sizeof(BEntry), hipMemcpyHostToDevice, st));
     int2 *wpairs = (int2 *)(work + lay.off_wpairs);
-    TPA_HIP_CHECK(hipMemcpyAsync(wpairs, lay.wpairs.data(), lay.wpairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
-    // pageable host memory: the copies above are staged before returning, vectors may die later.
+    {   // all host-built tables in one copy out of the pinned arena
+        const int64_t t0 = lay.off_jobs, tbytes = lay.off_tab_end - lay.off_jobs;
+        char *stg = pin_stage().take((size_t)tbytes, st);
+        TPA_STAGE_CHECK(stg);
+        stage_put(stg, t0, lay.off_jobs, lay.jobs);
+        stage_put(stg, t0, lay.off_rows, lay.rows);
+        stage_put(stg, t0, lay.off_pairs, lay.pairs);
+        stage_put(stg, t0, lay.off_bent, lay.bentries);
+        stage_put(stg, t0, lay.off_wpairs, lay.wpairs);
+        stage_put(stg, t0, lay.off_b32e, lay.b32_entries);
+        stage_put(stg, t0, lay.off_b32p, lay.b32_pairs);
+        TPA_HIP_CHECK(hipMemcpyAsync(work + t0, stg, (size_t)tbytes, hipMemcpyHostToDevice, st));
+    }
     const int g_rows = (int)(lay.rows.size() / (NT / 64));
     const int g_pairs = (int)(lay.pairs.size() / (NT / 64));
     if (g_rows == 0) {
@@ -2748,6 +2812,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     TPA_LAUNCH_CHECK();
     int sweep = 0;
     bool converged = (lay.rmax_pad < 2);
+    unsigned int *posted = (unsigned int *)pin_stage().take(64, st);      // convergence counters (+ error flag), written by post_words_kernel
+    TPA_STAGE_CHECK(posted);
     const bool use_block = !tpa_svd_force_pairwise;
     // fused one-launch round: the spin-waits between sibling workgroups need the whole grid resident (4 workgroups of 38 KB LDS
     // per CU) and every part must fit the register-resident chunk budget.  (Oversubscribing the resident set by 4x / 16x was
@@ -2761,10 +2827,6 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     B32Pair *b32p = (B32Pair *)(work + lay.off_b32p);
     int *b32f = (int *)(work + lay.off_b32f);
     double *b32g = (double *)(work + lay.off_b32g), *b32q = (double *)(work + lay.off_b32q);
-    if (use_b32) {
-        TPA_HIP_CHECK(hipMemcpyAsync(b32e, lay.b32_entries.data(), lay.b32_entries.size() * sizeof(B32Entry), hipMemcpyHostToDevice, st));
-        TPA_HIP_CHECK(hipMemcpyAsync(b32p, lay.b32_pairs.data(), lay.b32_pairs.size() * sizeof(B32Pair), hipMemcpyHostToDevice, st));
-    }
     const bool use_fused_c = use_block && CPLX && tpa_svd_fused_round && lay.max_part_chunks <= 4 * FITC &&
                              (int64_t)lay.bentries.size() <= fused_round_capacity_c();
     unsigned int *pcnt = (unsigned int *)(work + lay.off_pcnt);
@@ -2803,9 +2865,14 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         TPA_LAUNCH_CHECK();
         unsigned int h2[2] = {0, 0};
         int herr = 0;
-        TPA_HIP_CHECK(hipMemcpyAsync(h2, cnt, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-        if (!use_b32 && ((use_fused && !use_wide) || use_fused_c)) TPA_HIP_CHECK(hipMemcpyAsync(&herr, perr, sizeof(int), hipMemcpyDeviceToHost, st));
-        TPA_HIP_CHECK(hipStreamSynchronize(st));
+        {
+            const bool with_err = !use_b32 && ((use_fused && !use_wide) || use_fused_c);
+            post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, with_err ? perr : nullptr, posted);
+            TPA_HIP_CHECK(hipStreamSynchronize(st));
+            h2[0] = posted[0];
+            h2[1] = posted[1];
+            herr = with_err ? (int)posted[2] : 0;
+        }
         if (herr) {
             snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: sibling workgroups of a fused Jacobi round lost each other (spin limit)");
             return TPA_E_NOCONV;
@@ -2816,15 +2883,17 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     if (sweeps_done) *sweeps_done = sweep;
     svd_norms_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, W, sig);
     TPA_LAUNCH_CHECK();
-    std::vector<double> hs(lay.sig_elems);
-    TPA_HIP_CHECK(hipMemcpyAsync(hs.data(), sig, lay.sig_elems * 8, hipMemcpyDeviceToHost, st));
+    double *hs = (double *)pin_stage().take((size_t)lay.sig_elems * 8 + 8, st);
+    int64_t *hp = (int64_t *)pin_stage().take((size_t)lay.sig_elems * 8 + 8, st);
+    TPA_STAGE_CHECK(hs);
+    TPA_STAGE_CHECK(hp);
+    TPA_HIP_CHECK(hipMemcpyAsync(hs, sig, lay.sig_elems * 8, hipMemcpyDeviceToHost, st));
     TPA_HIP_CHECK(hipStreamSynchronize(st));
-    std::vector<int64_t> hp(lay.sig_elems);
     bool bad = false;
     for (int b = 0; b < n_jobs; ++b) {
         const SvdJob &J = lay.jobs[b];
-        int64_t *p = hp.data() + J.sig_off;
-        const double *s = hs.data() + J.sig_off;
+        int64_t *p = hp + J.sig_off;
+        const double *s = hs + J.sig_off;
         std::iota(p, p + J.R, (int64_t)0);
         std::stable_sort(p, p + J.R, [s](int64_t x, int64_t y) { return s[x] > s[y]; });
         for (int64_t i = 0; i < J.R; ++i)
@@ -2834,10 +2903,10 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: NaN/Inf in singular values");
         return TPA_E_NAN;
     }
-    TPA_HIP_CHECK(hipMemcpyAsync(perm, hp.data(), lay.sig_elems * 8, hipMemcpyHostToDevice, st));
+    TPA_HIP_CHECK(hipMemcpyAsync(perm, hp, lay.sig_elems * 8, hipMemcpyHostToDevice, st));
     svd_finish_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, perm, W, G, sig, (double *)u_base, s_dev, (double *)vh_base);
     TPA_LAUNCH_CHECK();
-    TPA_HIP_CHECK(hipStreamSynchronize(st));  // hp must outlive the async copy
+    TPA_HIP_CHECK(hipStreamSynchronize(st));  // callers read the results (and the staging arena is reused by the next call)
     if (!converged) {
         snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: no convergence in %d sweeps", max_sweeps);
         return TPA_E_NOCONV;
@@ -2967,8 +3036,14 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     SvdJob *sjobs = (SvdJob *)(work + q.off_sjobs);
     QrpState *state = (QrpState *)(work + q.off_state);
     double *fro2 = (double *)(work + q.off_fro), *fpart = (double *)(work + q.off_fpart);
-    TPA_HIP_CHECK(hipMemcpyAsync(qjobs, q.qjobs.data(), q.qjobs.size() * sizeof(QrpJob), hipMemcpyHostToDevice, st));
-    TPA_HIP_CHECK(hipMemcpyAsync(sjobs, lay.jobs.data(), lay.jobs.size() * sizeof(SvdJob), hipMemcpyHostToDevice, st));
+    {   // qjobs and sjobs are neighbours in the work arena: one staged copy
+        const int64_t t0 = q.off_qjobs, tbytes = q.off_sjobs + (int64_t)lay.jobs.size() * sizeof(SvdJob) - q.off_qjobs;
+        char *stg = pin_stage().take((size_t)tbytes, st);
+        TPA_STAGE_CHECK(stg);
+        stage_put(stg, t0, q.off_qjobs, q.qjobs);
+        stage_put(stg, t0, q.off_sjobs, lay.jobs);
+        TPA_HIP_CHECK(hipMemcpyAsync(work + t0, stg, (size_t)tbytes, hipMemcpyHostToDevice, st));
+    }
     svd_fro_kernel<CPLX><<<dim3(FRO_PARTS, n_jobs), NT, 0, st>>>(sjobs, (const double *)a_base, fpart);
     svd_fro_sum_kernel<<<n_jobs, 64, 0, st>>>(sjobs, fpart, fro2);
     { const char *e = getenv("TPA_SVD_SMALL_PANEL"); if (e) tpa_svd_small_panel = atoi(e); }
@@ -3047,12 +3122,15 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
         qrp_extract_kernel_c<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const cd *)X, cperm, (cd *)Rtop);
     else
         qrp_extract_kernel<<<dim3(64, n_jobs), NT, 0, st>>>(qjobs, state, (const double *)X, cperm, (double *)Rtop);
-    TPA_HIP_CHECK(hipMemcpyAsync(hstate.data(), state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
-    TPA_HIP_CHECK(hipStreamSynchronize(st));
-    {   // NaN / Inf in the input: ||A||_F^2 is not finite (the pivot search would silently report rank 0)
-        std::vector<double> hfro(n_jobs);
-        TPA_HIP_CHECK(hipMemcpyAsync(hfro.data(), fro2, n_jobs * sizeof(double), hipMemcpyDeviceToHost, st));
+    {   // final states and ||A||_F^2 (NaN / Inf in the input: not finite -- the pivot search would silently report rank 0): one wait
+        QrpState *pst = (QrpState *)pin_stage().take((size_t)n_jobs * sizeof(QrpState), st);
+        double *hfro = (double *)pin_stage().take((size_t)n_jobs * 8, st);
+        TPA_STAGE_CHECK(pst);
+        TPA_STAGE_CHECK(hfro);
+        TPA_HIP_CHECK(hipMemcpyAsync(pst, state, n_jobs * sizeof(QrpState), hipMemcpyDeviceToHost, st));
+        TPA_HIP_CHECK(hipMemcpyAsync(hfro, fro2, n_jobs * sizeof(double), hipMemcpyDeviceToHost, st));
         TPA_HIP_CHECK(hipStreamSynchronize(st));
+        for (int b = 0; b < n_jobs; ++b) hstate[b] = pst[b];
         for (int b = 0; b < n_jobs; ++b)
             if (!std::isfinite(hfro[b])) {
                 snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: NaN/Inf in block %d", b);
@@ -3271,6 +3349,7 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
     for (int b = 0; b < n_jobs; ++b) TPA_ARG_CHECK(jobs_host[8 * b + 1] > 0 && jobs_host[8 * b + 2] > 0);
+    pin_stage().reset();      // the previous call on this thread ended with a stream synchronisation
     Layout lay = make_layout(dtype, jobs_host, n_jobs);
     TPA_ARG_CHECK(work_bytes >= lay.total);
     hipStream_t st = (hipStream_t)stream;
@@ -3415,6 +3494,7 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
     for (int b = 0; b < n_jobs; ++b) TPA_ARG_CHECK(jobs_host[8 * b + 1] > 0);
+    pin_stage().reset();
     EighLayout lay = make_eigh_layout(dtype, jobs_host, n_jobs);
     TPA_ARG_CHECK(work_bytes >= lay.total);
     hipStream_t st = (hipStream_t)stream;
