@@ -88,11 +88,45 @@ def scratch(name, n, dtype):
     return buf.view(tdt)[:max(int(n), 1)] if n > 0 else buf.view(tdt)[:0]
 
 
+PIN_RING_BYTES = 64 << 20
+PIN_MAX_BYTES = 1 << 20
+_pin_ring = None
+_pin_lock = None
+
+
 def to_device(arr):
-    """numpy array (any int/float dtype) -> device tensor of the same dtype (blocking H2D)."""
+    """numpy array (any int/float dtype) -> device tensor of the same dtype.
+
+    Small arrays (tables, scale vectors, singular values: <= 1 MB) go through a persistent PINNED ring buffer and a non-blocking
+    copy on the current stream: ``tensor.to('cuda')`` from pageable memory blocks the host for ~40 us per call, and the per-call
+    tables of the warm start / Loewdin clean-up alone are 10 - 20 uploads per ``npc.svd`` (round-3 idle-gap analysis: the GPU sat
+    idle behind them).  The source is copied into the ring before this returns, so the caller may reuse it at once; the ring wraps
+    after a device synchronisation (every few hundred uploads).  Larger arrays: plain (blocking) copy."""
+    global _pin_ring, _pin_lock
     _lib.require_gpu()
+    t = torch()
     arr = np.ascontiguousarray(arr)
-    return torch().from_numpy(arr).to('cuda')
+    nb = arr.nbytes
+    if nb == 0 or nb > PIN_MAX_BYTES or arr.dtype.kind not in 'iufcb' or arr.dtype.itemsize > 16:
+        return t.from_numpy(arr).to('cuda')
+    tdt = t.from_numpy(np.empty(0, dtype=arr.dtype)).dtype
+    if _pin_lock is None:
+        import threading
+        _pin_lock = threading.Lock()
+    with _pin_lock:
+        if _pin_ring is None:
+            buf = t.empty(PIN_RING_BYTES, dtype=t.uint8).pin_memory()
+            _pin_ring = [buf, buf.numpy(), 0]
+        buf, view, pos = _pin_ring
+        pos = (pos + 255) // 256 * 256
+        if pos + nb > PIN_RING_BYTES:
+            t.cuda.synchronize()          # every copy that was queued out of the ring has been executed
+            pos = 0
+        view[pos:pos + nb] = arr.reshape(-1).view(np.uint8)
+        _pin_ring[2] = pos + nb
+        dst = t.empty(nb, dtype=t.uint8, device='cuda')
+        dst.copy_(buf[pos:pos + nb], non_blocking=True)
+    return dst.view(tdt).reshape(arr.shape)
 
 
 _table_cache = None
