@@ -597,11 +597,38 @@ class TwoSiteH:
                 ops[1, :9] = [0, p2.cfg, p2.tasks_dev.data_ptr(), p2.links_dev.data_ptr(), p2.tiles_dev.data_ptr(), p2.n_tiles, 2, 1, -2]
                 res = (ops, bufs, (p1, p2))
                 last = p2
+        self.__dict__['_program_out'] = None
         if res is not None and not (last.res_total == theta._arena.numel() and np.array_equal(last.res_qdata, theta._qdata)
                                     and np.array_equal(last.res_offsets, theta._offsets)):
+            self.__dict__['_program_out'] = (key, last.res_qdata, last.res_offsets, last.res_total)
             res = None
         self.__dict__['_program'] = (key, res)
         return res
+
+    def native_input(self, theta, max_pad=2):
+        """``(vector, program)`` for ``tpa_lanczos_run``: ``theta`` itself, or -- when H_eff creates blocks that ``theta`` does not
+        store (tiny extreme charge sectors of a state grown from a product state: the first Krylov step of the step-by-step
+        loop goes the generic way for them) -- ``theta`` embedded with zero blocks in the block structure of ``H_eff theta``,
+        provided that structure is closed under another application.  ``None`` if no replayable program exists."""
+        vec = theta
+        for _ in range(max_pad + 1):
+            prog = self.matvec_program(vec)
+            if prog is not None:
+                return vec, prog
+            out = self.__dict__.get('_program_out')
+            if out is None or out[0] != (vec._struct_key(), vec.dtype):
+                return None
+            _, qdata, offsets, total = out
+            have = {tuple(r) for r in qdata.tolist()}
+            if not all(tuple(r) in have for r in vec._qdata.tolist()):
+                return None                      # H_eff theta lacks blocks of theta: not an embedding
+            pad = npc.Array(vec.legs, vec.dtype, vec.qtotal, vec.get_leg_labels())
+            pad._set_blocks(qdata, arena=dev.zeros(total, vec.dtype), qdata_sorted=True)
+            if not np.array_equal(pad._offsets, offsets):
+                return None
+            npc._scatter_blocks(vec, pad, pad._arena)
+            vec = pad
+        return None
 
     def _plan_matches(self, theta):
         return self._plans[2] == theta._struct_key() and self._plans[3] == theta.dtype

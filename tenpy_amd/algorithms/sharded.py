@@ -103,6 +103,7 @@ def restrict_plan_rows(plan, res_leg0, lo, hi):
 class ShardedTwoSiteH(TwoSiteH):
     """TwoSiteH whose matvec is sharded over ``torch.distributed`` ranks by rows of theta'."""
     matvec_program = None       # the sharded matvec has an all-gather inside: not a replayable single-GPU launch program
+    native_input = None
 
     def __init__(self, env, i0, combine=True, move_right=True, group=None):
         super().__init__(env, i0, combine, move_right)      # factored when the MPO allows it, else row panels of LHeff

@@ -80,13 +80,17 @@ class LanczosGroundState:
         and the options are the ones the native loop covers (no re-orthogonalisation, all Krylov vectors cached)."""
         if not (NATIVE and PIPELINED) or self.reortho or self.N_cache < self.N_max or self.N_max + 1 > 64:
             return None
-        make = getattr(self.H, 'matvec_program', None)
+        make = getattr(self.H, 'native_input', None)
         if make is None:
             return None
         w = self.psi0
         if w.stored_blocks == 0 or not w._is_packed():
             return None
-        return make(w)
+        got = make(w)
+        if got is None:
+            return None
+        self.psi0, prog = got          # (possibly theta embedded in the block structure of H theta)
+        return prog
 
     def _run_native(self, prog):
         """``_build_krylov`` + ``_calc_result_full`` through ``tpa_lanczos_run`` / ``tpa_krylov_combine``: the device side of every
