@@ -2432,8 +2432,19 @@ from . import _svd_warm  # noqa: E402
 
 def _svd_sig_counts(S_host, ks, s_offs, rel):
     """Per block: number of singular values above ``rel * |S_b|_2`` (they are sorted descending inside a block)."""
-    out = np.zeros(len(ks), dtype=np.int64)
-    for b in range(len(ks)):
+    ks = np.asarray(ks, dtype=np.int64)
+    nb = len(ks)
+    if nb == 0:
+        return np.zeros(0, dtype=np.int64)
+    starts = np.asarray(s_offs[:nb], dtype=np.int64)
+    if np.all(ks > 0) and np.array_equal(starts[1:], starts[:-1] + ks[:-1]) and starts[-1] + ks[-1] <= len(S_host):
+        seg = S_host[starts[0]:starts[-1] + ks[-1]]        # the blocks lie back to back: one segmented reduction
+        rel_starts = starts - starts[0]
+        fro = np.sqrt(np.add.reduceat(seg * seg, rel_starts))
+        above = seg > np.repeat(rel * fro, ks)
+        return np.where(fro > 0., np.add.reduceat(above.astype(np.int64), rel_starts), 0)
+    out = np.zeros(nb, dtype=np.int64)
+    for b in range(nb):
         sb = S_host[s_offs[b]:s_offs[b] + ks[b]]
         fro = float(np.sqrt(np.sum(sb * sb)))
         out[b] = int(np.sum(sb > rel * fro)) if fro > 0. else 0
