@@ -40,14 +40,34 @@ def _gemm_tile(dtype):
     return npc._gemm_tile(np.dtype(dtype), 1)
 
 
-def raw_gemm(dtype, spec, A_arena, B_arena, C_arena):
-    """Batched ``C_t = A_t B_t`` on raw arenas.  ``spec``: int64 ``[n, 12]`` rows
-    ``(c_off, m, n, ldc, a_off, a_rs, a_ks, b_off, b_ks, b_ns, k, flags)`` with ``A_t(i, l) = A[a_off + i a_rs + l a_ks]``,
-    ``B_t(l, j) = B[b_off + l b_ks + j b_ns]`` (flags bit 0 / 1: conjugate A / B).  Tables are cached by content."""
+_plans = OrderedDict()        # host-side plans of the functions below, keyed by the bytes of their integer inputs
+_PLANS_MAX = 16384
+
+
+def _plan_get(key):
+    pl = _plans.get(key)
+    if pl is not None:
+        _plans.move_to_end(key)
+    return pl
+
+
+def _plan_put(key, pl):
+    _plans[key] = pl
+    if len(_plans) > _PLANS_MAX:
+        _plans.popitem(last=False)
+    return pl
+
+
+def _key(tag, *arrays):
+    return (tag,) + tuple(a.tobytes() if isinstance(a, np.ndarray) else a for a in arrays)
+
+
+def gemm_table(dtype, spec):
+    """Device tables of :func:`raw_gemm` for ``spec`` (None if there is nothing to do), cached by content."""
     spec = np.ascontiguousarray(spec, dtype=np.int64)
     spec = spec[(spec[:, 1] > 0) & (spec[:, 2] > 0)]
     if len(spec) == 0:
-        return
+        return None
     dtype = np.dtype(dtype)
     key = (dtype.str, spec.tobytes())
     tab = _tables.get(key)
@@ -75,24 +95,45 @@ def raw_gemm(dtype, spec, A_arena, B_arena, C_arena):
             _tables.popitem(last=False)
     else:
         _tables.move_to_end(key)
-    dev.check(dev.lib().tpa_gemm_chain(dev.code(dtype), 1, tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr(), tab[3],
-                                       A_arena.data_ptr(), B_arena.data_ptr(), C_arena.data_ptr(), dev.stream()), "gemm_chain")
+    return tab
+
+
+def run_gemm(dtype, tab, A_arena, B_arena, C_arena):
+    if tab is not None:
+        dev.check(dev.lib().tpa_gemm_chain(dev.code(dtype), 1, tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr(), tab[3],
+                                           A_arena.data_ptr(), B_arena.data_ptr(), C_arena.data_ptr(), dev.stream()), "gemm_chain")
+
+
+def copy_table(jobs):
+    jobs = np.ascontiguousarray(jobs, dtype=np.int64)
+    if len(jobs) == 0:
+        return None
+    key = ('copy', jobs.tobytes())
+    tab = _tables.get(key)
+    if tab is None:
+        tab = (dev.to_device(jobs), int(np.max(np.prod(jobs[:, 4:4 + COPY_MAXDIM].clip(1), axis=1))), len(jobs))
+        _tables[key] = tab
+        if len(_tables) > _TABLES_MAX:
+            _tables.popitem(last=False)
+    return tab
+
+
+def run_copy(dtype, tab, src_arena, dst_arena):
+    if tab is not None:
+        dev.check(dev.lib().tpa_copy_batch(dev.code(dtype), tab[0].data_ptr(), tab[2], tab[1], src_arena.data_ptr(),
+                                           dst_arena.data_ptr(), dev.stream()), "copy_batch")
+
+
+def raw_gemm(dtype, spec, A_arena, B_arena, C_arena):
+    """Batched ``C_t = A_t B_t`` on raw arenas.  ``spec``: int64 ``[n, 12]`` rows
+    ``(c_off, m, n, ldc, a_off, a_rs, a_ks, b_off, b_ks, b_ns, k, flags)`` with ``A_t(i, l) = A[a_off + i a_rs + l a_ks]``,
+    ``B_t(l, j) = B[b_off + l b_ks + j b_ns]`` (flags bit 0 / 1: conjugate A / B).  Tables are cached by content."""
+    run_gemm(dtype, gemm_table(dtype, spec), A_arena, B_arena, C_arena)
 
 
 def raw_copy(dtype, jobs, src_arena, dst_arena):
     """``tpa_copy_batch`` on host-built jobs (cached upload by content)."""
-    jobs = np.ascontiguousarray(jobs, dtype=np.int64)
-    if len(jobs) == 0:
-        return
-    key = ('copy', jobs.tobytes())
-    tab = _tables.get(key)
-    if tab is None:
-        tab = (dev.to_device(jobs), int(np.max(np.prod(jobs[:, 4:4 + COPY_MAXDIM].clip(1), axis=1))))
-        _tables[key] = tab
-        if len(_tables) > _TABLES_MAX:
-            _tables.popitem(last=False)
-    dev.check(dev.lib().tpa_copy_batch(dev.code(dtype), tab[0].data_ptr(), len(jobs), tab[1], src_arena.data_ptr(),
-                                       dst_arena.data_ptr(), dev.stream()), "copy_batch")
+    run_copy(dtype, copy_table(jobs), src_arena, dst_arena)
 
 
 def copy_jobs_2d(dst_off, dst_rs, dst_cs, src_off, src_rs, src_cs, rows, cols, conj=False):
@@ -121,29 +162,41 @@ def lowdin_rows(dtype, arena, off, nvec, length, vs, cs, iterations=1):
     """In place ``V <- (3 I - V V^H) V / 2`` for sets of vectors ``V_t[i][j] = arena[off_t + i vs_t + j cs_t]`` (``i < nvec_t``,
     ``j < length_t``): first-order symmetric orthonormalisation; a defect d = |V V^H - 1| becomes 3 d^2 / 8.
     The vectors are gathered into a contiguous buffer T, then per iteration G = T T^H, T2 = G T (matrix cores),
-    T <- 1.5 T - 0.5 T2, and scattered back."""
-    off, nvec, length, vs, cs = (np.asarray(x, dtype=np.int64) for x in (off, nvec, length, vs, cs))
-    keep = nvec > 0
-    off, nvec, length, vs, cs = off[keep], nvec[keep], length[keep], vs[keep], cs[keep]
-    if len(off) == 0:
-        return
+    T <- 1.5 T - 0.5 T2, and scattered back.  The tables depend on the integer arguments only and are planned once."""
     dtype = np.dtype(dtype)
-    cplx = dtype.kind == 'c'
-    g_off = np.concatenate([[0], np.cumsum(nvec * nvec)])
-    t_off = np.concatenate([[0], np.cumsum(nvec * length)])
-    z = np.zeros(len(off), dtype=np.int64)
-    one = z + 1
-    T = dev.scratch('lowdin_T', int(t_off[-1]), dtype)
-    raw_copy(dtype, copy_jobs_2d(t_off[:-1], length, one, off, vs, cs, nvec, length), arena, T)
+    off, nvec, length, vs, cs = (np.ascontiguousarray(x, dtype=np.int64) for x in (off, nvec, length, vs, cs))
+    key = _key('lowdin', dtype.str, off, nvec, length, vs, cs)
+    pl = _plan_get(key)
+    if pl is None:
+        keep = nvec > 0
+        o, nv, ln, v, c = off[keep], nvec[keep], length[keep], vs[keep], cs[keep]
+        if len(o) == 0:
+            pl = _plan_put(key, False)
+        else:
+            cplx = dtype.kind == 'c'
+            g_off = np.concatenate([[0], np.cumsum(nv * nv)])
+            t_off = np.concatenate([[0], np.cumsum(nv * ln)])
+            z = np.zeros(len(o), dtype=np.int64)
+            one = z + 1
+            pl = _plan_put(key, dict(
+                nT=int(t_off[-1]), nG=int(g_off[-1]),
+                gather=copy_table(copy_jobs_2d(t_off[:-1], ln, one, o, v, c, nv, ln)),
+                gram=gemm_table(dtype, np.stack([g_off[:-1], nv, nv, nv, t_off[:-1], ln, one, t_off[:-1], one, ln, ln,
+                                                 z + (2 if cplx else 0)], axis=1)),
+                mult=gemm_table(dtype, np.stack([t_off[:-1], nv, ln, ln, g_off[:-1], nv, one, t_off[:-1], ln, one, nv, z], axis=1)),
+                scatter=copy_table(copy_jobs_2d(o, v, c, t_off[:-1], ln, one, nv, ln))))
+    if pl is False:
+        return
+    T = dev.scratch('lowdin_T', pl['nT'], dtype)
+    run_copy(dtype, pl['gather'], arena, T)
     for _ in range(iterations):
-        G = dev.scratch('lowdin_G', int(g_off[-1]), dtype)
-        raw_gemm(dtype, np.stack([g_off[:-1], nvec, nvec, nvec, t_off[:-1], length, one, t_off[:-1], one, length, length,
-                                  z + (2 if cplx else 0)], axis=1), T, T, G)
-        T2 = dev.scratch('lowdin_T2', int(t_off[-1]), dtype)
-        raw_gemm(dtype, np.stack([t_off[:-1], nvec, length, length, g_off[:-1], nvec, one, t_off[:-1], length, one, nvec, z], axis=1), G, T, T2)
+        G = dev.scratch('lowdin_G', pl['nG'], dtype)
+        run_gemm(dtype, pl['gram'], T, T, G)
+        T2 = dev.scratch('lowdin_T2', pl['nT'], dtype)
+        run_gemm(dtype, pl['mult'], G, T, T2)
         _scal(dtype, 1.5, T)
         _axpy(dtype, -0.5, T2, T)
-    raw_copy(dtype, copy_jobs_2d(off, vs, cs, t_off[:-1], length, one, nvec, length), T, arena)
+    run_copy(dtype, pl['scatter'], T, arena)
 
 
 class Basis:
@@ -188,26 +241,39 @@ def cache_put(key, side, basis):
         _cache.popitem(last=False)
 
 
+def _row_norms_plan(off, rows, cols):
+    off, rows, cols = (np.ascontiguousarray(x, dtype=np.int64) for x in (off, rows, cols))
+    key = _key('rownorms', off, rows, cols)
+    pl = _plan_get(key)
+    if pl is None:
+        nb = len(off)
+        o_off = np.concatenate([[0], np.cumsum(rows)])
+        jobs = np.zeros((nb, 6), dtype=np.int64)
+        jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3], jobs[:, 4] = off, 1, rows, cols, o_off[:-1]
+        tab = np.zeros(((int(o_off[-1]) + 3) // 4 * 4, 2), dtype=np.int32) - 1
+        tab[:int(o_off[-1]), 0] = np.repeat(np.arange(nb), rows)
+        tab[:int(o_off[-1]), 1] = np.arange(int(o_off[-1])) - np.repeat(o_off[:-1], rows)
+        pl = _plan_put(key, (dev.to_device(jobs), dev.to_device(tab), len(tab), int(o_off[-1]), o_off[:-1].copy(), nb))
+    return pl
+
+
+def _row_norms_launch(dtype, arena, pl):
+    """Enqueue the per-row squared norms; returns the device buffer (read it with :func:`_row_norms_read`)."""
+    out = dev.empty(pl[3], np.float64)
+    dev.check(dev.lib().tpa_axis_sqnorm_batch(dev.code(dtype), pl[0].data_ptr(), pl[1].data_ptr(), pl[2], arena.data_ptr(),
+                                              out.data_ptr(), dev.stream()), "axis_sqnorm")
+    return out
+
+
+def _row_norms_read(out, pl):
+    h = dev.to_host(out)
+    return np.add.reduceat(h, pl[4]) if pl[5] else np.zeros(0)
+
+
 def _row_norms_sq(dtype, arena, off, rows, cols):
     """Host float64 array of ``|block_b|_F^2`` (one wavefront per row, summed on the host).  Synchronises."""
-    L = dev.lib()
-    nb = len(off)
-    o_off = np.concatenate([[0], np.cumsum(rows)])
-    jobs = np.zeros((nb, 6), dtype=np.int64)
-    jobs[:, 0], jobs[:, 1], jobs[:, 2], jobs[:, 3], jobs[:, 4] = off, 1, rows, cols, o_off[:-1]
-    tab = np.zeros(((int(o_off[-1]) + 3) // 4 * 4, 2), dtype=np.int32) - 1
-    tab[:int(o_off[-1]), 0] = np.repeat(np.arange(nb), rows)
-    tab[:int(o_off[-1]), 1] = np.arange(int(o_off[-1])) - np.repeat(o_off[:-1], rows)
-    key = ('rn', jobs.tobytes())
-    t = _tables.get(key)
-    if t is None:
-        t = (dev.to_device(jobs), dev.to_device(tab))
-        _tables[key] = t
-    out = dev.empty(int(o_off[-1]), np.float64)
-    dev.check(L.tpa_axis_sqnorm_batch(dev.code(dtype), t[0].data_ptr(), t[1].data_ptr(), len(tab), arena.data_ptr(),
-                                      out.data_ptr(), dev.stream()), "axis_sqnorm")
-    h = dev.to_host(out)
-    return np.add.reduceat(h, o_off[:-1]) if nb else np.zeros(0)
+    pl = _row_norms_plan(off, rows, cols)
+    return _row_norms_read(_row_norms_launch(dtype, arena, pl), pl)
 
 
 DEBUG = bool(os.environ.get('TPA_SVD_WARM_DEBUG'))      # print the residuals |E_b| / |A_b| of every attempt
@@ -233,98 +299,132 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
     dtype = np.dtype(dtype)
     cplx = dtype.kind == 'c'
     nb = len(ms)
-    offs, ms, ns, b_off, b_k, b_len = (np.asarray(x, dtype=np.int64) for x in (offs, ms, ns, b_off, b_k, b_len))
-    R = side == 'R'
-    ps_all = ms if R else ns                  # rows of X
-    ls_all = ns if R else ms                  # length of the basis vectors
-    kk_all = np.minimum(ms, ns)
+    offs, ms, ns, b_off, b_k, b_len = (np.ascontiguousarray(x, dtype=np.int64) for x in (offs, ms, ns, b_off, b_k, b_len))
     done = np.zeros(nb, dtype=bool)
     S_out = [None] * nb
-    act = np.nonzero((b_k > 0) & (b_k <= kk_all) & (b_len == ls_all))[0]
-    stats['fb_shape'] += int(nb - len(act))
-    if len(act) == 0:
+    # ---- stage A (planned once per block / basis structure): which blocks have a fitting basis, W = Bq X^H, the part of A that
+    #      the basis spans, the tables of the two norm reductions
+    keyA = _key('warmA', dtype.str, side, int(a_arena.numel()), offs, ms, ns, b_off, b_k, b_len)
+    A = _plan_get(keyA)
+    if A is None:
+        A = _plan_put(keyA, _warm_plan_a(dtype, cplx, side, int(a_arena.numel()), offs, ms, ns, b_off, b_k, b_len))
+    stats['fb_shape'] += A['n_unfit']
+    if not A['ok']:
         return done, S_out
-    if not (np.array_equal(offs, np.concatenate([[0], np.cumsum(ms * ns)[:-1]])) and int(np.sum(ms * ns)) == a_arena.numel()):
-        return done, S_out                   # blocks not packed back to back (E = A - P is formed on the flat arena)
     U_arena, V_arena, u_off_all, v_off_all = out
-    conjB, conjA = (2 if cplx else 0), (1 if cplx else 0)
-    o, m, n, p, l, kk = offs[act], ms[act], ns[act], ps_all[act], ls_all[act], kk_all[act]
-    z = np.zeros(len(act), dtype=np.int64)
-    one = z + 1
-    x_rs, x_cs = (n, one) if R else (one, n)      # X(j, l) = A[o + j x_rs + l x_cs]
-
-    def residual(bar, boff, bk, sel):
-        """W = Bq X^H for all active blocks;  E = A - (part spanned by the basis) and |E_b|_F^2 for the blocks ``sel``."""
-        w_off = np.concatenate([[0], np.cumsum(bk * p)])
-        W = dev.scratch('warm_W', int(w_off[-1]), dtype)
-        # A(i, l) = Bq[i][l];  B(l, j) = conj(X[j][l])
-        raw_gemm(dtype, np.stack([w_off[:-1], bk, p, p, boff, l, one, o, x_cs, x_rs, l, z + conjB], axis=1), bar, a_arena, W)
-        P = dev.scratch('warm_P', a_arena.numel(), dtype)
-        dev.check(dev.lib().tpa_fill_zero(P.data_ptr(), int(P.numel()) * P.element_size(), dev.stream()), "fill_zero")
-        t = sel
-        if R:       # A = W^H Bq
-            raw_gemm(dtype, np.stack([o[t], m[t], n[t], n[t], w_off[:-1][t], one[t], p[t], boff[t], l[t], one[t], bk[t], z[t] + conjA], axis=1),
-                     W, bar, P)
-        else:       # A = X^T = Bq^T conj(W)
-            raw_gemm(dtype, np.stack([o[t], m[t], n[t], n[t], boff[t], one[t], l[t], w_off[:-1][t], p[t], one[t], bk[t], z[t] + conjB], axis=1),
-                     bar, W, P)
-        E = dev.scratch('warm_E', a_arena.numel(), dtype)
-        E.copy_(a_arena)
-        _axpy(dtype, -1.0, P, E)
-        return W, w_off, E, _row_norms_sq(dtype, E, o[t], m[t], n[t])
-
-    kq = b_k[act].copy()
-    bq_arena, bq_off = b_arena, b_off[act].copy()
-    everyone = np.arange(len(act))
-    W, w_off, E, nrm = residual(bq_arena, bq_off, kq, everyone)
-    nrmA = _row_norms_sq(dtype, a_arena, o, m, n)
+    W = dev.scratch('warm_W', A['nW'], dtype)
+    run_gemm(dtype, A['gemm_W'], b_arena, a_arena, W)
+    P = dev.scratch('warm_P', a_arena.numel(), dtype)
+    dev.check(dev.lib().tpa_fill_zero(P.data_ptr(), int(P.numel()) * P.element_size(), dev.stream()), "fill_zero")
+    if side == 'R':     # A = W^H Bq
+        run_gemm(dtype, A['gemm_P'], W, b_arena, P)
+    else:               # A = X^T = Bq^T conj(W)
+        run_gemm(dtype, A['gemm_P'], b_arena, W, P)
+    E = dev.scratch('warm_E', a_arena.numel(), dtype)
+    E.copy_(a_arena)
+    _axpy(dtype, -1.0, P, E)
+    nE = _row_norms_launch(dtype, E, A['norms'])
+    nA = _row_norms_launch(dtype, a_arena, A['norms'])
+    nrm, nrmA = _row_norms_read(nE, A['norms']), _row_norms_read(nA, A['norms'])        # (one wait: the second is ready with the first)
     ok = np.isfinite(nrm) & np.isfinite(nrmA) & (nrmA > 0.)
     e_rel = np.where(ok, np.sqrt(np.where(ok, nrm, 0.) / np.where(ok, nrmA, 1.)), np.inf)
     stats['e_rel_last'] = float(np.max(np.where(np.isfinite(e_rel), e_rel, 1.)))
     stats['e_rel_max'] = max(stats['e_rel_max'], stats['e_rel_last'])
     if DEBUG:
-        print('warm level -1 e_rel', np.array2string(e_rel, precision=1), 'kq', kq, 'kk', kk, flush=True)
+        print('warm level -1 e_rel', np.array2string(e_rel, precision=1), 'kq', A['kq'], 'kk', A['kk'], flush=True)
     keep = e_rel <= E_TOL
     stats['fb_stale'] += int(np.sum(~keep))
-    # ---- Jacobi on the rows of W (k x p, k <= p), no rank-revealing QR, for the blocks that are still warm
-    sel = np.nonzero(keep)[0]
-    if len(sel) == 0:
+    if not np.any(keep):
         return done, S_out
-    idx = act[sel]
-    o, m, n, p, l, kk, z, one = o[sel], m[sel], n[sel], p[sel], l[sel], kk[sel], z[sel], one[sel]
-    kq = kq[sel]
-    ju_off = np.concatenate([[0], np.cumsum(kq * kq)])
-    js_off = np.concatenate([[0], np.cumsum(kq)])
-    jv_off = np.concatenate([[0], np.cumsum(kq * p)])
-    jjobs = np.zeros((len(sel), 8), dtype=np.int64)
-    jjobs[:, 0], jjobs[:, 1], jjobs[:, 2] = w_off[:-1][sel], kq, p
-    jjobs[:, 3], jjobs[:, 4], jjobs[:, 5] = ju_off[:-1], js_off[:-1], jv_off[:-1]
-    jjobs[:, 6] = 1                       # square blocks: orthogonalise the rows
-    JU = dev.scratch('warm_JU', int(ju_off[-1]), dtype)
-    JV = dev.scratch('warm_JV', int(jv_off[-1]), dtype)
-    JS = dev.scratch('warm_JS', int(js_off[-1]), np.float64)
-    S_J = run_svd(jjobs, W, JU, JS, JV, False)
+    # ---- stage B (planned per set of blocks that are still warm): Jacobi on the rows of W (k x p, k <= p) without any QR, then
+    #      W = U' S VH'  ->  X = VH'^H S (U'^H Bq);  Z = U'^H Bq (k x len) is the accumulated basis
+    keyB = keyA + (keep.tobytes(), u_off_all.tobytes(), v_off_all.tobytes())
+    B = _plan_get(keyB)
+    if B is None:
+        B = _plan_put(keyB, _warm_plan_b(dtype, cplx, side, A, keep, np.asarray(u_off_all, dtype=np.int64), np.asarray(v_off_all, dtype=np.int64)))
+    JU = dev.scratch('warm_JU', B['nJU'], dtype)
+    JV = dev.scratch('warm_JV', B['nJV'], dtype)
+    JS = dev.scratch('warm_JS', B['nJS'], np.float64)
+    S_J = run_svd(B['jjobs'], W, JU, JS, JV, False)
     if S_J is None:
-        stats['fb_svd'] += len(sel)
+        stats['fb_svd'] += len(B['idx'])
         return done, S_out
-    # ---- outputs.  W = U' S VH'  ->  X = VH'^H S (U'^H Bc);  Z = U'^H Bc (k x len) is the accumulated basis
-    zb_off = np.concatenate([[0], np.cumsum(kq * l)])
-    Z = dev.scratch('warm_Z', int(zb_off[-1]), dtype)
-    raw_gemm(dtype, np.stack([zb_off[:-1], kq, l, l, ju_off[:-1], one, kq, bq_off[sel], l, one, kq, z + conjA], axis=1), JU, bq_arena, Z)
+    Z = dev.scratch('warm_Z', B['nZ'], dtype)
+    run_gemm(dtype, B['gemm_Z'], JU, b_arena, Z)
     if lowdin_basis:
-        lowdin_rows(dtype, Z, zb_off[:-1], kq, l, l, one, iterations=1)
-    u_off, v_off = u_off_all[idx], v_off_all[idx]
-    if R:
+        lowdin_rows(dtype, Z, *B['lowdin_args'], iterations=1)
+    if side == 'R':
         # VH_A rows = Z ;  U_A[j][i] = conj(VH'[i][j])
-        raw_copy(dtype, copy_jobs_2d(v_off, n, one, zb_off[:-1], l, one, kq, n), Z, V_arena)
-        raw_copy(dtype, copy_jobs_2d(u_off, kk, one, jv_off[:-1], one, p, m, kq, conj=cplx), JV, U_arena)
+        run_copy(dtype, B['copy_1'], Z, V_arena)
+        run_copy(dtype, B['copy_2'], JV, U_arena)
     else:
         # A = X^T = Z^T S conj(VH'):  U_A[l][i] = Z[i][l] ;  VH_A[i][j] = conj(VH'[i][j])
-        raw_copy(dtype, copy_jobs_2d(u_off, kk, one, zb_off[:-1], one, l, m, kq), Z, U_arena)
-        raw_copy(dtype, copy_jobs_2d(v_off, n, one, jv_off[:-1], p, one, kq, n, conj=cplx), JV, V_arena)
-    for t, b in enumerate(idx):
+        run_copy(dtype, B['copy_1'], Z, U_arena)
+        run_copy(dtype, B['copy_2'], JV, V_arena)
+    js_off, kq, kk = B['js_off'], B['kq'], B['kk']
+    for t, b in enumerate(B['idx']):
         sb = np.zeros(int(kk[t]), dtype=np.float64)
         sb[:kq[t]] = S_J[js_off[t]:js_off[t + 1]]
         S_out[b] = sb
         done[b] = True
     return done, S_out
+
+
+def _warm_plan_a(dtype, cplx, side, numel, offs, ms, ns, b_off, b_k, b_len):
+    nb = len(ms)
+    R = side == 'R'
+    ps_all = ms if R else ns                  # rows of X
+    ls_all = ns if R else ms                  # length of the basis vectors
+    kk_all = np.minimum(ms, ns)
+    act = np.nonzero((b_k > 0) & (b_k <= kk_all) & (b_len == ls_all))[0]
+    pl = dict(ok=False, n_unfit=int(nb - len(act)))
+    if len(act) == 0:
+        return pl
+    if not (np.array_equal(offs, np.concatenate([[0], np.cumsum(ms * ns)[:-1]])) and int(np.sum(ms * ns)) == numel):
+        return pl                            # blocks not packed back to back (E = A - P is formed on the flat arena)
+    conjB, conjA = (2 if cplx else 0), (1 if cplx else 0)
+    o, m, n, p, l, kk = offs[act], ms[act], ns[act], ps_all[act], ls_all[act], kk_all[act]
+    z = np.zeros(len(act), dtype=np.int64)
+    one = z + 1
+    x_rs, x_cs = (n, one) if R else (one, n)      # X(j, l) = A[o + j x_rs + l x_cs]
+    kq, boff = b_k[act].copy(), b_off[act].copy()
+    w_off = np.concatenate([[0], np.cumsum(kq * p)])
+    # W = Bq X^H:  A(i, l) = Bq[i][l];  B(l, j) = conj(X[j][l])
+    gemm_W = gemm_table(dtype, np.stack([w_off[:-1], kq, p, p, boff, l, one, o, x_cs, x_rs, l, z + conjB], axis=1))
+    if R:
+        gemm_P = gemm_table(dtype, np.stack([o, m, n, n, w_off[:-1], one, p, boff, l, one, kq, z + conjA], axis=1))
+    else:
+        gemm_P = gemm_table(dtype, np.stack([o, m, n, n, boff, one, l, w_off[:-1], p, one, kq, z + conjB], axis=1))
+    pl.update(ok=True, act=act, o=o, m=m, n=n, p=p, l=l, kk=kk, kq=kq, boff=boff, w_off=w_off, nW=int(w_off[-1]),
+              gemm_W=gemm_W, gemm_P=gemm_P, norms=_row_norms_plan(o, m, n))
+    return pl
+
+
+def _warm_plan_b(dtype, cplx, side, A, keep, u_off_all, v_off_all):
+    R = side == 'R'
+    conjA = 1 if cplx else 0
+    sel = np.nonzero(keep)[0]
+    idx = A['act'][sel]
+    m, n, p, l, kk, kq, boff = (A[x][sel] for x in ('m', 'n', 'p', 'l', 'kk', 'kq', 'boff'))
+    w_off = A['w_off'][:-1][sel]
+    z = np.zeros(len(sel), dtype=np.int64)
+    one = z + 1
+    ju_off = np.concatenate([[0], np.cumsum(kq * kq)])
+    js_off = np.concatenate([[0], np.cumsum(kq)])
+    jv_off = np.concatenate([[0], np.cumsum(kq * p)])
+    jjobs = np.zeros((len(sel), 8), dtype=np.int64)
+    jjobs[:, 0], jjobs[:, 1], jjobs[:, 2] = w_off, kq, p
+    jjobs[:, 3], jjobs[:, 4], jjobs[:, 5] = ju_off[:-1], js_off[:-1], jv_off[:-1]
+    jjobs[:, 6] = 1                       # square blocks: orthogonalise the rows
+    zb_off = np.concatenate([[0], np.cumsum(kq * l)])
+    gemm_Z = gemm_table(dtype, np.stack([zb_off[:-1], kq, l, l, ju_off[:-1], one, kq, boff, l, one, kq, z + conjA], axis=1))
+    u_off, v_off = u_off_all[idx], v_off_all[idx]
+    if R:
+        copy_1 = copy_table(copy_jobs_2d(v_off, n, one, zb_off[:-1], l, one, kq, n))
+        copy_2 = copy_table(copy_jobs_2d(u_off, kk, one, jv_off[:-1], one, p, m, kq, conj=cplx))
+    else:
+        copy_1 = copy_table(copy_jobs_2d(u_off, kk, one, zb_off[:-1], one, l, m, kq))
+        copy_2 = copy_table(copy_jobs_2d(v_off, n, one, jv_off[:-1], p, one, kq, n, conj=cplx))
+    return dict(idx=idx, kq=kq, kk=kk, js_off=js_off, jjobs=np.ascontiguousarray(jjobs), nJU=int(ju_off[-1]), nJV=int(jv_off[-1]),
+                nJS=int(js_off[-1]), nZ=int(zb_off[-1]), gemm_Z=gemm_Z, lowdin_args=(zb_off[:-1].copy(), kq, l, l, one),
+                copy_1=copy_1, copy_2=copy_2)

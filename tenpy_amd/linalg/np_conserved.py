@@ -2491,17 +2491,26 @@ def _svd_warm_store(a, key, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
     ksig = _svd_sig_counts(S_host, ks, s_offs, _svd_warm.E_RANK_TOL)
     if np.any(ksig <= 0):
         return
-    one = np.ones(len(ks), dtype=np.int64)
-    # side R: k x n row-major = the first rows of VH_b
-    r_off = np.concatenate([[0], np.cumsum(ksig * ns)])
-    Rb = dev.empty(int(r_off[-1]), a.dtype)
-    _svd_warm.raw_copy(a.dtype, _svd_warm.copy_jobs_2d(r_off[:-1], ns, one, v_offs[:-1], ns, one, ksig, ns), V_arena, Rb)
-    _svd_warm.cache_put(key, 'R', _svd_warm.Basis(Rb, r_off[:-1], ksig, ns, _leg_sector_keys(a.legs[1], a._qdata[:, 1]), a.dtype))
-    # side L: k x m row-major = U_b^T (plain transpose: the rows span the row space of theta^T)
-    l_off = np.concatenate([[0], np.cumsum(ksig * ms)])
-    Lb = dev.empty(int(l_off[-1]), a.dtype)
-    _svd_warm.raw_copy(a.dtype, _svd_warm.copy_jobs_2d(l_off[:-1], ms, one, u_offs[:-1], one, ks, ksig, ms), U_arena, Lb)
-    _svd_warm.cache_put(key, 'L', _svd_warm.Basis(Lb, l_off[:-1], ksig, ms, _leg_sector_keys(a.legs[0], a._qdata[:, 0]), a.dtype))
+    ms, ns, ks = (np.ascontiguousarray(x, dtype=np.int64) for x in (ms, ns, ks))
+    pkey = _svd_warm._key('store', ksig, ms, ns, ks, np.ascontiguousarray(u_offs, dtype=np.int64), np.ascontiguousarray(v_offs, dtype=np.int64))
+    pl = _svd_warm._plan_get(pkey)
+    if pl is None:
+        one = np.ones(len(ks), dtype=np.int64)
+        r_off = np.concatenate([[0], np.cumsum(ksig * ns)])     # side R: k x n row-major = the first rows of VH_b
+        l_off = np.concatenate([[0], np.cumsum(ksig * ms)])     # side L: k x m row-major = U_b^T (the rows span the row space of theta^T)
+        pl = _svd_warm._plan_put(pkey, dict(
+            r_off=r_off[:-1].copy(), nR=int(r_off[-1]), l_off=l_off[:-1].copy(), nL=int(l_off[-1]), ksig=ksig.copy(),
+            copy_R=_svd_warm.copy_table(_svd_warm.copy_jobs_2d(r_off[:-1], ns, one, v_offs[:-1], ns, one, ksig, ns)),
+            copy_L=_svd_warm.copy_table(_svd_warm.copy_jobs_2d(l_off[:-1], ms, one, u_offs[:-1], one, ks, ksig, ms))))
+    sect = a.__dict__.get('_tpa_sector_keys')
+    if sect is None or sect[0] is not a._qdata:
+        sect = a.__dict__['_tpa_sector_keys'] = (a._qdata, _leg_sector_keys(a.legs[0], a._qdata[:, 0]), _leg_sector_keys(a.legs[1], a._qdata[:, 1]))
+    Rb = dev.empty(pl['nR'], a.dtype)
+    _svd_warm.run_copy(a.dtype, pl['copy_R'], V_arena, Rb)
+    _svd_warm.cache_put(key, 'R', _svd_warm.Basis(Rb, pl['r_off'], pl['ksig'], ns, sect[2], a.dtype))
+    Lb = dev.empty(pl['nL'], a.dtype)
+    _svd_warm.run_copy(a.dtype, pl['copy_L'], U_arena, Lb)
+    _svd_warm.cache_put(key, 'L', _svd_warm.Basis(Lb, pl['l_off'], pl['ksig'], ms, sect[1], a.dtype))
 
 
 # A warm-started call may leave some charge blocks to the cold path (no basis, stale basis, full-rank edge blocks).  They are
@@ -2522,8 +2531,10 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
     basis = _svd_warm.cache_get(key, side)
     if basis is None or basis.dtype != a.dtype:
         return None
-    leg = a.legs[1] if side == 'R' else a.legs[0]
-    want = _leg_sector_keys(leg, a._qdata[:, 1 if side == 'R' else 0])
+    sect = a.__dict__.get('_tpa_sector_keys')
+    if sect is None or sect[0] is not a._qdata:
+        sect = a.__dict__['_tpa_sector_keys'] = (a._qdata, _leg_sector_keys(a.legs[0], a._qdata[:, 0]), _leg_sector_keys(a.legs[1], a._qdata[:, 1]))
+    want = sect[2] if side == 'R' else sect[1]
     have = {k: i for i, k in enumerate(basis.sectors)}
     order = np.array([have.get(k, -1) for k in want], dtype=np.int64)
     found = order >= 0
