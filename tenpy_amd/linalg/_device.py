@@ -78,14 +78,19 @@ def scratch(name, n, dtype):
     allocator for a different size every call splits its cached blocks and ends in a fresh hipMalloc per call (measured: the
     same ``tpa_svd_batch`` took 20.7 instead of 16.4 ms when 300 MB of temporaries had been allocated and freed before it).
     The contents are only valid until the next request under the same name; all users are ordered on one stream."""
-    import torch as real_torch
     dt = np.dtype(dtype)
-    need = max(int(n), 1) * dt.itemsize
-    buf = _pool.get(name)
-    if buf is None or buf.numel() * 8 < need:
-        buf = _pool[name] = empty(((int(need * 1.5) + 7) // 8 + 32) // 2 * 2, np.float64)      # `empty`: the (test-patchable) allocator; even: complex views
-    tdt = {'float64': real_torch.float64, 'complex128': real_torch.complex128, 'uint8': real_torch.uint8}[dt.name]
-    return buf.view(tdt)[:max(int(n), 1)] if n > 0 else buf.view(tdt)[:0]
+    n = int(n)
+    need = max(n, 1) * dt.itemsize
+    ent = _pool.get(name)
+    if ent is None or ent[0].numel() * 8 < need:
+        buf = empty(((int(need * 1.5) + 7) // 8 + 32) // 2 * 2, np.float64)      # `empty`: the (test-patchable) allocator; even: complex views
+        ent = _pool[name] = (buf, {})
+    buf, views = ent
+    v = views.get(dt.char)
+    if v is None:
+        import torch as real_torch
+        v = views[dt.char] = buf.view({'float64': real_torch.float64, 'complex128': real_torch.complex128, 'uint8': real_torch.uint8}[dt.name])
+    return v[:max(n, 1)] if n > 0 else v[:0]
 
 
 PIN_RING_BYTES = 64 << 20

@@ -684,6 +684,15 @@ class LegPipe(LegCharge):
         self._fuse(sort, bunch)
         self.test_sanity()
 
+    def _content_key(self):
+        """Hashable key of everything a reshaping plan takes from this pipe (``q_map``, block structure); memoised: pipes are
+        never modified after construction (``conj`` etc. make new ones)."""
+        k = self.__dict__.get('_ckey')
+        if k is None or k[0] is not self.q_map:
+            k = self.__dict__['_ckey'] = (self.q_map, hash((self.q_map.tobytes(), self.q_map_slices.tobytes(), self.slices.tobytes(),
+                                                             int(self.qconj), tuple(self.subqshape), tuple(self.subshape))))
+        return k[1]
+
     def _fuse(self, sort, bunch):
         nlegs, qnumber = self.nlegs, self.chinfo.qnumber
         nq = self.subqshape

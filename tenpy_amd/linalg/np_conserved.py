@@ -142,6 +142,14 @@ class Array:
         self._skey = None
         return sizes
 
+    def _adopt_blocks(self, qdata, offsets, arena, qdata_sorted):
+        """Install a planned block list (``qdata`` / ``offsets`` are shared, read-only arrays of a reshaping plan)."""
+        self._qdata = qdata
+        self._offsets = offsets
+        self._arena = arena
+        self._qdata_sorted = qdata_sorted
+        self._skey = None
+
     def _block_sizes_flat(self):
         """Number of elements of every stored block.  Memoised on the identity of ``_qdata`` and of the legs (both are
         replaced, never modified in place): the Lanczos vector kernels ask for it ~60 times per bond."""
@@ -687,6 +695,17 @@ class Array:
         res = Array(legs, self.dtype, self.qtotal, new_labels)
         if self.stored_blocks == 0:
             return res
+        # the bookkeeping below (new block list, offsets, copy jobs) depends on the block structure of ``self``, the leg groups and
+        # the fusion tables of the pipes only: planned once, replayed for every Array of that structure (one per bond and sweep)
+        pkey = ('comb', self._struct_key(), tuple(tuple(int(c) for c in cl) for cl in combine_legs), tuple(new_axes),
+                tuple(p._content_key() for p in pipes))
+        plan = _reshape_plan_get(pkey)
+        if plan is not None:
+            res._adopt_blocks(plan[0], plan[1], dev.zeros(plan[2], self.dtype), True)
+            if plan[3] is not None:
+                dev.check(dev.lib().tpa_copy_batch(dev.code(self.dtype), plan[3].data_ptr(), plan[4], plan[5], self._arena.data_ptr(),
+                                                   res._arena.data_ptr(), dev.stream()), "copy_batch")
+            return res
         nold = self.stored_blocks
         # --- new qdata and the slice start inside the fused block, per old block
         qdata = np.empty((nold, res.rank), dtype=np.intp)
@@ -755,6 +774,8 @@ class Array:
         jobs[:, 1] = self._offsets
         sizes = np.prod(old_shapes, axis=1)
         _run_copy(self.dtype, jobs, int(np.max(sizes)), self._arena, res._arena)
+        if 0 < len(jobs) <= 60000 and int(np.max(sizes)) > 0:
+            _reshape_plan_put(pkey, (res._qdata, res._offsets, int(res._arena.numel()), dev.table(jobs), len(jobs), int(np.max(sizes))))
         return res
 
     def _combine_legs_via_transpose(self, combine_legs, new_axes, pipes, transp):
@@ -848,6 +869,15 @@ class Array:
         res = Array(res_legs, self.dtype, self.qtotal, res_labels)
         if self.stored_blocks == 0:
             return res
+        pkey = ('split', self._struct_key(), tuple(int(a) for a in axes), tuple(self.legs[a]._content_key() for a in sorted(axes)))
+        plan = _reshape_plan_get(pkey) if self.rank <= COPY_MAXDIM else None
+        if plan is not None:
+            res._adopt_blocks(plan[0], plan[1], dev.empty(plan[2], self.dtype), False)
+            dev.check(dev.lib().tpa_copy_batch(dev.code(self.dtype), plan[3].data_ptr(), plan[4], plan[5], self._arena.data_ptr(),
+                                               res._arena.data_ptr(), dev.stream()), "copy_batch")
+            if cutoff > 0.:
+                res.ipurge_zeros(cutoff)
+            return res
         nold = self.stored_blocks
         split_axes = [a for a in range(self.rank) if a in axes]
         nsplit = len(split_axes)
@@ -914,6 +944,8 @@ class Array:
         jobs[:, 1] = src_off
         sizes = np.prod(new_shapes, axis=1)
         _run_copy(self.dtype, jobs, int(np.max(sizes)) if nnew else 0, self._arena, res._arena)
+        if 0 < nnew <= 60000 and int(np.max(sizes)) > 0:
+            _reshape_plan_put(pkey, (res._qdata, res._offsets, int(res._arena.numel()), dev.table(jobs), nnew, int(np.max(sizes))))
         if cutoff > 0.:
             res.ipurge_zeros(cutoff)
         return res
@@ -1001,6 +1033,17 @@ class Array:
         if axes == tuple(range(self.rank)):
             return self
         axes_arr = np.array(axes, dtype=np.intp)
+        pkey = ('transp', self._struct_key(), axes) if self.stored_blocks and self.rank <= COPY_MAXDIM else None
+        plan = _reshape_plan_get(pkey) if pkey is not None else None
+        if plan is not None:        # (see combine_legs: the bookkeeping is planned once per block structure)
+            self.legs = [self.legs[a] for a in axes]
+            self._set_shape()
+            self._labels = [self._labels[a] for a in axes]
+            new_arena = dev.empty(plan[2], self.dtype)
+            dev.check(dev.lib().tpa_copy_batch(dev.code(self.dtype), plan[3].data_ptr(), plan[4], plan[5], self._arena.data_ptr(),
+                                               new_arena.data_ptr(), dev.stream()), "copy_batch")
+            self._adopt_blocks(plan[0], plan[1], new_arena, False)
+            return self
         old_shapes = self._block_shapes()
         old_strides = _c_strides(old_shapes)
         self.legs = [self.legs[a] for a in axes]
@@ -1046,6 +1089,8 @@ class Array:
         _run_copy(self.dtype, jobs, int(np.max(sizes)), self._arena, new_arena)
         self._arena = new_arena
         self._offsets = new_offs
+        if pkey is not None and 0 < len(jobs) <= 60000 and int(np.max(sizes)) > 0:
+            _reshape_plan_put(pkey, (self._qdata, self._offsets, int(np.sum(sizes)), dev.table(jobs), len(jobs), int(np.max(sizes))))
         return self
 
     def transpose(self, axes=None):
@@ -1352,6 +1397,14 @@ class Array:
         res._skey = None
         if self.stored_blocks == 0:
             return res
+        pkey = ('proj', self._struct_key(), int(axis), hash(np.ascontiguousarray(mask).tobytes()))
+        plan = _reshape_plan_get(pkey)
+        if plan is not None:
+            res._adopt_blocks(plan[0], plan[1], dev.empty(plan[2], self.dtype), self._qdata_sorted)
+            if plan[3] is not None:
+                dev.check(dev.lib().tpa_gather_axis_batch(dev.code(self.dtype), plan[3].data_ptr(), plan[5], plan[6], plan[4].data_ptr(),
+                                                          self._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "gather")
+            return res
         keep = map_qind[self._qdata[:, axis]] >= 0
         old_q = self._qdata[keep]
         old_off = self._offsets[keep]
@@ -1361,6 +1414,7 @@ class Array:
         old_leg = self.legs[axis]
         res._set_blocks(new_q, qdata_sorted=self._qdata_sorted)
         if len(new_q) == 0:
+            _reshape_plan_put(pkey, (res._qdata, res._offsets, 0, None, None, 0, 0))
             return res
         new_shapes = res._block_shapes()
         # per old qindex of this leg: list of kept local indices, packed into one index array
@@ -1384,6 +1438,7 @@ class Array:
         dev.check(dev.lib().tpa_gather_axis_batch(dev.code(self.dtype), jd.data_ptr(), len(jobs),
                                                   int(np.max(np.prod(new_shapes, axis=1))), idd.data_ptr(),
                                                   self._arena.data_ptr(), res._arena.data_ptr(), dev.stream()), "gather")
+        _reshape_plan_put(pkey, (res._qdata, res._offsets, int(res._arena.numel()), jd, idd, len(jobs), int(np.max(np.prod(new_shapes, axis=1)))))
         return res
 
     def take_slice(self, indices, axes):
@@ -1565,6 +1620,44 @@ class Array:
 # ======================================================================================================
 # helpers on copy jobs
 # ======================================================================================================
+
+_reshape_plans = OrderedDict()
+_RESHAPE_PLANS_MAX = 16384
+
+
+def clear_device_caches():
+    """Forget every cached device table / plan / scratch buffer (tests that switch between the emulated and the real device)."""
+    _plan_cache.clear()
+    _reshape_plans.clear()
+    dev._pool.clear()
+    if dev._table_cache is not None:
+        dev._table_cache.clear()
+    _svd_warm._tables.clear()
+    _svd_warm._plans.clear()
+    _svd_warm.cache_clear()
+    try:
+        from ..algorithms import mps_common as _mc
+        _mc._heff_plans.clear()
+        _mc.MpoApplyPlan._cache.clear()
+    except ImportError:      # (the linalg package is importable on its own)
+        pass
+
+
+def _reshape_plan_get(key):
+    pl = _reshape_plans.get(key)
+    if pl is not None:
+        _reshape_plans.move_to_end(key)
+    return pl
+
+
+def _reshape_plan_put(key, plan):
+    for arr in plan[:2]:        # block list and offsets are handed to every Array that replays the plan: nobody may write into them
+        if isinstance(arr, np.ndarray):
+            arr.setflags(write=False)
+    _reshape_plans[key] = plan
+    if len(_reshape_plans) > _RESHAPE_PLANS_MAX:
+        _reshape_plans.popitem(last=False)
+
 
 def _c_strides(shapes):
     """C-order strides for each row of a (n, rank) array of shapes."""

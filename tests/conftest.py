@@ -32,7 +32,7 @@ def backend(request, monkeypatch):
     """'mock': host logic on the numpy emulation of the C-ABI device calls (CPU container);
     'gpu': the real HIP kernels on an MI355X."""
     from tenpy_amd.linalg import np_conserved as npc
-    npc._plan_cache.clear()
+    npc.clear_device_caches()
     if request.param == "mock":
         import mock_device
         mock_device.install(monkeypatch)
@@ -40,4 +40,4 @@ def backend(request, monkeypatch):
         from tenpy_amd import _lib
         _lib.require_gpu()
     yield request.param
-    npc._plan_cache.clear()
+    npc.clear_device_caches()

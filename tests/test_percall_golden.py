@@ -55,9 +55,9 @@ def test_percall_hubbard_chi1024_structure():
     """The same charge sectors 4 times as wide (block structure of the chi = 1024 ladder, fused theta 4096 x 4096)."""
     from tenpy_amd import _lib
     _lib.require_gpu()
-    npc._plan_cache.clear()
+    npc.clear_device_caches()
     _percall(golden('percall_hubbard.pkl')[1])
-    npc._plan_cache.clear()
+    npc.clear_device_caches()
 
 
 def test_percall_tebd_complex_chi64(backend):
@@ -70,9 +70,9 @@ def test_percall_tebd_complex_chi1024_structure():
     """Bond sectors 16 times as wide: two ~800 x 800 complex blocks per theta (the block-SVD-bound case of config 5)."""
     from tenpy_amd import _lib
     _lib.require_gpu()
-    npc._plan_cache.clear()
+    npc.clear_device_caches()
     _percall_tebd(golden('percall_tebd.pkl')[1])
-    npc._plan_cache.clear()
+    npc.clear_device_caches()
 
 
 def _percall_tebd(rec):
@@ -105,9 +105,9 @@ def test_percall_vs_reference_full_size():
     from tenpy_amd import _lib
     from tenpy_amd.linalg import np_conserved as npc
     _lib.require_gpu()
-    npc._plan_cache.clear()
+    npc.clear_device_caches()
     _percall(golden('percall2048.pkl')[0])
-    npc._plan_cache.clear()
+    npc.clear_device_caches()
 
 
 def _percall(rec):
