@@ -2584,10 +2584,6 @@ def _svd_warm_store(a, key, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
     ksig = _svd_sig_counts(S_host, ks, s_offs, _svd_warm.E_RANK_TOL)
     if np.any(ksig <= 0):
         return
-    # The numerical rank at 1e-15 moves by a few vectors from visit to visit, and every table of the warm start depends on it: rounded
-    # DOWN to a multiple of 16 the same tables recur (cache hits instead of ~2 rebuilt + uploaded GEMM tables per bond).  The dropped
-    # vectors have sigma within a factor ~1.3 of E_RANK_TOL |A| (their weight, < 16 (2e-15)^2, goes into the residual E, far below E_TOL).
-    ksig = np.where(ksig >= 32, ksig // 16 * 16, ksig)
     ms, ns, ks = (np.ascontiguousarray(x, dtype=np.int64) for x in (ms, ns, ks))
     pkey = _svd_warm._key('store', ksig, ms, ns, ks, np.ascontiguousarray(u_offs, dtype=np.int64), np.ascontiguousarray(v_offs, dtype=np.int64))
     pl = _svd_warm._plan_get(pkey)
