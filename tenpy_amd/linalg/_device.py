@@ -136,6 +136,8 @@ def to_device(arr):
 
 _table_cache = None
 TABLE_CACHE_MAX_ENTRIES = 32768
+TABLE_CACHE_TOTAL_BYTES = 1 << 30     # of device memory for all cached tables together
+_table_bytes = 0
 TABLE_CACHE_MAX_BYTES = 1 << 18       # per table; larger ones are uploaded every time (hashing them would cost more than the copy)
 
 
@@ -151,12 +153,15 @@ def table(arr):
     if _table_cache is None:
         from collections import OrderedDict
         _table_cache = OrderedDict()
+    global _table_bytes
     key = (arr.dtype.str, arr.shape, arr.tobytes())
     t = _table_cache.get(key)
     if t is None:
         t = _table_cache[key] = to_device(arr)
-        if len(_table_cache) > TABLE_CACHE_MAX_ENTRIES:
-            _table_cache.popitem(last=False)
+        _table_bytes += arr.nbytes
+        while len(_table_cache) > TABLE_CACHE_MAX_ENTRIES or _table_bytes > TABLE_CACHE_TOTAL_BYTES:
+            _, old = _table_cache.popitem(last=False)
+            _table_bytes -= old.numel() * old.element_size()
     else:
         _table_cache.move_to_end(key)
     return t

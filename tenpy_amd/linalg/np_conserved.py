@@ -1632,6 +1632,7 @@ def clear_device_caches():
     dev._pool.clear()
     if dev._table_cache is not None:
         dev._table_cache.clear()
+        dev._table_bytes = 0
     _svd_warm._tables.clear()
     _svd_warm._plans.clear()
     _svd_warm.cache_clear()
