@@ -104,7 +104,10 @@ def _fused_heff(env_t, W, left):
             tuple((l.charges.tobytes(), int(l.qconj)) for l in env_t.legs))
     plan = _heff_plans.get(pkey)
     if plan is not None and plan['ent'] is ent:
-        _heff_plans.move_to_end(pkey)
+        try:
+            _heff_plans.move_to_end(pkey)
+        except KeyError:      # evicted by another thread in between (the reference's `+ h.c.` worker contracts concurrently)
+            pass
         res = npc.Array(plan['legs'], env_t.dtype, plan['qtotal'], plan['labels'])
         res._adopt_blocks(plan['qdata'], plan['offsets'], dev.zeros(plan['total'], env_t.dtype), True)
         dev.check(dev.lib().tpa_lincomb_batch(dev.code(env_t.dtype), plan['jobs'].data_ptr(), plan['n_jobs'], plan['terms'].data_ptr(),

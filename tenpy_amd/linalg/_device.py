@@ -163,7 +163,10 @@ def table(arr):
             _, old = _table_cache.popitem(last=False)
             _table_bytes -= old.numel() * old.element_size()
     else:
-        _table_cache.move_to_end(key)
+        try:
+            _table_cache.move_to_end(key)
+        except KeyError:      # evicted by another thread in between (the reference's `+ h.c.` worker contracts concurrently)
+            pass
     return t
 
 

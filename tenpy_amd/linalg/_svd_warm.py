@@ -47,7 +47,10 @@ _PLANS_MAX = 16384
 def _plan_get(key):
     pl = _plans.get(key)
     if pl is not None:
-        _plans.move_to_end(key)
+        try:
+            _plans.move_to_end(key)
+        except KeyError:      # evicted by another thread in between (the reference's `+ h.c.` worker contracts concurrently)
+            pass
     return pl
 
 
@@ -94,7 +97,10 @@ def gemm_table(dtype, spec):
         if len(_tables) > _TABLES_MAX:
             _tables.popitem(last=False)
     else:
-        _tables.move_to_end(key)
+        try:
+            _tables.move_to_end(key)
+        except KeyError:      # evicted by another thread in between (the reference's `+ h.c.` worker contracts concurrently)
+            pass
     return tab
 
 

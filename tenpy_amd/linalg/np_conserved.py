@@ -1647,7 +1647,10 @@ def clear_device_caches():
 def _reshape_plan_get(key):
     pl = _reshape_plans.get(key)
     if pl is not None:
-        _reshape_plans.move_to_end(key)
+        try:
+            _reshape_plans.move_to_end(key)
+        except KeyError:      # evicted by another thread in between (the reference's `+ h.c.` worker contracts concurrently)
+            pass
     return pl
 
 
@@ -2118,7 +2121,10 @@ def plan_tensordot(a, b, axes=2):
     key = (a_use._struct_key(), b_use._struct_key(), tuple(ca), tuple(cb), a.dtype.str, b.dtype.str)
     plan = _plan_cache.get(key)
     if plan is not None:
-        _plan_cache.move_to_end(key)
+        try:
+            _plan_cache.move_to_end(key)
+        except KeyError:      # evicted by another thread in between (the reference's `+ h.c.` worker contracts concurrently)
+            pass
         return plan, a_use, b_use
     plan = _build_plan(a_use, b_use, ca, cb, fa, fb)
     _plan_cache[key] = plan
