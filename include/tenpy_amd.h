@@ -180,7 +180,8 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
  * Gram + in-LDS eigen-solve); bit 0 = one wavefront per row pair; bit 1 = two-kernel Jacobi rounds instead of the fused one; bit 2 = full local
  * sweep in every round; bits 4-7 = local sweeps; bit 9 (512) = no pivoted-QR preconditioner; bit 10 (1024) = NO predicted
  * convergence; bit 11 (2048) = no one-workgroup-per-pair round (real data, blocks with rank + columns <= 2048; the fused round with
- * column parts is used instead).  Predicted convergence (default since round 2, validated on the MI355X on chi = 2048 blocks: same singular values
+ * column parts is used instead); bit 12 (4096) = no 32-row-block rounds (real data; the 8-row-block kernels run instead); bit 13 (8192) = no
+ * look-ahead round (the host drains the stream after every sweep before it enqueues the next one).  Predicted convergence (default since round 2, validated on the MI355X on chi = 2048 blocks: same singular values
  * to 1.4e-15 sigma_max, same orthogonality, one to two sweeps fewer): a sweep in which no rotated pair had a scaled cosine
  * above 1e-7 ends the iteration without the verification sweep (quadratic convergence leaves cosines <= 1e-14). */
 int tpa_svd_set_algorithm(int pairwise);

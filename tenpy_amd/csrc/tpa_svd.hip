@@ -2534,6 +2534,7 @@ int tpa_svd_cross_only = 1;  // rounds r > 0 of a sweep rotate only cross-block 
                         // 32 x 32 solve dominates); kept as a tuning option, off by default
 int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair kernel also for real data
 int tpa_svd_rank_cap = 0;        // > 0: the pivoted QR gives up (TPA_E_RANKCAP) once a block needs more than this many columns
+int tpa_svd_lookahead = 1;       // 32-row-block path: first round of the next sweep enqueued before the host reads the counters of this one (bit 13 switches it off)
 int tpa_svd_b32 = 1;             // real data: 32-row blocks, three launches per round (tpa_svd_b32.inc); bit 12 of tpa_svd_set_algorithm switches it off
 
 struct Layout {
@@ -2759,8 +2760,11 @@ inline PinStage &pin_stage() {
         }                                                                                            \
     } while (0)
 
-__global__ void post_words_kernel(const unsigned int *__restrict__ a, int na, const int *__restrict__ b, unsigned int *__restrict__ host) {
-    for (int i = 0; i < na; ++i) host[i] = a[i];
+__global__ void post_words_kernel(unsigned int *__restrict__ a, int na, const int *__restrict__ b, unsigned int *__restrict__ host, int zero_after) {
+    for (int i = 0; i < na; ++i) {
+        host[i] = a[i];
+        if (zero_after) a[i] = 0u;      // the counters start the next sweep at zero without a separate memset
+    }
     if (b != nullptr) host[na] = (unsigned int)b[0];
     __threadfence_system();
 }
@@ -2835,14 +2839,39 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     if (use_fused || use_fused_c) TPA_HIP_CHECK(hipMemsetAsync(pcnt, 0, lay.bentries.size() * 4 + 4, st));
     const int rounds = use_b32 ? (int)std::max<int64_t>(lay.nb32_max_pad - 1, 1)
                                : use_block ? (int)std::max<int64_t>(lay.nb_max_pad - 1, 1) : (int)std::max<int64_t>(lay.rmax_pad - 1, 1);
+    // 32-row-block path: ONE ROUND OF LOOK-AHEAD.  The host has to see the rotation counters of sweep t before it knows whether
+    // sweep t + 1 is needed, and the device used to idle for that round trip (~25 us, 6 - 8 times per call: 6 % of a chi = 512
+    // call).  Now round 0 of sweep t + 1 is enqueued BEHIND the posting kernel of sweep t and before the host waits (on an event
+    // recorded right after the post, not on the stream); if sweep t turns out to have converged, that one round was superfluous
+    // but harmless -- it applies the same kind of sub-threshold rotations a further sweep would.
+    auto b32_round = [&](int r) {
+        const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
+        svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, b32g);
+        svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local);
+        svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, G, b32q, b32f);
+    };
+    if (use_b32 && tpa_svd_lookahead && !converged) {
+        static thread_local hipEvent_t ev_post = nullptr;
+        if (ev_post == nullptr) TPA_HIP_CHECK(hipEventCreateWithFlags(&ev_post, hipEventDisableTiming));
+        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
+        b32_round(0);
+        while (!converged && sweep < max_sweeps) {
+            for (int r = 1; r < rounds; ++r) b32_round(r);
+            post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, nullptr, posted, 1);
+            TPA_HIP_CHECK(hipEventRecord(ev_post, st));
+            if (sweep + 1 < max_sweeps) b32_round(0);          // look-ahead: first round of the next sweep
+            TPA_LAUNCH_CHECK();
+            TPA_HIP_CHECK(hipEventSynchronize(ev_post));
+            ++sweep;
+            converged = (posted[0] == 0) || (tpa_svd_predict_convergence && posted[1] == 0);
+        }
+    }
     while (!converged && sweep < max_sweeps) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
             const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
             if (use_b32) {
-                svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, b32g);
-                svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local);
-                svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, G, b32q, b32f);
+                b32_round(r);
             } else if (use_fused_c) {
                 ++fused_seq;
                 svd_round_fused_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)W, (double2 *)G, gpart, pcnt, fused_seq, cnt,
@@ -2867,7 +2896,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         int herr = 0;
         {
             const bool with_err = !use_b32 && ((use_fused && !use_wide) || use_fused_c);
-            post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, with_err ? perr : nullptr, posted);
+            post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, with_err ? perr : nullptr, posted, 0);
             TPA_HIP_CHECK(hipStreamSynchronize(st));
             h2[0] = posted[0];
             h2[1] = posted[1];
@@ -3536,6 +3565,7 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_fused_round = (pairwise & 2) ? 0 : 1;  // bit 1: two-kernel rounds (gram, then solve + apply)
     tpa_svd_wide_round = (pairwise & 2048) ? 0 : 1;   // bit 11: no one-workgroup-per-pair round (-> fused round with column parts)
     tpa_svd_b32 = ((pairwise & 4096) || (pairwise & 2)) ? 0 : 1;   // bit 12 (or the two-kernel 8-row rounds of bit 1): no 32-row-block rounds
+    tpa_svd_lookahead = (pairwise & 8192) ? 0 : 1;     // bit 13: no look-ahead round (the host drains the stream after every sweep)
     tpa_svd_predict_convergence = (pairwise & 1024) ? 0 : 1;   // bit 10: always run the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     return 0;
