@@ -183,8 +183,21 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
  * column parts is used instead); bit 12 (4096) = no 32-row-block rounds (real data; the 8-row-block kernels run instead); bit 13 (8192) = no
  * look-ahead round (the host drains the stream after every sweep before it enqueues the next one).  Predicted convergence (default since round 2, validated on the MI355X on chi = 2048 blocks: same singular values
  * to 1.4e-15 sigma_max, same orthogonality, one to two sweeps fewer): a sweep in which no rotated pair had a scaled cosine
- * above 1e-7 ends the iteration without the verification sweep (quadratic convergence leaves cosines <= 1e-14). */
+ * above 1e-7 ends the iteration without the verification sweep (quadratic convergence leaves cosines <= 1e-14).
+ * Round 4 -- Gram-only sweeps (csrc/tpa_svd_b32.inc; real data, calls whose largest block has >= 96 rows; default): a sweep starts
+ * from ONE exact Gram matrix W W^T per block (grouped GEMM), its rounds rotate that matrix alone (solve per pair + 64^3 MFMA
+ * updates of the Gram tiles and of the accumulated transform) and end with one product [W | G] <- Qtot [W | G]; bit 20
+ * (1048576) = off (gram / solve / apply on the data in every round, the round-3 path).
+ * Round 4 -- end game by simultaneous rotations (csrc/tpa_svd_refine.inc; OFF by default, bit 21 (2097152) = on, bit 15 (32768) =
+ * also for complex data): after `pre` cyclic sweeps (bits 16-19 = `pre` + 1; 0: default 3; 1 = none: warm-started calls) every
+ * further sweep is replaced by a step that takes ALL pair rotations from one exact Gram matrix, makes the transform unitary by
+ * Newton-Schulz (GEMMs) and applies it to [W | G] (GEMM); same pairwise stopping rule, evaluated on the exact Gram matrix for
+ * all pairs; cyclic sweeps take over again whenever a step does not shrink the rotations. */
 int tpa_svd_set_algorithm(int pairwise);
+/* Counters of the refinement path since the last reset (host, all calls of the process): out8 = {calls that entered the
+ * refinement, refinement steps, Newton-Schulz steps, cyclic sweeps before the first step, extra cyclic sweeps after a stalled
+ * step, calls that never used it, their cyclic sweeps, failed calls (-> TPA_E_NOCONV, the caller's fallback chain)}. */
+int tpa_svd_refine_stats(int64_t *out8, int reset);
 /* Rank cap of the pivoted-QR stage (0 = none, default): with cap > 0 tpa_svd_batch returns TPA_E_RANKCAP as soon as some
  * block turns out to have numerical rank above ~cap (checked every 64 columns).  Used by the warm-started SVD for the residual
  * blocks E = A - P, which are decomposed only if they are of low rank (tenpy_amd/linalg/_svd_warm.py). */

@@ -29,7 +29,9 @@ def _newer(src_list, target):
 def build(force=False, verbose=False):
     """Compile every source for gfx950 and link ``libtenpy_amd.so``.  Returns the library path."""
     os.makedirs(OUT_DIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "tpa_common.h"), os.path.join(CSRC, "tpa_svd_b32.inc"), os.path.join(HERE, "..", "include", "tenpy_amd.h")]
+    # every header / include file under csrc/ (a changed .inc must rebuild its .hip: round 4 lost a GPU run to a stale object)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
+    headers.append(os.path.join(HERE, "..", "include", "tenpy_amd.h"))
     objs = []
     jobs = []
     for s in SOURCES:

@@ -835,6 +835,7 @@ __global__ __launch_bounds__(NTW) void svd_round_wide_kernel(const SvdJob *__res
 }
 
 #include "tpa_svd_b32.inc"
+#include "tpa_svd_refine.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // Complex (Hermitian) version of the split block-Jacobi round.  Same structure; chunks are 32 complex columns
@@ -2536,6 +2537,16 @@ int tpa_svd_force_pairwise = 0;  // test hook: 1 = use the wavefront-per-pair ke
 int tpa_svd_rank_cap = 0;        // > 0: the pivoted QR gives up (TPA_E_RANKCAP) once a block needs more than this many columns
 int tpa_svd_lookahead = 1;       // 32-row-block path: first round of the next sweep enqueued before the host reads the counters of this one (bit 13 switches it off)
 int tpa_svd_b32 = 1;             // real data: 32-row blocks, three launches per round (tpa_svd_b32.inc); bit 12 of tpa_svd_set_algorithm switches it off
+int tpa_svd_gonly = 1;           // real data, 32-row blocks: Gram-only sweeps (one exact Gram matrix per sweep, rounds on it alone, one product
+                                 // [W | G] <- Qtot [W | G] at the end; tpa_svd_b32.inc); bit 20 of tpa_svd_set_algorithm switches it off
+int tpa_svd_refine = 0;          // end game by simultaneous rotations + Newton-Schulz on the MFMA (tpa_svd_refine.inc): bit 0 real data, bit 1 complex data;
+                                 // OFF by default (measured: 12.7 vs 13.9 ms on the saturated chi = 2048 theta, but 3.86 vs 3.61 s per sweep --
+                                 // the small blocks of the other bonds lose); bit 21 of tpa_svd_set_algorithm switches it on, bit 15 also for complex data
+int tpa_svd_refine_pre = 3;      // Jacobi sweeps before the first refinement step (bits 16..19 of tpa_svd_set_algorithm: value + 1)
+constexpr double REF_KINF_ENTER = 6.0;    // largest row sum of |K| with which a refinement step is attempted
+constexpr int64_t REF_MIN_R = 96;   // calls whose largest block has fewer rows keep the plain Jacobi rounds (1 - 2 rounds per sweep there)
+int64_t tpa_svd_refine_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calls with refinement, refinement steps, Newton-Schulz steps, Jacobi sweeps of those calls,
+                                                                 // extra Jacobi sweeps after a stagnating step, calls without refinement, their sweeps, failures
 
 struct Layout {
     std::vector<SvdJob> jobs;
@@ -2547,6 +2558,12 @@ struct Layout {
     std::vector<B32Pair> b32_pairs;
     int64_t nb32_max_pad = 0;
     int64_t off_b32e = 0, off_b32p = 0, off_b32g = 0, off_b32q = 0, off_b32f = 0, off_tab_end = 0;
+    std::vector<B32GUp> b32_gup;   // tiles of the Gram-only rounds
+    std::vector<int> b32_first_pair;
+    int64_t off_gup = 0;
+    RefTables ref;                 // GEMM tables of the refinement / the Gram-only sweeps (empty unless the largest block has >= REF_MIN_R rows)
+    int64_t off_rtasks = 0, off_rlinks = 0, off_rtiles = 0, off_rrt = 0;                // ... inside the uploaded table range
+    int64_t off_w2 = 0, off_rp = 0, off_rq = 0, off_rm = 0, off_rowpart = 0;           // second [W | G] image, split-K partials, Q, M, |K| row sums
     bool wide_ok = true;           // every job has <= FIT * NTW / 64 column chunks of [W | G]
     int64_t nb_max_pad = 0;
     int64_t max_part_chunks = 0;   // largest number of (W + G) column chunks of one part (fused round: <= 4 * FIT)
@@ -2619,6 +2636,7 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
                 const int64_t NB32 = (J.R + BB - 1) / BB, NB32p = (NB32 + 1) / 2 * 2;
                 const int64_t nW32 = (J.L + CB - 1) / CB, nG32 = (J.R + CB - 1) / CB;
                 const int np32 = (int)std::min<int64_t>(B32_MAX_PARTS, std::max<int64_t>(1, (nW32 + nG32 + 3) / 4));
+                lay.b32_first_pair.push_back((int)lay.b32_pairs.size());
                 for (int64_t p = 0; p < NB32p / 2; ++p) {
                     const int pairidx = (int)lay.b32_pairs.size();
                     lay.b32_pairs.push_back(B32Pair{b, (int)p, (int)lay.b32_entries.size(), np32});
@@ -2664,6 +2682,30 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + (int64_t)lay.b32_entries.size() * sizeof(B32Entry), 256);
     lay.off_b32p = o;
     o = align_up(o + (int64_t)lay.b32_pairs.size() * sizeof(B32Pair), 256);
+    if (lay.rmax_pad >= REF_MIN_R) {     // (independent of the algorithm switches: tpa_svd_worksize must not depend on them)
+        ref_make_tables(lay.ref, lay.jobs, dtype, (lay.g_elems + 1) / 2 * 2, (lay.off_g - lay.off_w) / esz);
+        lay.off_rtasks = o;
+        o = align_up(o + (int64_t)lay.ref.tasks.size() * 8, 256);
+        lay.off_rlinks = o;
+        o = align_up(o + (int64_t)lay.ref.links.size() * 8, 256);
+        lay.off_rtiles = o;
+        o = align_up(o + (int64_t)lay.ref.tiles.size() * 4, 256);
+        lay.off_rrt = o;
+        o = align_up(o + (int64_t)lay.ref.rtiles.size() * sizeof(RefTile), 256);
+        if (dtype != TPA_C128) {
+            for (int b = 0; b < (int)lay.jobs.size(); ++b) {
+                const SvdJob &J = lay.jobs[b];
+                const int NB32 = (int)((J.R + BB - 1) / BB), np = (NB32 + 1) / 2, first = lay.b32_first_pair[b];
+                const int nct = (int)((J.R + TB - 1) / TB);
+                for (int pa = 0; pa < np; ++pa) {
+                    for (int pb = 0; pb < np; ++pb) lay.b32_gup.push_back(B32GUp{2 * b, pa, pb, first + pa, first + pb, (int)J.R, J.g_off});
+                    for (int c = 0; c < nct; ++c) lay.b32_gup.push_back(B32GUp{2 * b + 1, pa, c, first + pa, first + pa, (int)J.R, J.g_off});
+                }
+            }
+            lay.off_gup = o;
+            o = align_up(o + (int64_t)lay.b32_gup.size() * sizeof(B32GUp), 256);
+        }
+    }
     lay.off_tab_end = o;
     lay.off_pcnt = o;
     o = align_up(o + (int64_t)lay.bentries.size() * 4 + 64, 256);   // per-entry pair counters + error flag
@@ -2682,6 +2724,18 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         o = align_up(o + (int64_t)lay.b32_entries.size() * GSZ * 8, 256);
         lay.off_b32q = o;
         o = align_up(o + (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
+    }
+    if (lay.ref.enabled) {
+        lay.off_w2 = o;                                   // [W2 | G2] with the spacing of [W | G]
+        o = align_up(o + (lay.off_g - lay.off_w) + lay.g_elems * esz, 256);
+        lay.off_rp = o;
+        o = align_up(o + (int64_t)REF_MAX_SPLIT * ((lay.g_elems + 1) / 2 * 2) * esz, 256);
+        lay.off_rq = o;
+        o = align_up(o + lay.g_elems * esz, 256);
+        lay.off_rm = o;
+        o = align_up(o + lay.g_elems * esz, 256);
+        lay.off_rowpart = o;
+        o = align_up(o + lay.sig_elems * lay.ref.nts * 8, 256);
     }
     lay.total = o;
     return lay;
@@ -2726,23 +2780,31 @@ int64_t fused_round_capacity_c() {
 struct PinStage {
     char *base = nullptr;
     size_t cap = 0, used = 0;
-    void reset() { used = 0; }
+    std::vector<char *> retired;      // outgrown arenas: pointers handed out earlier in the same call stay valid until reset()
+    void reset() {
+        used = 0;
+        if (!retired.empty()) {
+            (void)hipDeviceSynchronize();     // rare (the arena grew during the previous call); a call that failed half-way may have left copies queued
+            for (char *p : retired) (void)hipHostFree(p);
+            retired.clear();
+        }
+    }
     char *take(size_t bytes, hipStream_t st) {
+        (void)st;
         const size_t need = (used + 255) / 256 * 256;
         if (base == nullptr || need + bytes > cap) {
-            if (base != nullptr) {
-                if (hipStreamSynchronize(st) != hipSuccess) return nullptr;   // copies out of the old arena may still be queued
-                (void)hipHostFree(base);
-                base = nullptr;
-            }
+            // never free an arena inside a call -- tables staged earlier may still be queued for upload, and the host
+            // sort of the singular values reads a block taken before the one that triggered the growth
+            if (base != nullptr) retired.push_back(base);
+            base = nullptr;
             cap = std::max<size_t>(2 * (need + bytes), (size_t)4 << 20);
             if (hipHostMalloc((void **)&base, cap, hipHostMallocDefault) != hipSuccess) {
                 base = nullptr;
                 cap = 0;
                 return nullptr;
             }
-            used = 0;
-            return take(bytes, st);
+            used = bytes;
+            return base;
         }
         used = need + bytes;
         return base + need;
@@ -2799,6 +2861,13 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         stage_put(stg, t0, lay.off_wpairs, lay.wpairs);
         stage_put(stg, t0, lay.off_b32e, lay.b32_entries);
         stage_put(stg, t0, lay.off_b32p, lay.b32_pairs);
+        if (lay.ref.enabled) {
+            stage_put(stg, t0, lay.off_rtasks, lay.ref.tasks);
+            stage_put(stg, t0, lay.off_rlinks, lay.ref.links);
+            stage_put(stg, t0, lay.off_rtiles, lay.ref.tiles);
+            stage_put(stg, t0, lay.off_rrt, lay.ref.rtiles);
+            stage_put(stg, t0, lay.off_gup, lay.b32_gup);
+        }
         TPA_HIP_CHECK(hipMemcpyAsync(work + t0, stg, (size_t)tbytes, hipMemcpyHostToDevice, st));
     }
     const int g_rows = (int)(lay.rows.size() / (NT / 64));
@@ -2847,26 +2916,128 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     auto b32_round = [&](int r) {
         const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
         svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, b32g);
-        svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local);
+        svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
         svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, G, b32q, b32f);
     };
-    if (use_b32 && tpa_svd_lookahead && !converged) {
-        static thread_local hipEvent_t ev_post = nullptr;
-        if (ev_post == nullptr) TPA_HIP_CHECK(hipEventCreateWithFlags(&ev_post, hipEventDisableTiming));
+    // work areas and GEMM tables shared by the Gram-only sweeps and the refinement steps
+    constexpr int ES = CPLX ? 2 : 1;
+    const RefTables &rt = lay.ref;
+    const int64_t *rtasks = (const int64_t *)(work + lay.off_rtasks), *rlinks = (const int64_t *)(work + lay.off_rlinks);
+    const int32_t *rtiles = (const int32_t *)(work + lay.off_rtiles);
+    const RefTile *rrt = (const RefTile *)(work + lay.off_rrt);
+    double *W2 = (double *)(work + lay.off_w2), *G2 = (double *)(work + lay.off_w2 + (lay.off_g - lay.off_w));
+    double *P = (double *)(work + lay.off_rp), *Qm = (double *)(work + lay.off_rq), *Mm = (double *)(work + lay.off_rm);
+    const int64_t pstride = (lay.g_elems + 1) / 2 * 2 * ES, n_q = lay.g_elems * ES;
+    const int n_rt = (int)rt.rtiles.size();
+    auto gemm = [&](const RefTables::Span &sp, const void *A, const void *B, void *C) {
+        return tpa_gemm_chain(CPLX ? TPA_C128 : TPA_F64, 1, rtasks, rlinks, rtiles + 4 * sp.tile0, sp.n_tiles, A, B, C, st);
+    };
+    // End game by simultaneous rotations (tpa_svd_refine.inc): the Jacobi loops below stop after `jac_limit` sweeps and hand over.
+    const bool use_refine = use_block && lay.ref.enabled && (tpa_svd_refine & (CPLX ? 2 : 1)) && !converged;
+    int jac_limit = use_refine ? std::min(max_sweeps, std::max(tpa_svd_refine_pre, 0)) : max_sweeps;
+    double *Wc = W, *Gc = G;            // current [W | G] image (the refinement steps ping-pong between two)
+    static thread_local hipEvent_t ev_post = nullptr;
+    if (ev_post == nullptr) TPA_HIP_CHECK(hipEventCreateWithFlags(&ev_post, hipEventDisableTiming));
+    auto b32_round_on = [&](int r, double *Wx, double *Gx) {
+        const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
+        svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, Wx, b32g);
+        svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
+        svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, Wx, Gx, b32q, b32f);
+    };
+    // one Jacobi sweep on the image (Wx, Gx) with whatever round kernel this call uses; counters -> posted[0..1]
+    auto jacobi_sweep_on = [&](double *Wx, double *Gx) -> int {
+        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
+        for (int r = 0; r < rounds; ++r) {
+            const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
+            if (use_b32) {
+                b32_round_on(r, Wx, Gx);
+            } else if (use_fused_c) {
+                ++fused_seq;
+                svd_round_fused_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)Wx, (double2 *)Gx, gpart, pcnt, fused_seq, cnt,
+                                                                                  fro2, rho, tpa_svd_local_sweeps, full_local, perr);
+            } else if (use_block && CPLX) {
+                svd_gram_part_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (const double2 *)Wx, gpart);
+                svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)Wx, (double2 *)Gx, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
+            } else if (use_wide) {
+                svd_round_wide_kernel<<<(int)lay.wpairs.size(), NTW, 0, st>>>(jobs, wpairs, r, Wx, Gx, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
+            } else if (use_fused) {
+                ++fused_seq;
+                svd_round_fused_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, Wx, Gx, gpart, pcnt, fused_seq, cnt, fro2, rho,
+                                                                                tpa_svd_local_sweeps, full_local, perr);
+            } else {
+                svd_gram_part_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, Wx, gpart);
+                svd_solve_apply_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, Wx, Gx, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
+            }
+        }
+        TPA_LAUNCH_CHECK();
+        const bool with_err = !use_b32 && ((use_fused && !use_wide) || use_fused_c);
+        post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, with_err ? perr : nullptr, posted, 1);
+        TPA_HIP_CHECK(hipStreamSynchronize(st));
+        if (with_err && posted[2]) {
+            snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: sibling workgroups of a fused Jacobi round lost each other (spin limit)");
+            return TPA_E_NOCONV;
+        }
+        return 0;
+    };
+    // ---- Gram-only sweeps (tpa_svd_b32.inc): needs the predicted-convergence rule (the stopping decision must not rest on an
+    //      updated Gram matrix alone) and the GEMM tables of the refinement layout
+    const bool use_gonly = use_b32 && !CPLX && tpa_svd_gonly && tpa_svd_predict_convergence && lay.ref.enabled && !lay.b32_gup.empty();
+    if (use_gonly && !converged && jac_limit > 0) {
+        const B32GUp *gup = (const B32GUp *)(work + lay.off_gup);
+        double *Wn = W2, *Gn = G2;
+        int rc_g = 0;
+        auto g_begin = [&]() {        // S = W W^T (both triangles) -> Mm,  Qtot = 1 -> Qm
+            if (int rc = gemm(rt.gram, Wc, Wc, P)) rc_g = rc;
+            ref_nsm_kernel<false><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Mm, 0.0, -1.0, 1.0, nullptr, Qm);
+        };
+        auto g_round = [&](int r) {
+            const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
+            svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, Mm, r);
+            svd_b32_gupdate_kernel<<<(int)lay.b32_gup.size(), NTB, 0, st>>>(gup, r, Mm, Qm, b32q, b32f);
+        };
+        auto g_end = [&]() {          // [W | G] <- Qtot [W | G] into the other image
+            if (int rc = gemm(rt.apply, Qm, Wc, Wn)) rc_g = rc;
+            std::swap(Wc, Wn);
+            std::swap(Gc, Gn);
+        };
+        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
+        g_begin();
+        g_round(0);
+        while (!converged && sweep < jac_limit) {
+            for (int r = 1; r < rounds; ++r) g_round(r);
+            g_end();
+            post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, nullptr, posted, 1);
+            TPA_HIP_CHECK(hipEventRecord(ev_post, st));
+            if (tpa_svd_lookahead && sweep + 1 < jac_limit) {      // look-ahead: Gram matrix and first round of the next sweep (they touch S,
+                g_begin();                                         // Qtot and the pair transforms only: harmless if this sweep was the last)
+                g_round(0);
+            }
+            if (rc_g) return rc_g;
+            TPA_LAUNCH_CHECK();
+            TPA_HIP_CHECK(hipEventSynchronize(ev_post));
+            ++sweep;
+            converged = (posted[0] == 0) || posted[1] == 0;
+            if (!tpa_svd_lookahead && !converged && sweep < jac_limit) {
+                g_begin();
+                g_round(0);
+            }
+        }
+    } else
+    if (use_b32 && tpa_svd_lookahead && !converged && jac_limit > 0) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
         b32_round(0);
-        while (!converged && sweep < max_sweeps) {
+        while (!converged && sweep < jac_limit) {
             for (int r = 1; r < rounds; ++r) b32_round(r);
             post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, nullptr, posted, 1);
             TPA_HIP_CHECK(hipEventRecord(ev_post, st));
-            if (sweep + 1 < max_sweeps) b32_round(0);          // look-ahead: first round of the next sweep
+            if (sweep + 1 < jac_limit) b32_round(0);          // look-ahead: first round of the next sweep
             TPA_LAUNCH_CHECK();
             TPA_HIP_CHECK(hipEventSynchronize(ev_post));
             ++sweep;
             converged = (posted[0] == 0) || (tpa_svd_predict_convergence && posted[1] == 0);
         }
     }
-    while (!converged && sweep < max_sweeps) {
+    while (!converged && sweep < jac_limit) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
         for (int r = 0; r < rounds; ++r) {
             const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
@@ -2909,6 +3080,112 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         ++sweep;
         converged = (h2[0] == 0) || (tpa_svd_predict_convergence && h2[1] == 0);
     }
+    if (use_refine && !converged && sweep < max_sweeps) {
+        // ---- refinement steps: Gram (GEMM) -> K, counters, |K| bound -> host -> Newton-Schulz (GEMMs) -> [W | G] <- Q [W | G] (GEMM)
+        double *rowpart = (double *)(work + lay.off_rowpart);
+        unsigned int *rposted = (unsigned int *)pin_stage().take(64, st);
+        TPA_STAGE_CHECK(rposted);
+        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned int), st));
+        double *Wn = (Wc == W) ? W2 : W, *Gn = (Gc == G) ? G2 : G;
+        int it = 0, ns_total = 0, extra_sweeps = 0, stalled = 0, backoff = 1;
+        double kinf_prev = 0.0;
+        const int jac_sweeps = sweep;
+        bool failed = false;
+        for (; it < REF_MAX_IT && sweep < max_sweeps; ++it) {
+            if (int rc = gemm(rt.gram, Wc, Wc, P)) return rc;
+            ref_build_kernel<CPLX><<<n_rt, 256, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Qm, rowpart, rt.nts, fro2, rho, cnt);
+            ref_post_kernel<<<1, 256, 0, st>>>(jobs, rows, (int)lay.rows.size(), rowpart, rt.nts, cnt, rposted);
+            TPA_HIP_CHECK(hipEventRecord(ev_post, st));
+            TPA_LAUNCH_CHECK();
+            TPA_HIP_CHECK(hipEventSynchronize(ev_post));
+            const unsigned int n_need = rposted[0], n_big = rposted[1];
+            double kinf, e_last, cmax2;
+            {
+                const unsigned long long kb = (unsigned long long)rposted[2] | ((unsigned long long)rposted[3] << 32);
+                const unsigned long long eb = (unsigned long long)rposted[4] | ((unsigned long long)rposted[5] << 32);
+                const unsigned long long cb = (unsigned long long)rposted[6] | ((unsigned long long)rposted[7] << 32);
+                memcpy(&kinf, &kb, 8);
+                memcpy(&e_last, &eb, 8);
+                memcpy(&cmax2, &cb, 8);
+            }
+            // NaN, or the last Newton-Schulz step of the previous iteration started far from unitary (the plan is a rigorous bound:
+            // this is a sanity check, not a convergence test)
+            if (!(kinf == kinf) || !(e_last < 1.0e-6) || !(cmax2 == cmax2)) {
+                failed = true;
+                break;
+            }
+            if (n_need == 0) {
+                converged = true;
+                break;
+            }
+            // Simultaneous rotations only converge from near-orthogonal rows.  Measured on the rank-569 block of the chi = 2048 theta:
+            // row sums of |K| of 2.7 / 5.1 / 8.1 after 3 / 2 / 1 cyclic sweeps (then 5 / 7 / 8 steps with 26 / 39 / 60 Newton-Schulz
+            // steps: a sweep costs about as much as the 18 steps it saves), 12 straight after the pivoted QR -- and from there they
+            // GROW to 200.  So: above REF_KINF_ENTER, or when three steps in a row fail to shrink |K|, cyclic sweeps on the current
+            // image take over again -- 1, then 2, 4, ... before the next attempt.
+            if (it > 0 && kinf > 0.5 && kinf > 0.85 * kinf_prev) ++stalled;
+            else stalled = 0;
+            kinf_prev = kinf;
+            if (stalled >= 3 || kinf > REF_KINF_ENTER) {
+                bool jac_done = false;
+                for (int e = 0; e < backoff && sweep < max_sweeps && !jac_done; ++e) {
+                    if (int rc = jacobi_sweep_on(Wc, Gc)) return rc;
+                    ++sweep;
+                    ++extra_sweeps;
+                    jac_done = (posted[0] == 0) || (tpa_svd_predict_convergence && posted[1] == 0);
+                }
+                backoff = std::min(2 * backoff, 8);
+                stalled = 0;
+                kinf_prev = 0.0;
+                if (jac_done) {
+                    converged = true;
+                    break;
+                }
+                TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned int), st));
+                continue;
+            }
+            double scale;
+            const int ns = ref_ns_plan(kinf, scale);
+            for (int k = 0; k < ns; ++k) {
+                if (int rc = gemm(rt.nst, Qm, Qm, P)) return rc;
+                const double s_ = (k == 0) ? scale : 1.0;
+                ref_nsm_kernel<CPLX><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_r, pstride, Mm, 1.5 * s_, 0.5 * s_ * s_ * s_, s_ * s_,
+                                                           (k == ns - 1) ? (unsigned long long *)(cnt + 2) : nullptr, nullptr);
+                if (int rc = gemm(rt.nsq, Mm, Qm, P)) return rc;
+                ref_qsum_kernel<<<(int)((n_q / 2 + 256) / 256), 256, 0, st>>>(P, rt.nsplit_r, pstride, Qm, n_q);
+            }
+            ns_total += ns;
+            if (int rc = gemm(rt.apply, Qm, Wc, Wn)) return rc;
+            std::swap(Wc, Wn);
+            std::swap(Gc, Gn);
+            ++sweep;
+            // Simultaneous rotations leave cosines of ~ (largest cosine before) x (largest rotation) -- near-degenerate pairs keep
+            // |K| ~ 1e-2 while the cosines are already ~1e-8 -- so the step is final only if that product is far below the tolerance
+            // of the pairwise rule; otherwise the next Gram matrix decides.
+            if (tpa_svd_predict_convergence && n_big == 0 && std::sqrt(cmax2) * (kinf + std::sqrt(cmax2)) < 2.0e-17) {
+                ++it;
+                converged = true;
+                break;
+            }
+        }
+        TPA_LAUNCH_CHECK();
+        tpa_svd_refine_counters[0] += 1;
+        tpa_svd_refine_counters[1] += it;
+        tpa_svd_refine_counters[2] += ns_total;
+        tpa_svd_refine_counters[3] += jac_sweeps;
+        tpa_svd_refine_counters[4] += extra_sweeps;
+        if (failed) {
+            tpa_svd_refine_counters[7] += 1;
+            TPA_HIP_CHECK(hipStreamSynchronize(st));
+            snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: refinement step failed (NaN or non-unitary transform)");
+            return TPA_E_NOCONV;
+        }
+    } else if (!use_refine) {
+        tpa_svd_refine_counters[5] += 1;
+        tpa_svd_refine_counters[6] += sweep;
+    }
+    W = Wc;
+    G = Gc;
     if (sweeps_done) *sweeps_done = sweep;
     svd_norms_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, W, sig);
     TPA_LAUNCH_CHECK();
@@ -3568,5 +3845,16 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_lookahead = (pairwise & 8192) ? 0 : 1;     // bit 13: no look-ahead round (the host drains the stream after every sweep)
     tpa_svd_predict_convergence = (pairwise & 1024) ? 0 : 1;   // bit 10: always run the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
+    tpa_svd_refine = (pairwise & 2097152) ? (1 | ((pairwise & 32768) ? 2 : 0)) : 0;   // bit 21: refinement steps (off by default); bit 15: also for complex data
+    tpa_svd_gonly = (pairwise & 1048576) ? 0 : 1;     // bit 20: no Gram-only sweeps (the round-3 rounds: gram, solve, apply on the data)
+    tpa_svd_refine_pre = ((pairwise >> 16) & 15) ? (int)((pairwise >> 16) & 15) - 1 : 3;   // bits 16..19: Jacobi sweeps before the first step, + 1
+    return 0;
+}
+
+extern "C" int tpa_svd_refine_stats(int64_t *out8, int reset) {
+    for (int i = 0; i < 8; ++i) {
+        out8[i] = tpa_svd_refine_counters[i];
+        if (reset) tpa_svd_refine_counters[i] = 0;
+    }
     return 0;
 }

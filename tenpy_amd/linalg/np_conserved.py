@@ -2484,13 +2484,27 @@ def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, swee
 # NaN re-try of np_conserved.py:4970-4982: every entry is a `tpa_svd_set_algorithm` code that is tried when the previous
 # one returned TPA_E_NOCONV or produced NaNs: default (pivoted-QR preconditioner + fused block Jacobi), block Jacobi
 # without the preconditioner and with two-kernel rounds, then the plain one-wavefront-per-row-pair Jacobi.
-SVD_ALGORITHM_CHAIN = (0, 512 | 2, 1 | 512)
+# Round 4: the default (code 0) runs Gram-only sweeps on 32-row blocks (csrc/tpa_svd_b32.inc).  SVD_REFINE (TPA_SVD_REFINE=1, off by
+# default: slower over a whole sweep) adds the end game by simultaneous rotations (bit 21, csrc/tpa_svd_refine.inc).
+SVD_REFINE_ON = 2097152
+SVD_REFINE = os.environ.get('TPA_SVD_REFINE', '0') != '0'
+SVD_ALG0 = int(os.environ.get('TPA_SVD_ALG0', '0'))             # measurement knob: extra bits for the head of the chain (e.g. 1048576 = no Gram-only sweeps)
+SVD_ALGORITHM_CHAIN = ((SVD_REFINE_ON if SVD_REFINE else 0) | SVD_ALG0, 512 | 2, 1 | 512)
+# warm-started calls (`_svd_warm`): no pivoted QR (bit 9); with the refinement the steps begin at once (bits 16-19 = cyclic sweeps
+# before the first step + 1)
+SVD_ALGORITHM_CHAIN_WARM = ((512 | (1 << 16) | SVD_REFINE_ON | SVD_ALG0,) if SVD_REFINE else ()) + (512 | SVD_ALG0, 512 | 2, 1 | 512)
 SVD_MAX_SWEEPS = 80
 svd_robust_stats = {'retries': 0, 'last_chain': ()}
+_svd_alg_initialised = False
 
 
 def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, sweeps, chain=None):
     """One batched device SVD with the fallback chain; returns the singular values on the host."""
+    global _svd_alg_initialised
+    if not _svd_alg_initialised:          # the library starts in state 0; a knob may have changed the head of the chain
+        _svd_alg_initialised = True
+        if SVD_ALGORITHM_CHAIN[0] != 0:
+            L.tpa_svd_set_algorithm(SVD_ALGORITHM_CHAIN[0])
     chain = SVD_ALGORITHM_CHAIN if chain is None else chain
     wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
     work = dev.scratch('svd_work', int(wb), np.uint8)
@@ -2657,7 +2671,7 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
         sw = dev.c_int()
         j = np.ascontiguousarray(j)
         try:
-            S_h = _svd_batch_robust(L, code, j, len(j), arena, U, S, VH, sw, chain=None if qrp else (512, 512 | 2, 1 | 512))
+            S_h = _svd_batch_robust(L, code, j, len(j), arena, U, S, VH, sw, chain=None if qrp else SVD_ALGORITHM_CHAIN_WARM)
         except (np.linalg.LinAlgError, ValueError):
             return None
         total_sweeps[0] += sw.value
