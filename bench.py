@@ -316,6 +316,7 @@ def main():
         eng.phase_time = {k: 0. for k in eng.phase_time}
     # ---- timed region: exactly K steps
     for tm in (npc.gemm_timer, npc.svd_timer):
+        tm.keep = bool(os.environ.get('TPA_BENCH_SVD_RECORDS')) and tm is npc.svd_timer
         tm.reset()
         tm.enabled = True
     n0 = 0 if is_tebd else len(eng.update_stats['E_total'])
@@ -341,6 +342,13 @@ def main():
     for tm in (npc.gemm_timer, npc.svd_timer):
         tm.enabled = False
         tm.collect()
+    if os.environ.get('TPA_BENCH_SVD_RECORDS'):       # diagnostic: HIP-event time, kind, sweeps and largest block of every timed SVD call
+        with open(os.environ['TPA_BENCH_SVD_RECORDS'], 'w') as f:
+            json.dump([[t] + list(tag or ()) for t, tag in npc.svd_timer.records], f)
+        _log = (_ct.c_int64 * (8 * 8192))()
+        _n = dev_lib().tpa_svd_call_log(_log, 8192, 0)
+        with open(os.environ['TPA_BENCH_SVD_RECORDS'] + '.calls', 'w') as f:       # the library's own log of its last tpa_svd_batch calls
+            json.dump([list(_log[8 * i:8 * i + 8]) for i in range(_n)], f)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

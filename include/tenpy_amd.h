@@ -198,6 +198,9 @@ int tpa_svd_set_algorithm(int pairwise);
  * refinement, refinement steps, Newton-Schulz steps, cyclic sweeps before the first step, extra cyclic sweeps after a stalled
  * step, calls that never used it, their cyclic sweeps, failed calls (-> TPA_E_NOCONV, the caller's fallback chain)}. */
 int tpa_svd_refine_stats(int64_t *out8, int reset);
+/* Diagnostic ring of the most recent tpa_svd_batch calls (host): rows of out = {min(m, n) of the largest block, its max(m, n),
+ * blocks, sweeps, pivoted QR used, algorithm switches, wall microseconds inside the call, return code}; returns the rows written. */
+int64_t tpa_svd_call_log(int64_t *out, int64_t max_rows, int reset);
 /* Rank cap of the pivoted-QR stage (0 = none, default): with cap > 0 tpa_svd_batch returns TPA_E_RANKCAP as soon as some
  * block turns out to have numerical rank above ~cap (checked every 64 columns).  Used by the warm-started SVD for the residual
  * blocks E = A - P, which are decomposed only if they are of low rank (tenpy_amd/linalg/_svd_warm.py). */

@@ -16,6 +16,7 @@
 #include "tpa_common.h"
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -3647,10 +3648,60 @@ extern "C" int64_t tpa_svd_worksize(int dtype, const int64_t *jobs_host, int n_j
     return total;
 }
 
+// diagnostic ring of the last calls of tpa_svd_batch: {rows of the largest block (min(m, n)), its columns, blocks, sweeps,
+// pivoted QR used, algorithm switches (b32 | gonly << 1 | refine << 2), wall microseconds of the call, return code}
+constexpr int CALL_LOG_N = 8192;
+static int64_t tpa_svd_call_log_buf[CALL_LOG_N][8];
+static int64_t tpa_svd_call_log_count = 0;
+static int tpa_svd_batch_impl(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base,
+                              void *u_base, double *s_dev, void *vh_base, void *work_dev,
+                              int64_t work_bytes, int max_sweeps, double tol, int *sweeps_done,
+                              void *stream, int *used_qrp);
+
+extern "C" int64_t tpa_svd_call_log(int64_t *out, int64_t max_rows, int reset) {
+    const int64_t n = std::min<int64_t>(std::min<int64_t>(tpa_svd_call_log_count, CALL_LOG_N), max_rows);
+    const int64_t first = tpa_svd_call_log_count - n;
+    for (int64_t i = 0; i < n; ++i) memcpy(out + 8 * i, tpa_svd_call_log_buf[(first + i) % CALL_LOG_N], 64);
+    if (reset) tpa_svd_call_log_count = 0;
+    return n;
+}
+
 extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base,
                              void *u_base, double *s_dev, void *vh_base, void *work_dev,
                              int64_t work_bytes, int max_sweeps, double tol, int *sweeps_done,
                              void *stream) {
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int used_qrp = 0, sw = 0;
+    const int rc = tpa_svd_batch_impl(dtype, jobs_host, n_jobs, a_base, u_base, s_dev, vh_base, work_dev, work_bytes, max_sweeps, tol,
+                                      &sw, stream, &used_qrp);
+    if (sweeps_done) *sweeps_done = sw;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    int64_t rmax = 0, lmax = 0;
+    for (int b = 0; b < n_jobs; ++b) {
+        const int64_t r = std::min(jobs_host[8 * b + 1], jobs_host[8 * b + 2]);
+        if (r > rmax) {
+            rmax = r;
+            lmax = std::max(jobs_host[8 * b + 1], jobs_host[8 * b + 2]);
+        }
+    }
+    int64_t *e = tpa_svd_call_log_buf[tpa_svd_call_log_count % CALL_LOG_N];
+    e[0] = rmax;
+    e[1] = lmax;
+    e[2] = n_jobs;
+    e[3] = sw;
+    e[4] = used_qrp;
+    e[5] = tpa_svd_b32 | (tpa_svd_gonly << 1) | (tpa_svd_refine << 2);
+    e[6] = (int64_t)(t1.tv_sec - t0.tv_sec) * 1000000 + (t1.tv_nsec - t0.tv_nsec) / 1000;
+    e[7] = rc;
+    ++tpa_svd_call_log_count;
+    return rc;
+}
+
+static int tpa_svd_batch_impl(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base,
+                              void *u_base, double *s_dev, void *vh_base, void *work_dev,
+                              int64_t work_bytes, int max_sweeps, double tol, int *sweeps_done,
+                              void *stream, int *used_qrp) {
     TPA_ARG_CHECK(tol >= 0.0 && tol <= 1.0);
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
@@ -3666,6 +3717,7 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
         dim_max <= ((dtype == TPA_F64) ? (int64_t)NTP_MAX * RPT_MAX : (int64_t)2048)) {
         QrpLayout q = make_qrp_layout(dtype, jobs_host, n_jobs);
         TPA_ARG_CHECK(work_bytes >= q.total);
+        *used_qrp = 1;
         if (dtype == TPA_F64)
             return svd_run_qrp<false>(lay, q, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);
         return svd_run_qrp<true>(lay, q, n_jobs, a_base, u_base, s_dev, vh_base, (char *)work_dev, max_sweeps, sweeps_done, st, tol);

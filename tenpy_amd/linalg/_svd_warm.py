@@ -283,9 +283,21 @@ def _row_norms_sq(dtype, arena, off, rows, cols):
 
 
 DEBUG = bool(os.environ.get('TPA_SVD_WARM_DEBUG'))      # print the residuals |E_b| / |A_b| of every attempt
+PROFILE = bool(os.environ.get('TPA_SVD_PROFILE'))       # diagnostic: synchronise after the stages of a warm attempt and time them
+_t_last = [0.]
 
 
-def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, side, run_svd, out, lowdin_basis=True):
+def _tick(name):
+    import time
+    dev.torch().cuda.synchronize()
+    now = time.time()
+    if name is not None:
+        stats[name] = stats.get(name, 0.) + (now - _t_last[0])
+    _t_last[0] = now
+
+
+
+def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, side, run_svd, out, lowdin_basis=True, need_all=False):
     """Warm-started SVD of the blocks ``A_b`` (``ms[b] x ns[b]`` row-major at ``offs[b]``, packed back to back) with row
     bases ``Bq_b`` (``b_k[b] x b_len[b]`` row-major at ``b_off[b]`` in ``b_arena``; ``b_k[b] = 0``: no basis for block b).
 
@@ -305,6 +317,8 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
     dtype = np.dtype(dtype)
     cplx = dtype.kind == 'c'
     nb = len(ms)
+    if PROFILE:
+        _tick(None)
     offs, ms, ns, b_off, b_k, b_len = (np.ascontiguousarray(x, dtype=np.int64) for x in (offs, ms, ns, b_off, b_k, b_len))
     done = np.zeros(nb, dtype=bool)
     S_out = [None] * nb
@@ -340,7 +354,13 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
         print('warm level -1 e_rel', np.array2string(e_rel, precision=1), 'kq', A['kq'], 'kk', A['kk'], flush=True)
     keep = e_rel <= E_TOL
     stats['fb_stale'] += int(np.sum(~keep))
-    if not np.any(keep):
+    if PROFILE:
+        _tick('t_warm_stage_a')
+    # ``need_all``: the caller takes the cold path for the WHOLE call as soon as one block is stale (np_conserved.
+    # SVD_WARM_MAX_COLD_FRACTION = 0) -- then decomposing the blocks that did pass is wasted work.  Round 4, per-call records of a
+    # chi = 2048 sweep: a "stale" attempt cost 9.3 ms on the large bonds (the Jacobi chain of the passing blocks), not the 0.8 ms
+    # of the two GEMMs + norms.
+    if not np.any(keep) or (need_all and not (np.all(keep) and len(A['act']) == nb)):
         return done, S_out
     # ---- stage B (planned per set of blocks that are still warm): Jacobi on the rows of W (k x p, k <= p) without any QR, then
     #      W = U' S VH'  ->  X = VH'^H S (U'^H Bq);  Z = U'^H Bq (k x len) is the accumulated basis
@@ -352,6 +372,8 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
     JV = dev.scratch('warm_JV', B['nJV'], dtype)
     JS = dev.scratch('warm_JS', B['nJS'], np.float64)
     S_J = run_svd(B['jjobs'], W, JU, JS, JV, False)
+    if PROFILE:
+        _tick('t_warm_jacobi')
     if S_J is None:
         stats['fb_svd'] += len(B['idx'])
         return done, S_out
@@ -367,6 +389,8 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
         # A = X^T = Z^T S conj(VH'):  U_A[l][i] = Z[i][l] ;  VH_A[i][j] = conj(VH'[i][j])
         run_copy(dtype, B['copy_1'], Z, U_arena)
         run_copy(dtype, B['copy_2'], JV, V_arena)
+    if PROFILE:
+        _tick('t_warm_stage_b')
     js_off, kq, kk = B['js_off'], B['kq'], B['kk']
     for t, b in enumerate(B['idx']):
         sb = np.zeros(int(kk[t]), dtype=np.float64)

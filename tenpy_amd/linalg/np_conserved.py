@@ -1955,6 +1955,8 @@ class KernelTimer:
 
     def reset(self):
         self.pending = []
+        self.records = []          # (ms, tag) per timed call when `keep` is set (diagnostic: bench.py TPA_BENCH_SVD_RECORDS)
+        self.keep = getattr(self, 'keep', False)
         self.n_launch = 0
         self.flops = 0
         self.bytes_min = 0
@@ -1967,12 +1969,12 @@ class KernelTimer:
         ev.record()
         return ev
 
-    def end(self, ev0, plan):
+    def end(self, ev0, plan, tag=None):
         if ev0 is None:
             return
         ev1 = dev.torch().cuda.Event(enable_timing=True)
         ev1.record()
-        self.pending.append((ev0, ev1))
+        self.pending.append((ev0, ev1, tag))
         self.n_launch += 1
         self.flops += plan.flops
         self.bytes_min += plan.bytes_min
@@ -1983,7 +1985,10 @@ class KernelTimer:
         """Resolve pending event pairs (synchronises)."""
         if self.pending:
             self.pending[-1][1].synchronize()
-            self.ms += sum(a.elapsed_time(b) for a, b in self.pending)
+            ts = [a.elapsed_time(b) for a, b, _ in self.pending]
+            self.ms += sum(ts)
+            if self.keep:
+                self.records.extend((t, p[2]) for t, p in zip(ts, self.pending))
             self.pending = []
         return self.ms
 
@@ -2682,14 +2687,14 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
     ev = svd_timer.begin()
     done, S_blocks = _svd_warm.svd_blocks_warm(a.dtype, a._arena, offs, ms, ns, basis.arena, b_off, b_k, b_len, side, run_svd,
                                                (U_arena, V_arena, u_offs[:-1], v_offs[:-1]),
-                                               lowdin_basis=(age % 8 == 0))
+                                               lowdin_basis=(age % 8 == 0), need_all=(SVD_WARM_MAX_COLD_FRACTION <= 0.))
     cold = np.nonzero(~done)[0]
     if len(cold) and np.sum(weight[cold]) > SVD_WARM_MAX_COLD_FRACTION * np.sum(weight):
         _svd_warm.stats['fallbacks'] += 1
         # try again after a few visits: the residual of a converging state shrinks by roughly a decade per sweep
         e = _svd_warm.stats.get('e_rel_last', 1.)
         _svd_warm.cooldown[key] = int(min(3, max(0, np.ceil(np.log10(max(e, 1e-300) / _svd_warm.E_TOL) / 2.5) - 1)))
-        svd_timer.end(ev, _Work(0., 0.) if ev is not None else None)
+        svd_timer.end(ev, _Work(0., 0.) if ev is not None else None, ('stale', 0, int(np.max(ks))))
         return None
     S_host = np.zeros(int(s_offs[-1]), dtype=np.float64)
     for b in np.nonzero(done)[0]:
@@ -2707,7 +2712,8 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
         for t, b in enumerate(cold):
             S_host[s_offs[b]:s_offs[b + 1]] = S_ch[cs_off[t]:cs_off[t + 1]]
     S_dev = dev.to_device(S_host)
-    svd_timer.end(ev, svd_work(ms, ns, a.dtype.itemsize, a.dtype.kind == 'c') if ev is not None else None)
+    svd_timer.end(ev, svd_work(ms, ns, a.dtype.itemsize, a.dtype.kind == 'c') if ev is not None else None,
+                  ('warm', total_sweeps[0], int(np.max(ks))))
     sweeps.value = total_sweeps[0]
     _svd_warm.ages[key] = age
     _svd_warm.stats['warm_calls'] += 1
@@ -2804,7 +2810,8 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
         else:
             ev = svd_timer.begin()
             S_host = _svd_batch_robust(L, code, jobs, nblk, a._arena, U_arena, S_dev, V_arena, sweeps)
-            svd_timer.end(ev, svd_work(ms, ns, a.dtype.itemsize, a.dtype.kind == 'c') if ev is not None else None)
+            svd_timer.end(ev, svd_work(ms, ns, a.dtype.itemsize, a.dtype.kind == 'c') if ev is not None else None,
+                          ('cold', sweeps.value, int(np.max(ks))))
         _svd_warm.stats['cold_calls'] += 1
         _svd_warm.stats['cold_sweeps'] += sweeps.value
         if hint is not None:
