@@ -81,8 +81,11 @@ REF = 2097152          # bit 21: refinement steps on;  bit 20 (1048576): Gram-on
 if os.environ.get('ONLY_ALG'):       # one variant only (for a rocprofv3 kernel trace)
     run(blocks, int(os.environ['ONLY_ALG']), "alg %s" % os.environ['ONLY_ALG'], refS)
     sys.exit(0)
+run(blocks, 1048576 | 4194304, "cold: round-3 rounds (data), round-3 solve", refS)
+run(blocks, 4194304, "cold: Gram-only sweeps, round-3 solve", refS)
 run(blocks, 1048576, "cold: round-3 rounds (data)", refS)
-run(blocks, 0, "cold: Gram-only sweeps", refS)
+run(blocks, 8388608, "cold: Gram-only, 2 launches per round", refS)
+run(blocks, 0, "cold: Gram-only, fused rounds", refS)
 run(blocks, 8192, "cold: Gram-only, no look-ahead", refS)
 for pre in (3, 2):
     run(blocks, REF | ((pre + 1) << 16), "cold: Gram-only %d sweeps + refinement" % pre, refS)
@@ -97,4 +100,5 @@ for b in blocks:
 refW = [np.linalg.svd(b, compute_uv=False) for b in warm]
 print("warm-shaped blocks:", [b.shape for b in warm])
 run(warm, 512 | 1048576, "warm-shaped: round-3 rounds", refW)
-run(warm, 512, "warm-shaped: Gram-only sweeps", refW)
+run(warm, 512 | 8388608, "warm-shaped: Gram-only, 2 launches", refW)
+run(warm, 512, "warm-shaped: Gram-only, fused rounds", refW)

@@ -2549,6 +2549,16 @@ constexpr int64_t REF_MIN_R = 96;   // calls whose largest block has fewer rows 
 int64_t tpa_svd_refine_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calls with refinement, refinement steps, Newton-Schulz steps, Jacobi sweeps of those calls,
                                                                  // extra Jacobi sweeps after a stagnating step, calls without refinement, their sweeps, failures
 
+int tpa_svd_fused_rounds = 1;    // Gram-only sweeps: one launch per round (svd_b32_round_kernel); bit 23 of tpa_svd_set_algorithm: solve and update as two launches
+int tpa_svd_solve2 = 1;          // 32-row blocks: second generation of the in-LDS solve (Q in registers; bit 22 of tpa_svd_set_algorithm: the round-3 kernel)
+inline void b32_solve_launch(int n_pairs, hipStream_t st, const SvdJob *jobs, const B32Pair *b32p, const double *b32g, double *b32q, int *b32f,
+                             unsigned int *cnt, const double *fro2, double rho, int full_local, const double *sfull, int r) {
+    if (tpa_svd_solve2)
+        svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, sfull, r);
+    else
+        svd_b32_solve_kernel<<<n_pairs, NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, sfull, r);
+}
+
 struct Layout {
     std::vector<SvdJob> jobs;
     std::vector<int2> rows;   // (job,row) per wavefront, padded to multiple of 4 with (-1,-1)
@@ -2560,6 +2570,7 @@ struct Layout {
     int64_t nb32_max_pad = 0;
     int64_t off_b32e = 0, off_b32p = 0, off_b32g = 0, off_b32q = 0, off_b32f = 0, off_tab_end = 0;
     std::vector<B32GUp> b32_gup;   // tiles of the Gram-only rounds
+    int n_gup_s = 0;
     std::vector<int> b32_first_pair;
     int64_t off_gup = 0;
     RefTables ref;                 // GEMM tables of the refinement / the Gram-only sweeps (empty unless the largest block has >= REF_MIN_R rows)
@@ -2698,10 +2709,16 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
                 const SvdJob &J = lay.jobs[b];
                 const int NB32 = (int)((J.R + BB - 1) / BB), np = (NB32 + 1) / 2, first = lay.b32_first_pair[b];
                 const int nct = (int)((J.R + TB - 1) / TB);
-                for (int pa = 0; pa < np; ++pa) {
+                for (int pa = 0; pa < np; ++pa)
                     for (int pb = 0; pb < np; ++pb) lay.b32_gup.push_back(B32GUp{2 * b, pa, pb, first + pa, first + pb, (int)J.R, J.g_off});
+            }
+            lay.n_gup_s = (int)lay.b32_gup.size();       // S tiles first, then the Qtot tiles (the last launch of a sweep needs only those)
+            for (int b = 0; b < (int)lay.jobs.size(); ++b) {
+                const SvdJob &J = lay.jobs[b];
+                const int NB32 = (int)((J.R + BB - 1) / BB), np = (NB32 + 1) / 2, first = lay.b32_first_pair[b];
+                const int nct = (int)((J.R + TB - 1) / TB);
+                for (int pa = 0; pa < np; ++pa)
                     for (int c = 0; c < nct; ++c) lay.b32_gup.push_back(B32GUp{2 * b + 1, pa, c, first + pa, first + pa, (int)J.R, J.g_off});
-                }
             }
             lay.off_gup = o;
             o = align_up(o + (int64_t)lay.b32_gup.size() * sizeof(B32GUp), 256);
@@ -2719,12 +2736,12 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     lay.off_fpart = o;
     o = align_up(o + (int64_t)lay.jobs.size() * 64 * 8, 256);
     lay.off_b32f = o;
-    o = align_up(o + (int64_t)lay.b32_pairs.size() * 4, 256);
+    o = align_up(o + 2 * (int64_t)lay.b32_pairs.size() * 4, 256);      // (two images: the fused rounds read round k - 1 while they write round k)
     if (dtype != TPA_C128) {
         lay.off_b32g = o;
         o = align_up(o + (int64_t)lay.b32_entries.size() * GSZ * 8, 256);
         lay.off_b32q = o;
-        o = align_up(o + (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
+        o = align_up(o + 2 * (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
     }
     if (lay.ref.enabled) {
         lay.off_w2 = o;                                   // [W2 | G2] with the spacing of [W | G]
@@ -2917,7 +2934,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     auto b32_round = [&](int r) {
         const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
         svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, b32g);
-        svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
+        b32_solve_launch((int)lay.b32_pairs.size(), st, jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
         svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, G, b32q, b32f);
     };
     // work areas and GEMM tables shared by the Gram-only sweeps and the refinement steps
@@ -2942,7 +2959,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     auto b32_round_on = [&](int r, double *Wx, double *Gx) {
         const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
         svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, Wx, b32g);
-        svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
+        b32_solve_launch((int)lay.b32_pairs.size(), st, jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
         svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, Wx, Gx, b32q, b32f);
     };
     // one Jacobi sweep on the image (Wx, Gx) with whatever round kernel this call uses; counters -> posted[0..1]
@@ -2991,10 +3008,27 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             if (int rc = gemm(rt.gram, Wc, Wc, P)) rc_g = rc;
             ref_nsm_kernel<false><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Mm, 0.0, -1.0, 1.0, nullptr, Qm);
         };
+        const bool fused = tpa_svd_fused_rounds && tpa_svd_solve2;
+        const int n_pairs = (int)lay.b32_pairs.size(), n_gup = (int)lay.b32_gup.size();
+        double *sbuf[2] = {Mm, P};                                       // S_k lives in image k % 2 (P: the split-K partials are dead by then)
+        double *qb2[2] = {b32q, b32q + (int64_t)n_pairs * TB * TB};
+        int *fb2[2] = {b32f, b32f + n_pairs};
         auto g_round = [&](int r) {
             const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
-            svd_b32_solve_kernel<<<(int)lay.b32_pairs.size(), NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, Mm, r);
-            svd_b32_gupdate_kernel<<<(int)lay.b32_gup.size(), NTB, 0, st>>>(gup, r, Mm, Qm, b32q, b32f);
+            if (!fused) {
+                b32_solve_launch(n_pairs, st, jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, Mm, r);
+                svd_b32_gupdate_kernel<<<n_gup, NTB, 0, st>>>(gup, r, Mm, Qm, b32q, b32f);
+                return;
+            }
+            // one launch per round: solve(r) on S_r formed from S_(r-1) and the transforms of round r - 1, + the tiles of update(r - 1)
+            if (r == 0)
+                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, full_local, sbuf[0], 0);
+            else
+                svd_b32_round_kernel<<<n_pairs + n_gup, NTS3, 0, st>>>(jobs, b32p, n_pairs, gup, r, sbuf[(r - 1) & 1], sbuf[r & 1], Qm,
+                                                                       qb2[(r - 1) & 1], qb2[r & 1], fb2[(r - 1) & 1], fb2[r & 1], cnt, fro2,
+                                                                       rho, full_local);
+            if (r == rounds - 1)      // the transforms of the last round still have to reach Qtot (its S tiles are never read)
+                svd_b32_gupdate_kernel<<<n_gup - lay.n_gup_s, NTB, 0, st>>>(gup + lay.n_gup_s, r, sbuf[r & 1], Qm, qb2[r & 1], fb2[r & 1]);
         };
         auto g_end = [&]() {          // [W | G] <- Qtot [W | G] into the other image
             if (int rc = gemm(rt.apply, Qm, Wc, Wn)) rc_g = rc;
@@ -3898,6 +3932,8 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_predict_convergence = (pairwise & 1024) ? 0 : 1;   // bit 10: always run the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     tpa_svd_refine = (pairwise & 2097152) ? (1 | ((pairwise & 32768) ? 2 : 0)) : 0;   // bit 21: refinement steps (off by default); bit 15: also for complex data
+    tpa_svd_fused_rounds = (pairwise & 8388608) ? 0 : 1;    // bit 23: two launches per Gram-only round
+    tpa_svd_solve2 = (pairwise & 4194304) ? 0 : 1;    // bit 22: the round-3 solve kernel (Q and S in LDS, nine wavefronts)
     tpa_svd_gonly = (pairwise & 1048576) ? 0 : 1;     // bit 20: no Gram-only sweeps (the round-3 rounds: gram, solve, apply on the data)
     tpa_svd_refine_pre = ((pairwise >> 16) & 15) ? (int)((pairwise >> 16) & 15) - 1 : 3;   // bits 16..19: Jacobi sweeps before the first step, + 1
     return 0;

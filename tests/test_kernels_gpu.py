@@ -291,7 +291,7 @@ def test_svd_gram_only_sweeps(env):
             sv[r // 3] = sv[r // 3 + 1] = sv[r // 3 + 2]
             sv[5] = sv[4] * (1 - 1e-9)
         mats.append((u * sv) @ v.T)
-    for base in (0, 512):
+    for base in (0, 512, 8388608, 512 | 8388608, 4194304):      # fused rounds (default) / two launches per round (bit 23) / round-3 solve kernel (bit 22)
         try:
             lib.tpa_svd_set_algorithm(base)
             res, rc, sweeps = _svd_call(torch, lib, mats)
