@@ -49,7 +49,7 @@ PEAK_HBM_GBS = 8000.0
 CPU_REF = os.path.join(ROOT, 'profiles', 'r02_cpu_reference.json')
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1)
@@ -64,7 +64,9 @@ def parse():
     ap.add_argument('--qr', action='store_true', help="tebd1024: QR-based truncation (decompose_theta_qr_based, reference "
                     "algorithms/tebd.py:685) instead of the block SVD of theta")
     ap.add_argument('--eig-svd', action='store_true', help="with --qr: _eig_based_svd for the bond matrix (truncation.py:473)")
-    return ap.parse_args()
+    ap.add_argument('--no-extras', action='store_true', help="heis2048 on one GPU: skip the legs after the headline (adaptive Lanczos sweep, "
+                    "other BASELINE configurations, TeNPy's own engine on the device, vector-kernel roofline)")
+    return ap.parse_args(argv)
 
 
 CONFIGS = {     # name: (default L, default chi, description)
@@ -268,8 +270,10 @@ def random_right_canonical_mps(p, L, chi, dtype, seed):
     return MPS([p] * L, Bs, Ss, form='B')
 
 
-def main():
-    args = parse()
+def run(argv=None, emit=True):
+    """One bench line (dict); printed as JSON by rank 0 when ``emit``."""
+    args = parse(argv)
+    out = None
     L0, chi0, desc = CONFIGS[args.config]
     args.L = args.L or L0
     args.chi = args.chi or chi0
@@ -505,10 +509,154 @@ def main():
                         base["port"] = port
                 if base is not None:
                     out["cpu_baseline"] = base
-        print(json.dumps(out), flush=True)
+        if world == 1 and not args.no_extras and args.config == 'heis2048' and not is_tebd and chi == CONFIGS['heis2048'][1]:
+            try:
+                extras(out, eng, args)
+            except Exception as e:      # the extra legs must never kill the bench line
+                out["extras_error"] = repr(e)
+        if emit:
+            print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def vector_roofline(n_elems, reps=20):
+    """HBM roofline of the bandwidth-bound kernels of the path (K2-K4 Lanczos vector operations, K8-K10 copies) on
+    vectors of the size of the timed wave function: HIP events around `reps` launches of each kernel on torch's current stream,
+    algorithmic bytes as SURVEY 8(d) counts them (axpy 2R + 1W, scal 1R + 1W, dot 2R, norm 1R, fused Lanczos update 3R + 1W,
+    packed copy 1R + 1W)."""
+    import torch
+    from tenpy_amd.linalg import _device as dev
+    L = dev.lib()
+    st = dev.stream()
+    n = int(n_elems)
+    x, y, z = (torch.randn(n, dtype=torch.float64, device='cuda') for _ in range(3))
+    scr = torch.zeros(4096, dtype=torch.float64, device='cuda')
+    res = torch.zeros(8, dtype=torch.float64, device='cuda')
+    jobs = np.zeros((1, 4 + 3 * 6), dtype=np.int64)
+    jobs[0, 2], jobs[0, 4], jobs[0, 5] = 2, n // 1024, 1024            # one 2-D job: rows x 1024, unit strides
+    jobs[0, 4 + 6], jobs[0, 5 + 6], jobs[0, 4 + 12], jobs[0, 5 + 12] = 1024, 1, 1024, 1
+    jd = dev.to_device(jobs)
+    kernels = {
+        "axpy": (3, lambda: L.tpa_axpy(0, n, 0.5, 0.0, x.data_ptr(), y.data_ptr(), st)),
+        "scal": (2, lambda: L.tpa_scal(0, n, 1.0000001, 0.0, y.data_ptr(), st)),
+        "dot": (2, lambda: L.tpa_dot(0, n, x.data_ptr(), y.data_ptr(), 0, res.data_ptr(), scr.data_ptr(), st)),
+        "nrm2sq": (1, lambda: L.tpa_nrm2sq(0, n, x.data_ptr(), res.data_ptr(), scr.data_ptr(), st)),
+        "lanczos_update": (4, lambda: L.tpa_lanczos_update(0, n, z.data_ptr(), -0.3, 0.0, x.data_ptr(), -0.2, 0.0, y.data_ptr(),
+                                                           res.data_ptr(), scr.data_ptr(), st)),
+        "copy_batch": (2, lambda: L.tpa_copy_batch(0, jd.data_ptr(), 1, (n // 1024) * 1024, x.data_ptr(), z.data_ptr(), st)),
+    }
+    per, tot_b, tot_ms = {}, 0., 0.
+    for name, (passes, fn) in kernels.items():
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nbytes = passes * 8. * (n if name != "copy_batch" else (n // 1024) * 1024)
+        per[name] = {"us": round(1e3 * ms, 2), "GBs": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)}
+        tot_b += nbytes
+        tot_ms += ms
+    ach = tot_b / tot_ms / 1e6
+    return {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+            "vector_elements": n, "kernels": per,
+            "note": "Lanczos vector kernels and the packed copy on float64 vectors of the size of the timed wave function (%d elements = "
+                    "%.1f MB): HIP events around %d launches each, algorithmic bytes per SURVEY 8(d); at this size the vectors stay in the "
+                    "256 MB Infinity Cache, so a fraction above 1 of the HBM peak is cache bandwidth, not an error" % (n, 8e-6 * n, reps)}
+
+
+def extras(out, eng, args):
+    """Legs after the headline (one GPU, heis2048 only; untimed for `value`), so that the driver's line witnesses what earlier rounds
+    only had in builder-run files under profiles/ (VERDICT r3 task 2): the first sweeps at the target chi, one sweep with the
+    reference's adaptive Lanczos rule, the HBM roofline of the vector kernels, the other BASELINE configurations, and TeNPy's own
+    TwoSiteDMRGEngine on the device."""
+    import subprocess
+    import torch
+    from tenpy_amd.linalg import krylov_based as kb
+    t_all = time.time()
+    ramp = out.get("untimed_sweeps", [])
+    out["first_sweeps_at_target_chi"] = {
+        "s": [r["s"] for r in ramp if r.get("chi_max") == args.chi][:3],
+        "note": "the first sweeps after chi_max reached %d (every bond still growing, few warm SVD starts): the non-steady-state regime; "
+                "`value` is the steady-state average" % args.chi}
+    # ---- one sweep with the reference's own Lanczos rule (dmrg.py:302: N_min = 2, N_max = 20, P_tol = 1e-14)
+    saved = eng.lanczos_params
+    l0 = dict(kb.stats)
+    eng.lanczos_params = {'N_min': 2, 'N_max': 20, 'P_tol': 1.e-14}
+    torch.cuda.synchronize()
+    t0 = time.time()
+    eng.sweep()
+    torch.cuda.synchronize()
+    t_ad = time.time() - t0
+    eng.lanczos_params = saved
+    st = {k: kb.stats[k] - l0[k] for k in kb.stats}
+    out["lanczos_adaptive"] = {"s_per_sweep": t_ad, "E": float(eng.sweep_stats['E'][-1]), "lanczos_stats": st,
+                               "matvecs_per_bond": st.get('n_matvec', 0) / max(2 * (eng.psi.L - 2), 1),
+                               "note": "one further sweep on the same state with the reference's adaptive stopping rule (N_min=2, N_max=20, "
+                                       "P_tol=1e-14, dmrg.py:302) instead of the forced N=%d of the timed sweeps" % args.lanczos_N}
+    try:
+        out["roofline_vec"] = vector_roofline(sum(int(b.size) for b in eng.psi.get_theta(eng.psi.L // 2 - 1, n=2)._data))
+    except Exception as e:
+        out["roofline_vec"] = {"error": repr(e)}
+    # ---- the other BASELINE configurations, in this process (no second import of torch), one warm-up step + two timed steps each
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_gemm", "energy_err",
+            "energy_err_note", "sv_max_rel_err", "sv_max_rel_err_individual", "svd_isometry_defect", "matvec_max_rel_err", "E0_rel_err",
+            "tebd_parity", "tebd_route", "cpu_baseline", "prep_s", "svd_stats")
+    others = {}
+    for name, argv in (("xxz512", ["--config", "xxz512"]), ("hubbard1024", ["--config", "hubbard1024"]),
+                       ("tebd1024", ["--config", "tebd1024"]), ("tebd1024_qr", ["--config", "tebd1024", "--qr"])):
+        t0 = time.time()
+        try:
+            is_t = name.startswith("tebd")
+            r = run(argv + ["--steps", "2", "--warmup", "1" if is_t else "2", "--no-extras", "--cpu-sample-bonds", "1"], emit=False)
+            o = {k: r[k] for k in keep if k in r}
+            if "svd_stats" in o:
+                o["svd_stats"] = {k: v for k, v in o["svd_stats"].items() if k in ("calls_timed", "jacobi_sweeps_per_call", "max_block")}
+            if "cpu_baseline" in o and isinstance(o["cpu_baseline"], dict):
+                o["cpu_baseline"] = {k: v for k, v in o["cpu_baseline"].items() if k != "port"}
+            o["leg_s"] = round(time.time() - t0, 1)
+            others[name] = o
+        except Exception as e:
+            others[name] = {"error": repr(e)}
+        torch.cuda.synchronize()
+    out["other_configs"] = others
+    # ---- TeNPy's own engine (the reference archive, unmodified) on the device: a second process (the import hook replaces modules)
+    try:
+        from oracle import build_ref
+        if build_ref.reference_root() is None:
+            out["module_form"] = {"skipped": "no reference tree / archive on this machine"}
+        else:
+            t0 = time.time()
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'module_form_bench.py'), '--chi', str(args.chi), '--L',
+                                 str(args.L), '--sweeps', '2'], capture_output=True, text=True, timeout=400)
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
+            if pr.returncode != 0 or not line:
+                out["module_form"] = {"error": (pr.stderr or pr.stdout)[-400:]}
+            else:
+                m = json.loads(line[-1])
+                tgt = [r for r in m["sweeps"] if r["kind"].startswith("target")]
+                out["module_form"] = {
+                    "what": m["what"], "s_per_sweep_at_target_chi": [r["s"] for r in tgt], "E": tgt[-1]["E"] if tgt else None,
+                    "ramp_sweeps_s": [r["s"] for r in m["sweeps"] if not r["kind"].startswith("target")],
+                    "two_site_h": m.get("two_site_h"),
+                    "svd_warm": {k: v for k, v in (m.get("svd_warm") or {}).items() if k in ("warm_calls", "cold_calls", "fallbacks", "fb_stale", "fb_nomatch")},
+                    "leg_s": round(time.time() - t0, 1),
+                    "note": "tenpy.algorithms.dmrg.TwoSiteDMRGEngine of the reference archive, unmodified, tenpy_amd.install.install(fused=True): "
+                            "the bench protocol (Neel state, mixer on during the chi ramp, then 2 sweeps at the target chi with Lanczos N=8) in a "
+                            "second process of this run; energies comparable with `untimed_sweeps` / profiles/r02_cpu_reference.json"}
+    except Exception as e:
+        out["module_form"] = {"error": repr(e)}
+    out["extras_s"] = round(time.time() - t_all, 1)
+
+
+def main():
+    run()
 
 
 if __name__ == '__main__':

@@ -24,6 +24,11 @@ __all__ = ['TwoSiteDMRGEngine']
 
 
 class TwoSiteDMRGEngine:
+    def _warm_token(self):
+        """Key of this engine's warm-start bases (``linalg/_svd_warm.owner_token``: unique for the life of the engine, released with it)."""
+        from ..linalg import _svd_warm
+        return _svd_warm.owner_token(self)
+
     def __init__(self, psi, model_H, options, resume_data=None):
         if not psi.finite:
             raise ValueError("the stand-alone driver handles finite chains; run TeNPy's engines on the mirror for the rest")
@@ -118,7 +123,7 @@ class TwoSiteDMRGEngine:
         npc.SVD_DIST_GROUP = self._svd_group                  # scoped to this call (other SVDs in the process stay local)
         # warm start of the block SVD: the right (left) singular vectors this bond produced on the previous visit span
         # theta_0 = M . B_{i0+1} (A_{i0} . M) of this one (linalg/_svd_warm.py); consumed by the next npc.svd call
-        npc.svd_hint = ((id(self), i0), 'R' if move_right else 'L')
+        npc.svd_hint = ((self._warm_token(), i0), 'R' if move_right else 'L')
         try:
             U, S, VH, err, _ = svd_theta(theta, self.trunc_params, qtotal_LR=[psi.get_B(i0, None).qtotal, None],
                                          inner_labels=['vR', 'vL'])

@@ -112,7 +112,8 @@ def device_two_site_h(Ref):
 def hinted_mixed_svd(ref_mixed_svd):
     def mixed_svd(self, theta):
         if self.mixer is None:       # plain svd_theta: the next npc.svd decomposes the theta of bond (i0, i0 + 1)
-            npc.svd_hint = ((id(self.psi), int(self.i0)), 'R' if self.move_right else 'L')
+            from ..linalg import _svd_warm
+            npc.svd_hint = ((_svd_warm.owner_token(self.psi), int(self.i0)), 'R' if self.move_right else 'L')
         try:
             return ref_mixed_svd(self, theta)
         finally:

@@ -227,24 +227,76 @@ E_TOL = 1.e-13
 E_RANK_TOL = 1.e-15       # singular vectors with values above this fraction of |A|_F are remembered as warm-start basis
 
 
+CACHE_MAX_BYTES = int(float(os.environ.get('TPA_SVD_WARM_CACHE_GB', '48')) * (1 << 30))      # device bytes held by the cached bases (LRU)
+_cache_bytes = [0]
+_owner_tokens = {}        # id(owner) -> (token, weakref finalizer): bases are keyed by a token that is never reused
+_next_token = [1]
+
+
 def cache_clear():
     _cache.clear()
+    _cache_bytes[0] = 0
     ages.clear()
     cooldown.clear()
+
+
+def owner_token(owner):
+    """Key material for the bases of one engine / state: a process-wide counter value bound to ``owner`` for its lifetime.  (``id()``
+    of a dead engine can be handed to a new object, whose first SVDs would then try a stale basis; and the bases of a finished run
+    -- ~130 MB per bond at chi = 2048 -- stayed cached until the LRU pushed them out.)  When ``owner`` is garbage-collected its bases
+    are dropped."""
+    import weakref
+    ent = _owner_tokens.get(id(owner))
+    if ent is not None and ent[1].alive and ent[2]() is owner:
+        return ent[0]
+    token = _next_token[0]
+    _next_token[0] += 1
+    oid = id(owner)
+
+    def _release(token=token, oid=oid):
+        for k in [k for k in _cache if k[0][0] == token]:
+            _cache_bytes[0] -= _basis_bytes(_cache.pop(k))
+        for d in (ages, cooldown):
+            for k in [k for k in d if k[0] == token]:
+                d.pop(k, None)
+        if _owner_tokens.get(oid, (None,))[0] == token:
+            _owner_tokens.pop(oid, None)
+    try:
+        fin = weakref.finalize(owner, _release)
+        ref = weakref.ref(owner)
+    except TypeError:            # not weak-referenceable: fall back to the plain identity (bounded by the byte cap)
+        return ('id', oid)
+    fin.atexit = False
+    _owner_tokens[oid] = (token, fin, ref)
+    return token
+
+
+def _basis_bytes(b):
+    try:
+        return int(b.arena.numel()) * int(b.arena.element_size())
+    except Exception:
+        return 0
 
 
 def cache_get(key, side):
     ent = _cache.get((key, side))
     if ent is not None:
-        _cache.move_to_end((key, side))
+        try:
+            _cache.move_to_end((key, side))
+        except KeyError:
+            pass
     return ent
 
 
 def cache_put(key, side, basis):
+    old = _cache.pop((key, side), None)
+    if old is not None:
+        _cache_bytes[0] -= _basis_bytes(old)
     _cache[(key, side)] = basis
-    _cache.move_to_end((key, side))
-    while len(_cache) > CACHE_MAX:
-        _cache.popitem(last=False)
+    _cache_bytes[0] += _basis_bytes(basis)
+    while len(_cache) > 1 and (len(_cache) > CACHE_MAX or _cache_bytes[0] > CACHE_MAX_BYTES):
+        _, ev = _cache.popitem(last=False)
+        _cache_bytes[0] -= _basis_bytes(ev)
 
 
 def _row_norms_plan(off, rows, cols):

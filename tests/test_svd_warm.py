@@ -127,3 +127,34 @@ def test_lowdin_rows(backend):
         _svd_warm.lowdin_rows(dt, arena, [0], [24], [60], [1], [24], iterations=2)
         out = dev.to_host(arena).reshape(60, 24)
         assert np.abs(out.conj().T @ out - np.eye(24)).max() < 1e-14
+
+
+def test_warm_cache_is_bounded_by_bytes_and_tied_to_its_owner(backend, monkeypatch):
+    """the cache of warm-start bases is capped by device BYTES (LRU), keyed by a token that is never reused, and the
+    bases of an engine disappear with the engine."""
+    import gc
+    from tenpy_amd.linalg import _svd_warm as sw
+    from tenpy_amd.linalg import _device as dev
+
+    class Owner:
+        pass
+    sw.cache_clear()
+    a, b = Owner(), Owner()
+    ta, tb = sw.owner_token(a), sw.owner_token(b)
+    assert ta != tb and sw.owner_token(a) == ta
+    arena = dev.zeros(1000, np.float64)            # 8000 bytes per basis
+    mk = lambda: sw.Basis(arena, np.zeros(1, np.int64), np.ones(1, np.int64), np.ones(1, np.int64), [(0, 1)], np.float64)
+    monkeypatch.setattr(sw, 'CACHE_MAX_BYTES', 3 * 8000)
+    for i in range(5):
+        sw.cache_put((ta, i), 'R', mk())
+    assert len(sw._cache) == 3 and sw._cache_bytes[0] == 3 * 8000           # the two oldest were evicted
+    assert sw.cache_get((ta, 0), 'R') is None and sw.cache_get((ta, 4), 'R') is not None
+    sw.cache_put((tb, 0), 'L', mk())
+    sw.cooldown[(ta, 4)] = 2
+    del a
+    gc.collect()
+    assert all(k[0][0] != ta for k in sw._cache) and (ta, 4) not in sw.cooldown     # a's bases went with a
+    assert sw.cache_get((tb, 0), 'L') is not None
+    c = Owner()
+    assert sw.owner_token(c) not in (ta, tb)        # tokens are never handed out twice
+    sw.cache_clear()
