@@ -92,6 +92,11 @@ int tpa_lanczos_step(int dtype, int64_t n, void *w_dev, const void *v1_dev, cons
  *   ops : HOST int64[n_ops][12] = {kind, cfg, p0, p1, p2, count, a_slot, b_slot, c_slot, max_elems, 0, 0}
  *         kind 0: tpa_gemm_chain(dtype, cfg, tasks = p0, links = p1, tiles = p2, n_tiles = count, A, B, C)
  *         kind 1: tpa_lincomb_batch(dtype, jobs = p0, n_jobs = count, terms = p1, max_elems, src = A, dst = C)
+ *         kind 2: tpa_copy_batch(dtype, jobs = p0, n_jobs = count, max_elems, src = A, dst = C)   (pack / unpack of row panels)
+ *         kind 3: the caller's collective number `cfg` -- `tpa_lanczos_set_collective` -- is invoked on the host at this point of
+ *                 the program; it enqueues an exchange (RCCL all-gather of the row panels of a sharded matvec) that is
+ *                 ordered on the launch stream.  The recurrence, its scalars and the stopping test stay replicated and bit-identical
+ *                 on every rank, so all ranks run the same number of steps.
  *         slots: >= 0 -> bufs[slot] (HOST array of n_bufs device pointers: fixed operands and temporaries), -1 -> the input
  *         vector v_k, -2 -> the output vector w of this matvec.  (p0..p2 are device pointers stored as integers.)
  *   krylov_dev : (N_max + 1) * n elements; on return vectors 0 .. N-1 are the orthonormal Krylov basis (v_0 = psi0 / |psi0|).
@@ -101,6 +106,9 @@ int tpa_lanczos_step(int dtype, int64_t n, void *w_dev, const void *v1_dev, cons
  *   info (HOST double[4]) = {N, number of matvecs launched, summed GEMM time in ms if time_gemms else 0, |psi0|};
  *   N = 0 <=> |psi0| < cutoff (nothing useful was computed).                                                          */
 typedef int (*tpa_lanczos_callback)(int step, double alpha, double beta_sq, void *user);
+/* Collective hook of op kind 3 (per host thread; NULL = none): returns 0 on success. */
+typedef int (*tpa_collective_callback)(int which, void *user);
+int tpa_lanczos_set_collective(tpa_collective_callback cb, void *user);
 int tpa_lanczos_run(int dtype, int64_t n, const int64_t *ops, int n_ops, void *const *bufs, int n_bufs,
                     void *krylov_dev, const void *psi0_dev, int N_max, double cutoff, int has_shift, double E_shift,
                     double *scalars_dev, double *scratch_dev, tpa_lanczos_callback cb, void *user,

@@ -20,6 +20,7 @@ _lib = None
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
 LANCZOS_CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_void_p)
+COLLECTIVE_CALLBACK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
 _SIGS = {
     "tpa_version": (ctypes.c_int, []),
     "tpa_last_error": (ctypes.c_char_p, []),
@@ -36,6 +37,7 @@ _SIGS = {
     "tpa_lanczos_step": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpa_lanczos_run": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_double, _vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
+    "tpa_lanczos_set_collective": (ctypes.c_int, [COLLECTIVE_CALLBACK, _vp]),
     "tpa_krylov_combine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpa_copy_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]),
     "tpa_lincomb_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_int64, _vp, _vp, _vp]),

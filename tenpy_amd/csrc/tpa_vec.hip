@@ -396,6 +396,15 @@ inline void *lz_slot(int64_t s, void *const *bufs, int n_bufs, const void *in, v
 
 }  // namespace
 
+// collective hook of the launch programs (op kind 3): set by the caller around a run, per host thread
+static thread_local tpa_collective_callback lz_collective = nullptr;
+static thread_local void *lz_collective_user = nullptr;
+extern "C" int tpa_lanczos_set_collective(tpa_collective_callback cb, void *user) {
+    lz_collective = cb;
+    lz_collective_user = user;
+    return 0;
+}
+
 extern "C" int tpa_lanczos_run(int dtype, int64_t n, const int64_t *ops, int n_ops, void *const *bufs, int n_bufs,
                                void *krylov_dev, const void *psi0_dev, int N_max, double cutoff, int has_shift, double E_shift,
                                double *scalars_dev, double *scratch_dev, tpa_lanczos_callback cb, void *user,
@@ -444,6 +453,15 @@ extern "C" int tpa_lanczos_run(int dtype, int64_t n, const int64_t *ops, int n_o
             } else if (op[0] == 1) {
                 TPA_ARG_CHECK(a != nullptr && c != nullptr);
                 if (int rc = tpa_lincomb_batch(dtype, (const int64_t *)op[2], (int)op[5], (const int64_t *)op[3], op[9], a, c, stream)) return rc;
+            } else if (op[0] == 2) {        // batched strided copy (pack / unpack of the row panels of a sharded matvec)
+                TPA_ARG_CHECK(a != nullptr && c != nullptr);
+                if (int rc = tpa_copy_batch(dtype, (const int64_t *)op[2], (int)op[5], op[9], a, c, stream)) return rc;
+            } else if (op[0] == 3) {        // collective of the caller (all-gather of the row panels): enqueued by the host callback
+                TPA_ARG_CHECK(lz_collective != nullptr);
+                if (int rc = lz_collective((int)op[1], lz_collective_user)) {
+                    snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_lanczos_run: the collective callback of op %d failed (%d)", o, rc);
+                    return TPA_E_BADARG;
+                }
             } else {
                 TPA_ARG_CHECK(false && "unknown op kind");
             }

@@ -26,7 +26,7 @@ PIPELINED = _os.environ.get('TPA_LANCZOS_PIPELINED', '1') != '0'     # device-re
 __all__ = ['LanczosGroundState', 'LanczosEvolution', 'Arnoldi', 'lanczos', 'gram_schmidt', 'iscale_prefactor', 'iadd_prefactor_other']
 
 
-stats = {'runs': 0, 'n_matvec': 0, 'n_ill_conditioned': 0, 'n_degenerate': 0}
+stats = {'runs': 0, 'n_matvec': 0, 'n_ill_conditioned': 0, 'n_degenerate': 0, 'n_native_sharded': 0}
 
 
 class LanczosGroundState:
@@ -97,7 +97,8 @@ class LanczosGroundState:
         step is enqueued by a C++ loop, the reference's host side of a step (tridiagonal ``eigh``, ``_converged``) runs in the
         callback one step late -- the same numbers as :meth:`_build_krylov_pipelined`, without ~0.5 ms of interpreter time per step."""
         from .. import _lib
-        ops, bufs, gemm_plans = prog
+        ops, bufs, gemm_plans = prog[:3]
+        collective = prog[3] if len(prog) > 3 else None       # sharded operators: the all-gather of the row panels (op kind 3)
         w = self.psi0
         n, dtype = w._arena.numel(), w.dtype
         code, L = dev.code(dtype), dev.lib()
@@ -122,10 +123,19 @@ class LanczosGroundState:
         ptrs = np.array([t.data_ptr() for t in bufs], dtype=np.int64)
         info = np.zeros(4, dtype=np.float64)
         timed = npc.gemm_timer.enabled
-        dev.check(L.tpa_lanczos_run(code, n, ops.ctypes.data, len(ops), ptrs.ctypes.data, len(ptrs), krylov.data_ptr(),
-                                    w._arena.data_ptr(), N_max, float(self._cutoff), int(self.E_shift is not None),
-                                    float(self.E_shift or 0.), scal.data_ptr(), scr.data_ptr(), cb, None, int(timed),
-                                    info.ctypes.data, dev.stream()), "lanczos_run")
+        ccb = None
+        if collective is not None:
+            ccb = _lib.COLLECTIVE_CALLBACK(collective)
+            L.tpa_lanczos_set_collective(ccb, None)
+            stats['n_native_sharded'] = stats.get('n_native_sharded', 0) + 1
+        try:
+            dev.check(L.tpa_lanczos_run(code, n, ops.ctypes.data, len(ops), ptrs.ctypes.data, len(ptrs), krylov.data_ptr(),
+                                        w._arena.data_ptr(), N_max, float(self._cutoff), int(self.E_shift is not None),
+                                        float(self.E_shift or 0.), scal.data_ptr(), scr.data_ptr(), cb, None, int(timed),
+                                        info.ctypes.data, dev.stream()), "lanczos_run")
+        finally:
+            if ccb is not None:
+                L.tpa_lanczos_set_collective(_lib.COLLECTIVE_CALLBACK(), None)
         if err:
             raise err[0]
         N, n_mv = int(info[0]), int(info[1])

@@ -2435,6 +2435,7 @@ def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, swee
     owner = svd_block_owners(ms, ns, world)
     mine = np.nonzero(owner == rank)[0]
     failed, err = 0., None
+    flag = dev.zeros(1, np.float64)       # (allocated BEFORE the try: an allocation failure must not skip the collective below)
     if len(mine):
         lj = np.ascontiguousarray(jobs[mine])
         ls_off = np.concatenate([[0], np.cumsum(ks[mine])])
@@ -2445,9 +2446,8 @@ def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, swee
             _svd_batch_robust(L, code, lj2, len(mine), a._arena, U_arena, S_loc, V_arena, sweeps)
             for t, b in enumerate(mine):
                 S_dev[int(jobs[b, 4]):int(jobs[b, 4]) + int(ks[b])].copy_(S_loc[int(ls_off[t]):int(ls_off[t + 1])])
-        except (np.linalg.LinAlgError, ValueError) as e:
-            failed, err = 1., e
-    flag = dev.zeros(1, np.float64)
+        except Exception as e:        # ANY failure (LinAlgError, ValueError, a HIP error, out of memory) is agreed on before the gather:
+            failed, err = 1., e       # a rank that raised alone would leave the others waiting in the collective forever
     flag.fill_(failed)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     if float(flag.item()) > 0.:       # every rank raises, none is left waiting in the all-gather
@@ -2793,7 +2793,9 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     # them out and counted a failed attempt as a launch of its own)
     ev_svd = svd_timer.begin()
     tried_warm = False
-    if hint is not None and SVD_WARM and SVD_DIST_GROUP is None and not full_matrices:
+    # (with a distribution group the warm attempt runs REPLICATED on every rank: its kernels are deterministic, so the decision
+    # "stale or not" and the results are bit-identical everywhere and need no exchange; only the cold path deals the blocks out)
+    if hint is not None and SVD_WARM and not full_matrices:
         tried_warm = True
         warm = _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_offs, sweeps)
         t0 = tick('t_warm_ok' if warm is not None else 't_warm_failed', t0)
@@ -2821,7 +2823,7 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
             y_vh = _svd_y_side_cold(ms, ns, a.dtype.kind == 'c') if first_try else None
             _svd_clean_small(a.dtype, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs, v_offs, y_vh)
             t0 = tick('t_clean', t0)
-    if hint is not None and SVD_WARM and compute_uv and SVD_DIST_GROUP is None:
+    if hint is not None and SVD_WARM and compute_uv:
         _svd_warm_store(a, hint[0], U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs, v_offs)
         t0 = tick('t_store', t0)
     if ev_svd is not None:

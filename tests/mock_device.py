@@ -186,6 +186,12 @@ class MockLib:
             w *= 1. / np.sqrt(bsq)
         return 0
 
+    _collective = None
+
+    def tpa_lanczos_set_collective(self, cb, user):
+        self._collective = cb
+        return 0
+
     def tpa_lanczos_run(self, code, n, ops_p, n_ops, bufs_p, n_bufs, krylov_p, psi0_p, N_max, cutoff, has_shift, E_shift,
                         scal_p, scr_p, cb, user, time_gemms, info_p, stream):
         """Emulation of the C++ loop of tpa_lanczos_run (tenpy_amd/csrc/tpa_vec.hip): same order of device calls, the callback
@@ -214,9 +220,13 @@ class MockLib:
                 a, b, c = slot(op[6], vin, w), slot(op[7], vin, w), slot(op[8], vin, w)
                 if op[0] == 0:
                     self.tpa_gemm_chain(code, int(op[1]), int(op[2]), int(op[3]), int(op[4]), int(op[5]), a, b, c, stream)
-                else:
-                    assert op[0] == 1
+                elif op[0] == 1:
                     self.tpa_lincomb_batch(code, int(op[2]), int(op[5]), int(op[3]), int(op[9]), a, c, stream)
+                elif op[0] == 2:
+                    self.tpa_copy_batch(code, int(op[2]), int(op[5]), int(op[9]), a, c, stream)
+                else:
+                    assert op[0] == 3 and self._collective is not None
+                    assert self._collective(int(op[1]), None) == 0
             n_mv += 1
             if has_shift:
                 self.tpa_axpy(code, n, E_shift, 0., vin, w, stream)

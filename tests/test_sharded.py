@@ -34,9 +34,27 @@ def _worker(rank, world, port, ret):
         _, p = spin_half_leg('Sz')
         psi = MPS.from_product_state([p] * L, [1, 0] * (L // 2))
         eng = TwoSiteDMRGEngine(psi, H, {'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}, 'shard_matvec': True})
+        from tenpy_amd.linalg import krylov_based as kb
+        from tenpy_amd.linalg import _svd_warm
         for s in range(3):
             eng.sweep()
             assert abs(eng.sweep_stats['E'][-1] - rec['E_sweeps'][s]) <= 1e-10 * abs(rec['E_sweeps'][s])
+        # round 4 (VERDICT r3 task 5): N > 1 runs the single-GPU fast path -- the Lanczos recurrence as ONE tpa_lanczos_run call with
+        # the all-gather as the launch program's collective op, and the warm-started block SVD (replicated on every rank)
+        assert kb.stats.get('n_native_sharded', 0) > 50, kb.stats
+        assert _svd_warm.stats['warm_calls'] > 0, _svd_warm.stats
+        # ... and the native sharded run gives the numbers of the unsharded one: same N, E to rounding, the same vector
+        from tenpy_amd.linalg.krylov_based import LanczosGroundState
+        from tenpy_amd.linalg import np_conserved as npc0
+        for i_b in (L // 2 - 1, 2):
+            hs, hr = ShardedTwoSiteH(eng.env, i_b), TwoSiteH(eng.env, i_b)
+            th = hr.combine_theta(psi.get_theta(i_b, n=2))
+            n0 = kb.stats.get('n_native_sharded', 0)
+            E_s, v_s, N_s = LanczosGroundState(hs, th, {'N_min': 2, 'N_max': 20, 'P_tol': 1.e-14}).run()
+            assert kb.stats.get('n_native_sharded', 0) == n0 + 1
+            E_r, v_r, N_r = LanczosGroundState(hr, th, {'N_min': 2, 'N_max': 20, 'P_tol': 1.e-14}).run()
+            assert N_s == N_r and abs(E_s - E_r) <= 1e-13 * abs(E_r)
+            np.testing.assert_array_equal(hs.prepare_svd(v_s).to_ndarray(), hr.prepare_svd(v_r).to_ndarray())
         # matvec: sharded == unsharded on this rank
         i0 = L // 2 - 1
         from tenpy_amd.algorithms import mps_common
