@@ -55,6 +55,7 @@ class TEBDEngine:
         C.itranspose(['vL', 'p0', 'p1', 'vR'])
         theta = C.scale_axis(psi.get_SL(i0), 'vL')
         theta = theta.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])
+        npc.svd_engine_floor = True      # a TEBD bond update truncates right after the SVD: the engines' absolute floor applies (np_conserved.SVD_ABS_FLOOR)
         U, S, V, err, renorm = svd_theta(theta, self.trunc_params, [psi.get_B(i0, None).qtotal, None],
                                          inner_labels=['vR', 'vL'])
         B_R = V.split_legs(1).ireplace_label('p1', 'p')

@@ -70,6 +70,9 @@ def zeros(n, dtype):
 
 
 _pool = {}
+import threading as _threading  # noqa: E402
+_thread_ident = _threading.get_ident
+_main_thread = [_threading.main_thread().ident]
 
 
 def scratch(name, n, dtype):
@@ -81,6 +84,9 @@ def scratch(name, n, dtype):
     dt = np.dtype(dtype)
     n = int(n)
     need = max(n, 1) * dt.itemsize
+    ident = _thread_ident()
+    if ident != _main_thread[0]:
+        name = (name, ident)          # a second host thread (DMRGThreadPlusHC) gets pools of its own
     ent = _pool.get(name)
     if ent is None or ent[0].numel() * 8 < need:
         buf = empty(((int(need * 1.5) + 7) // 8 + 32) // 2 * 2, np.float64)      # `empty`: the (test-patchable) allocator; even: complex views
@@ -188,12 +194,16 @@ def ptr(tensor):
 
 
 def reduction_buffers():
-    """Per-device (out[4], scratch[TPA_RED_SCRATCH]) doubles for the deterministic reductions."""
+    """(out[4], scratch[TPA_RED_SCRATCH]) doubles for the deterministic reductions: per device AND per host thread.  (Round 4: one
+    pair per device was shared by all threads -- with the reference's ``DMRGThreadPlusHC`` pattern, two threads contracting at the same
+    time, a second ``inner`` / ``norm`` overwrote the result of the first before it was read; found by tests/test_threads.py.)"""
+    import threading
     t = torch()
-    dev = t.cuda.current_device()
-    if dev not in _scratch:
-        _scratch[dev] = (t.zeros(4, dtype=t.float64, device='cuda'), t.zeros(4096, dtype=t.float64, device='cuda'))
-    return _scratch[dev]
+    key = (t.cuda.current_device(), threading.get_ident())
+    ent = _scratch.get(key)
+    if ent is None:
+        ent = _scratch[key] = (t.zeros(4, dtype=t.float64, device='cuda'), t.zeros(4096, dtype=t.float64, device='cuda'))
+    return ent
 
 
 def read_scalar(out, cplx):

