@@ -2651,7 +2651,7 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
                 lay.b32_first_pair.push_back((int)lay.b32_pairs.size());
                 for (int64_t p = 0; p < NB32p / 2; ++p) {
                     const int pairidx = (int)lay.b32_pairs.size();
-                    lay.b32_pairs.push_back(B32Pair{b, (int)p, (int)lay.b32_entries.size(), np32});
+                    lay.b32_pairs.push_back(B32Pair{b, (int)p, (int)lay.b32_entries.size(), np32, (int)J.R, (int)J.L, J.g_off});
                     for (int q = 0; q < np32; ++q) lay.b32_entries.push_back(B32Entry{b, (int)p, q, np32, pairidx, 0, 0, 0});
                 }
                 lay.nb32_max_pad = std::max(lay.nb32_max_pad, NB32p);
@@ -3126,7 +3126,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         double kinf_prev = 0.0;
         const int jac_sweeps = sweep;
         bool failed = false;
-        for (; it < REF_MAX_IT && sweep < max_sweeps; ++it) {
+        for (; it < REF_MAX_IT; ++it) {      // refinement steps have their own budget; cyclic sweeps count against max_sweeps
             if (int rc = gemm(rt.gram, Wc, Wc, P)) return rc;
             ref_build_kernel<CPLX><<<n_rt, 256, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Qm, rowpart, rt.nts, fro2, rho, cnt);
             ref_post_kernel<<<1, 256, 0, st>>>(jobs, rows, (int)lay.rows.size(), rowpart, rt.nts, cnt, rposted);
@@ -3149,6 +3149,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 failed = true;
                 break;
             }
+            if (getenv("TPA_REF_DEBUG"))
+                fprintf(stderr, "refine it %d: need %u big %u kinf %.3e cmax %.3e e_last %.3e sweep %d\n", it, n_need, n_big, kinf, std::sqrt(cmax2), e_last, sweep);
             if (n_need == 0) {
                 converged = true;
                 break;
@@ -3163,11 +3165,13 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             kinf_prev = kinf;
             if (stalled >= 3 || kinf > REF_KINF_ENTER) {
                 bool jac_done = false;
-                for (int e = 0; e < backoff && sweep < max_sweeps && !jac_done; ++e) {
+                for (int e = 0; e < backoff && jac_sweeps + extra_sweeps < max_sweeps && !jac_done; ++e) {
                     if (int rc = jacobi_sweep_on(Wc, Gc)) return rc;
                     ++sweep;
                     ++extra_sweeps;
-                    jac_done = (posted[0] == 0) || (tpa_svd_predict_convergence && posted[1] == 0);
+                    // no predicted convergence here: the simultaneous steps leave near-degenerate rows un-paired (cosines
+                    // delta^2 / gap after a sweep that started from delta), so only a sweep without any rotation ends the iteration
+                    jac_done = (posted[0] == 0);
                 }
                 backoff = std::min(2 * backoff, 8);
                 stalled = 0;
@@ -3195,13 +3199,20 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             std::swap(Gc, Gn);
             ++sweep;
             // Simultaneous rotations leave cosines of ~ (largest cosine before) x (largest rotation) -- near-degenerate pairs keep
-            // |K| ~ 1e-2 while the cosines are already ~1e-8 -- so the step is final only if that product is far below the tolerance
-            // of the pairwise rule; otherwise the next Gram matrix decides.
-            if (tpa_svd_predict_convergence && n_big == 0 && std::sqrt(cmax2) * (kinf + std::sqrt(cmax2)) < 2.0e-17) {
+            // |K| ~ 1e-2 .. 1 while the cosines are already ~1e-8 -- so a step is the last one only if every cosine it started from was
+            // at rounding level (< 1e-13: what it leaves cannot be told from noise); otherwise the next exact Gram matrix decides.
+            if (tpa_svd_predict_convergence && n_big == 0 && cmax2 < 1.0e-26) {
                 ++it;
                 converged = true;
                 break;
             }
+        }
+        // out of refinement steps (slow linear phase: many small rotations with |K| row sums > 1): cyclic sweeps finish the job
+        while (!converged && !failed && jac_sweeps + extra_sweeps < max_sweeps) {
+            if (int rc = jacobi_sweep_on(Wc, Gc)) return rc;
+            ++sweep;
+            ++extra_sweeps;
+            converged = (posted[0] == 0);
         }
         TPA_LAUNCH_CHECK();
         tpa_svd_refine_counters[0] += 1;

@@ -125,6 +125,27 @@ def svd_theta(theta, trunc_par, qtotal_LR=[None, None], inner_labels=['vR', 'vL'
     return U, S, VH, err, renormalization
 
 
+def svd_theta_batched(thetas, trunc_par, qtotal_LRs=None, inner_labels=['vR', 'vL']):
+    """``[svd_theta(theta, trunc_par, q, inner_labels) for ...]`` for the independent two-site wave functions of one Trotter half-step
+    (reference ``algorithms/tebd.py:374-414`` loops over ``np.arange(int(odd) % 2, L, 2)``): ONE batched block SVD
+    (``np_conserved.svd_batched``), then the reference's truncation per bond (:258-313)."""
+    out = []
+    for U, S, VH in npc.svd_batched(thetas, qtotal_LRs, inner_labels=inner_labels):
+        renormalization = np.linalg.norm(S)
+        S = S / renormalization
+        keep, new_norm, err = truncate(S, trunc_par)
+        new_len = int(np.sum(keep))
+        if new_len * 100 < len(S) and (trunc_par.get('chi_max', 100) is None or new_len != trunc_par.get('chi_max', 100)):
+            warnings.warn("Catastrophic reduction in chi: {0:d} -> {1:d}".format(len(S), new_len), stacklevel=2)
+        S = S[keep] / new_norm
+        renormalization *= new_norm
+        if not np.all(keep):
+            U.iproject(keep, axes=1)
+            VH.iproject(keep, axes=0)
+        out.append((U, S, VH, err, renormalization))
+    return out
+
+
 # ======================================================================================================
 # QR-based decomposition of theta (reference truncation.py:370-711), the variant the reference flags as
 # "faster on GPUs" (algorithms/tebd.py:658-661): two tensordots + two block QRs + an SVD (or eigh) of the

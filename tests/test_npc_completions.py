@@ -299,3 +299,30 @@ def test_detect_qtotal_uses_largest_entry(backend):
     flat = np.array([[1., 0.], [5., 0.], [0., 0.]])
     assert npc.detect_qtotal(flat, legs).tolist() == [1]
     assert npc.Array._combine_leg_labels(['a', 'b', '(c.d)']) == '(a.b.(c.d))'
+
+
+def test_svd_batched_equals_svd_per_matrix(backend):
+    """``svd_batched`` (one device call over the charge blocks of several independent matrices: the bonds of a TEBD half-step) returns
+    per matrix what ``svd`` returns: same legs, qdata, singular values, reconstruction; real and complex, with and without pipes."""
+    from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
+    rng = np.random.RandomState(8)
+    ch = ChargeInfo([2])
+    for cplx in (False, True):
+        arrs = []
+        for k in range(4):
+            la = LegCharge.from_qflat(ch, rng.randint(0, 2, size=(20 + 7 * k, 1)), 1).bunch()[1]
+            lb = LegCharge.from_qflat(ch, rng.randint(0, 2, size=(18 + 5 * k, 1)), -1).bunch()[1]
+            f = (lambda sh: rng.standard_normal(sh) + 1.j * rng.standard_normal(sh)) if cplx else rng.standard_normal
+            arrs.append(npc.Array.from_func(f, [la, lb], dtype=np.complex128 if cplx else np.float64, qtotal=[k % 2]).iset_leg_labels(['x', 'y']))
+        qs = [[None, None], [a.qtotal, None] if False else [None, None], [None, None], [None, None]]
+        got = npc.svd_batched(arrs, qs, inner_labels=['i', 'j'])
+        for a, (U, S, VH) in zip(arrs, got):
+            U1, S1, VH1 = npc.svd(a, inner_labels=['i', 'j'])
+            U.test_sanity()
+            VH.test_sanity()
+            assert U.get_leg_labels() == U1.get_leg_labels() and VH.get_leg_labels() == VH1.get_leg_labels()
+            np.testing.assert_array_equal(U._qdata, U1._qdata)
+            np.testing.assert_array_equal(VH._qdata, VH1._qdata)
+            np.testing.assert_allclose(S, S1, rtol=0, atol=1e-13 * S1.max())
+            rec = npc.tensordot(U.scale_axis(S, 'i'), VH, axes=['i', 'j'])
+            np.testing.assert_allclose(rec.to_ndarray(), a.to_ndarray(), rtol=0, atol=1e-12 * S1.max())
