@@ -192,10 +192,12 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
  * look-ahead round (the host drains the stream after every sweep before it enqueues the next one).  Predicted convergence (default since round 2, validated on the MI355X on chi = 2048 blocks: same singular values
  * to 1.4e-15 sigma_max, same orthogonality, one to two sweeps fewer): a sweep in which no rotated pair had a scaled cosine
  * above 1e-7 ends the iteration without the verification sweep (quadratic convergence leaves cosines <= 1e-14).
- * Round 4 -- Gram-only sweeps (csrc/tpa_svd_b32.inc; real data, calls whose largest block has >= 96 rows; default): a sweep starts
+ * Round 4 -- Gram-only sweeps (csrc/tpa_svd_b32.inc, real data; csrc/tpa_svd_b32c.inc, complex data -- there they are the only
+ * 32-row-block path; calls whose largest block has >= 96 rows; default): a sweep starts
  * from ONE exact Gram matrix W W^T per block (grouped GEMM), its rounds rotate that matrix alone (solve per pair + 64^3 MFMA
  * updates of the Gram tiles and of the accumulated transform) and end with one product [W | G] <- Qtot [W | G]; bit 20
- * (1048576) = off (gram / solve / apply on the data in every round, the round-3 path).
+ * (1048576) = off (gram / solve / apply on the data in every round, the round-3 path; complex data: the 8-row-block rounds).
+ * Bit 14 (16384): complex Gram-only rounds with the tiles the next solve does not read on a second stream (measured slower; off).
  * Round 4 -- end game by simultaneous rotations (csrc/tpa_svd_refine.inc; OFF by default, bit 21 (2097152) = on, bit 15 (32768) =
  * also for complex data): after `pre` cyclic sweeps (bits 16-19 = `pre` + 1; 0: default 3; 1 = none: warm-started calls) every
  * further sweep is replaced by a step that takes ALL pair rotations from one exact Gram matrix, makes the transform unitary by

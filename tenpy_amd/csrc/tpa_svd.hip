@@ -836,6 +836,7 @@ __global__ __launch_bounds__(NTW) void svd_round_wide_kernel(const SvdJob *__res
 }
 
 #include "tpa_svd_b32.inc"
+#include "tpa_svd_b32c.inc"
 #include "tpa_svd_refine.inc"
 
 // ---------------------------------------------------------------------------------------------------
@@ -2543,6 +2544,7 @@ int tpa_svd_gonly = 1;           // real data, 32-row blocks: Gram-only sweeps (
 int tpa_svd_refine = 0;          // end game by simultaneous rotations + Newton-Schulz on the MFMA (tpa_svd_refine.inc): bit 0 real data, bit 1 complex data;
                                  // OFF by default (measured: 12.7 vs 13.9 ms on the saturated chi = 2048 theta, but 3.86 vs 3.61 s per sweep --
                                  // the small blocks of the other bonds lose); bit 21 of tpa_svd_set_algorithm switches it on, bit 15 also for complex data
+int tpa_svd_overlap_c = 0;       // complex Gram-only rounds: tiles that the next solve does not read on a second stream (bit 14; measured slower)
 int tpa_svd_refine_pre = 3;      // Jacobi sweeps before the first refinement step (bits 16..19 of tpa_svd_set_algorithm: value + 1)
 constexpr double REF_KINF_ENTER = 6.0;    // largest row sum of |K| with which a refinement step is attempted
 constexpr int64_t REF_MIN_R = 96;   // calls whose largest block has fewer rows keep the plain Jacobi rounds (1 - 2 rounds per sweep there)
@@ -2704,13 +2706,12 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         o = align_up(o + (int64_t)lay.ref.tiles.size() * 4, 256);
         lay.off_rrt = o;
         o = align_up(o + (int64_t)lay.ref.rtiles.size() * sizeof(RefTile), 256);
-        if (dtype != TPA_C128) {
+        {
             for (int b = 0; b < (int)lay.jobs.size(); ++b) {
                 const SvdJob &J = lay.jobs[b];
                 const int NB32 = (int)((J.R + BB - 1) / BB), np = (NB32 + 1) / 2, first = lay.b32_first_pair[b];
-                const int nct = (int)((J.R + TB - 1) / TB);
-                for (int pa = 0; pa < np; ++pa)
-                    for (int pb = 0; pb < np; ++pb) lay.b32_gup.push_back(B32GUp{2 * b, pa, pb, first + pa, first + pb, (int)J.R, J.g_off});
+                for (int pa = 0; pa < np; ++pa)      // (complex: the Hermitian mirror tile is written by the tile's own workgroup)
+                    for (int pb = (dtype == TPA_C128) ? pa : 0; pb < np; ++pb) lay.b32_gup.push_back(B32GUp{2 * b, pa, pb, first + pa, first + pb, (int)J.R, J.g_off});
             }
             lay.n_gup_s = (int)lay.b32_gup.size();       // S tiles first, then the Qtot tiles (the last launch of a sweep needs only those)
             for (int b = 0; b < (int)lay.jobs.size(); ++b) {
@@ -2740,9 +2741,9 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     if (dtype != TPA_C128) {
         lay.off_b32g = o;
         o = align_up(o + (int64_t)lay.b32_entries.size() * GSZ * 8, 256);
-        lay.off_b32q = o;
-        o = align_up(o + 2 * (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
     }
+    lay.off_b32q = o;            // two images of 64 x 64 transforms per pair
+    o = align_up(o + ((dtype == TPA_C128) ? 4 : 2) * (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
     if (lay.ref.enabled) {
         lay.off_w2 = o;                                   // [W2 | G2] with the spacing of [W | G]
         o = align_up(o + (lay.off_g - lay.off_w) + lay.g_elems * esz, 256);
@@ -2999,22 +3000,58 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     };
     // ---- Gram-only sweeps (tpa_svd_b32.inc): needs the predicted-convergence rule (the stopping decision must not rest on an
     //      updated Gram matrix alone) and the GEMM tables of the refinement layout
-    const bool use_gonly = use_b32 && !CPLX && tpa_svd_gonly && tpa_svd_predict_convergence && lay.ref.enabled && !lay.b32_gup.empty();
+    //      Complex data (tpa_svd_b32c.inc): the Gram-only sweep is the ONLY 32-row-block path (two launches per round).
+    const bool use_gonly = (CPLX ? (use_block && tpa_svd_b32 && !lay.b32_pairs.empty()) : use_b32) && tpa_svd_gonly &&
+                           tpa_svd_predict_convergence && lay.ref.enabled && !lay.b32_gup.empty();
+    const int rounds_g = (int)std::max<int64_t>(lay.nb32_max_pad - 1, 1);
     if (use_gonly && !converged && jac_limit > 0) {
         const B32GUp *gup = (const B32GUp *)(work + lay.off_gup);
         double *Wn = W2, *Gn = G2;
         int rc_g = 0;
         auto g_begin = [&]() {        // S = W W^T (both triangles) -> Mm,  Qtot = 1 -> Qm
             if (int rc = gemm(rt.gram, Wc, Wc, P)) rc_g = rc;
-            ref_nsm_kernel<false><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Mm, 0.0, -1.0, 1.0, nullptr, Qm);
+            ref_nsm_kernel<CPLX><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Mm, 0.0, -1.0, 1.0, nullptr, Qm);
         };
-        const bool fused = tpa_svd_fused_rounds && tpa_svd_solve2;
+        const bool fused = !CPLX && tpa_svd_fused_rounds && tpa_svd_solve2;
+        const bool overlap_c = CPLX && tpa_svd_overlap_c;
+        static thread_local hipStream_t st2 = nullptr;
+        static thread_local hipEvent_t ev_c[2] = {nullptr, nullptr};
+        bool rest_pending = false;
+        if (overlap_c && st2 == nullptr) {
+            // Measured on the TEBD bonds of config 5 (two 1024 x 1024 blocks), s per step: one stream 4.31, two streams 4.67 (the
+            // 68 KB tile workgroups of the second stream fill every CU and the next solve -- 101 KB of LDS, needs an empty CU --
+            // queues behind them), second stream from hipExtStreamCreateWithCUMask (3/4 of the CUs, or all of them) 7.5: OFF by default.
+            TPA_HIP_CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+            TPA_HIP_CHECK(hipEventCreateWithFlags(&ev_c[0], hipEventDisableTiming));
+            TPA_HIP_CHECK(hipEventCreateWithFlags(&ev_c[1], hipEventDisableTiming));
+        }
         const int n_pairs = (int)lay.b32_pairs.size(), n_gup = (int)lay.b32_gup.size();
         double *sbuf[2] = {Mm, P};                                       // S_k lives in image k % 2 (P: the split-K partials are dead by then)
         double *qb2[2] = {b32q, b32q + (int64_t)n_pairs * TB * TB};
         int *fb2[2] = {b32f, b32f + n_pairs};
         auto g_round = [&](int r) {
             const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
+            if (CPLX) {
+                // complex data: solve(r) -> [tiles the solves of round r + 1 read] on the call's stream, the other tiles on a second
+                // stream beside solve(r + 1); the last round of a sweep only has to bring its transforms into Qtot
+                const bool last = (r == rounds_g - 1);
+                double2 *qbr = (double2 *)b32q + (int64_t)(r & 1) * n_pairs * TB * TB;
+                int *fbr = b32f + (r & 1) * n_pairs;
+                svd_b32_solve_c_kernel<<<n_pairs, NTSC, 0, st>>>(b32p, qbr, fbr, cnt, fro2, rho, full_local, (const double2 *)Mm, r);
+                const B32GUp *gl = last ? gup + lay.n_gup_s : gup;
+                const int nl = last ? n_gup - lay.n_gup_s : n_gup;
+                if (!overlap_c) {
+                    svd_b32_gupdate_c_kernel<<<nl, NTB, 0, st>>>(gl, r, (double2 *)Mm, (double2 *)Qm, qbr, fbr, 0);
+                    return;
+                }
+                if (hipEventRecord(ev_c[0], st) != hipSuccess || hipStreamWaitEvent(st2, ev_c[0], 0) != hipSuccess) rc_g = 999;
+                if (rest_pending && hipStreamWaitEvent(st, ev_c[1], 0) != hipSuccess) rc_g = 999;      // tiles of round r - 1
+                if (!last) svd_b32_gupdate_c_kernel<<<lay.n_gup_s, NTB, 0, st>>>(gup, r, (double2 *)Mm, (double2 *)Qm, qbr, fbr, 1);
+                svd_b32_gupdate_c_kernel<<<nl, NTB, 0, st2>>>(gl, r, (double2 *)Mm, (double2 *)Qm, qbr, fbr, last ? 0 : 2);
+                if (hipEventRecord(ev_c[1], st2) != hipSuccess) rc_g = 999;
+                rest_pending = true;
+                return;
+            }
             if (!fused) {
                 b32_solve_launch(n_pairs, st, jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, Mm, r);
                 svd_b32_gupdate_kernel<<<n_gup, NTB, 0, st>>>(gup, r, Mm, Qm, b32q, b32f);
@@ -3027,10 +3064,14 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 svd_b32_round_kernel<<<n_pairs + n_gup, NTS3, 0, st>>>(jobs, b32p, n_pairs, gup, r, sbuf[(r - 1) & 1], sbuf[r & 1], Qm,
                                                                        qb2[(r - 1) & 1], qb2[r & 1], fb2[(r - 1) & 1], fb2[r & 1], cnt, fro2,
                                                                        rho, full_local);
-            if (r == rounds - 1)      // the transforms of the last round still have to reach Qtot (its S tiles are never read)
+            if (r == rounds_g - 1)    // the transforms of the last round still have to reach Qtot (its S tiles are never read)
                 svd_b32_gupdate_kernel<<<n_gup - lay.n_gup_s, NTB, 0, st>>>(gup + lay.n_gup_s, r, sbuf[r & 1], Qm, qb2[r & 1], fb2[r & 1]);
         };
         auto g_end = [&]() {          // [W | G] <- Qtot [W | G] into the other image
+            if (rest_pending) {
+                if (hipStreamWaitEvent(st, ev_c[1], 0) != hipSuccess) rc_g = 999;
+                rest_pending = false;
+            }
             if (int rc = gemm(rt.apply, Qm, Wc, Wn)) rc_g = rc;
             std::swap(Wc, Wn);
             std::swap(Gc, Gn);
@@ -3039,7 +3080,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         g_begin();
         g_round(0);
         while (!converged && sweep < jac_limit) {
-            for (int r = 1; r < rounds; ++r) g_round(r);
+            for (int r = 1; r < rounds_g; ++r) g_round(r);
             g_end();
             post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, nullptr, posted, 1);
             TPA_HIP_CHECK(hipEventRecord(ev_post, st));
@@ -3057,6 +3098,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 g_round(0);
             }
         }
+        if (rest_pending) TPA_HIP_CHECK(hipStreamWaitEvent(st, ev_c[1], 0));      // (look-ahead round of a sweep that was not needed)
     } else
     if (use_b32 && tpa_svd_lookahead && !converged && jac_limit > 0) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
@@ -3944,6 +3986,7 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
     tpa_svd_refine = (pairwise & 2097152) ? (1 | ((pairwise & 32768) ? 2 : 0)) : 0;   // bit 21: refinement steps (off by default); bit 15: also for complex data
     tpa_svd_fused_rounds = (pairwise & 8388608) ? 0 : 1;    // bit 23: two launches per Gram-only round
+    tpa_svd_overlap_c = (pairwise & 16384) ? 1 : 0;   // bit 14: complex Gram-only rounds with the non-urgent tiles on a second stream (off by default)
     tpa_svd_solve2 = (pairwise & 4194304) ? 0 : 1;    // bit 22: the round-3 solve kernel (Q and S in LDS, nine wavefronts)
     tpa_svd_gonly = (pairwise & 1048576) ? 0 : 1;     // bit 20: no Gram-only sweeps (the round-3 rounds: gram, solve, apply on the data)
     tpa_svd_refine_pre = ((pairwise >> 16) & 15) ? (int)((pairwise >> 16) & 15) - 1 : 3;   // bits 16..19: Jacobi sweeps before the first step, + 1

@@ -274,14 +274,16 @@ def test_svd_rank_revealing_path(env, cplx):
         assert u[:, dead].abs().max().item() == 0.0 if bool(dead.any()) else True
 
 
-def test_svd_gram_only_sweeps(env):
+@pytest.mark.parametrize("cplx", [False, True])
+def test_svd_gram_only_sweeps(env, cplx):
     """Round 4: Gram-only sweeps of the 32-row-block iteration (one exact Gram matrix per sweep, rounds on it alone, one product
     with the accumulated transform at the end) against torch's LAPACK SVD and against the same call with the round-3 rounds
     (bit 20), with and without the pivoted-QR preconditioner: same singular values, reconstruction, orthonormality, and no more
-    sweeps than the rounds that touch the data."""
+    sweeps than the rounds that touch the data.  Complex data (csrc/tpa_svd_b32c.inc): the Gram-only sweep on 32-row blocks against
+    the 8-row-block rounds on the data (bit 20 switches it off)."""
     torch, lib, _lib = env
     g = torch.Generator(device="cpu").manual_seed(17)
-    dt = torch.float64
+    dt = torch.complex128 if cplx else torch.float64
     mats = []
     for (m, n, r) in [(300, 300, 160), (200, 333, 90), (420, 390, 390), (70, 40, 1), (128, 257, 128), (5, 90, 5), (97, 97, 97)]:
         u, _ = torch.linalg.qr(torch.randn(m, r, dtype=dt, generator=g))
@@ -290,8 +292,10 @@ def test_svd_gram_only_sweeps(env):
         if r > 8:
             sv[r // 3] = sv[r // 3 + 1] = sv[r // 3 + 2]
             sv[5] = sv[4] * (1 - 1e-9)
-        mats.append((u * sv) @ v.T)
-    for base in (0, 512, 8388608, 512 | 8388608, 4194304):      # fused rounds (default) / two launches per round (bit 23) / round-3 solve kernel (bit 22)
+        mats.append((u * sv.to(dt)) @ v.conj().T)
+    # fused rounds (default) / two launches per round (bit 23) / round-3 solve kernel (bit 22); complex data: one stream (default) / the tiles the
+    # next solve does not read on a second stream (bit 14)
+    for base in ((0, 16384) if cplx else (0, 512, 8388608, 512 | 8388608, 4194304)):
         try:
             lib.tpa_svd_set_algorithm(base)
             res, rc, sweeps = _svd_call(torch, lib, mats)
@@ -308,13 +312,13 @@ def test_svd_gram_only_sweeps(env):
             assert (s - ref).abs().max().item() <= 1e-13 * scale * max(m, n)
             assert (s - s2).abs().max().item() <= 1e-13 * scale * max(m, n)
             assert bool((s[:-1] >= s[1:]).all())
-            assert ((u * s) @ vh - x).abs().max().item() <= 1e-12 * scale * max(m, n)
+            assert ((u * s.to(dt)) @ vh - x).abs().max().item() <= 1e-12 * scale * max(m, n)
             for thresh, tol in ((1e-6, 1e-12), (1e-12, 1e-9)):
                 nz = s > thresh * scale
                 k = int(nz.sum())
                 if k:
-                    assert (u[:, nz].T @ u[:, nz] - torch.eye(k, dtype=dt)).abs().max().item() < tol
-                    assert (vh[nz] @ vh[nz].T - torch.eye(k, dtype=dt)).abs().max().item() < tol
+                    assert (u[:, nz].conj().T @ u[:, nz] - torch.eye(k, dtype=dt)).abs().max().item() < tol
+                    assert (vh[nz] @ vh[nz].conj().T - torch.eye(k, dtype=dt)).abs().max().item() < tol
 
 
 def _refine_stats(lib, reset=False):
