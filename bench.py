@@ -261,7 +261,10 @@ def build_tebd(args):
     if args.qr:     # the reference's GPU-motivated route -- QR of theta Y0 instead of the SVD of theta
         return QRBasedTEBDEngine(psi, h_bonds, {'dt': 0.05, 'compute_err': True, 'cbe_expand': 0.1, 'use_eig_based_svd': bool(args.eig_svd),
                                                 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
-    return TEBDEngine(psi, h_bonds, {'dt': 0.05, 'compute_err': False, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
+    opts = {'dt': 0.05, 'compute_err': False, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}}
+    if os.environ.get('TPA_TEBD_BATCH'):          # measurement knob: k bonds of a half-step per batched SVD call (tebd.py: update_bonds_batched)
+        opts['batch_bonds'] = int(os.environ['TPA_TEBD_BATCH'])
+    return TEBDEngine(psi, h_bonds, opts)
 
 
 def random_right_canonical_mps(p, L, chi, dtype, seed):

@@ -72,13 +72,14 @@ class TEBDEngine:
 
     # The bonds of one half-step do not share a site (reference tebd.py:374-414 loops over ``np.arange(int(odd) % 2, L, 2)``), so their
     # block SVDs can be decomposed in ONE batched device call (``np_conserved.svd_batched``; ``options['batch_bonds'] = True``; same
-    # numbers bond by bond, tests/test_tebd_golden.py).  Measured on the MI355X (round 4, chi = 1024 complex, 32 bonds x 2 blocks of
-    # 1024 x 1024 per call): 2.14 s per batched call against 32 x 54 ms = 1.7 s bond by bond -- 6.6 instead of 5.4 s per time step.
-    # The complex Jacobi still streams the whole block once per round of 8-row blocks (127 rounds per sweep): one bond alone is
-    # latency-bound at 0.75 TB/s of cache traffic, 64 blocks together are bandwidth-bound at 1.1 TB/s with the two-kernel rounds (the
-    # one-launch round needs all its workgroups co-resident), so there is nothing to win until complex data gets the Gram-only sweeps
-    # of the real path (two passes over the data per SWEEP).  Off by default.
-    batch_bonds_default = False
+    # numbers bond by bond, tests/test_tebd_golden.py; an integer k = groups of k bonds).  Measured on the MI355X (round 4, TFI L = 64,
+    # chi = 1024 complex: 2 blocks of 1024 x 1024 per bond), s per time step:
+    #   8-row-block complex rounds (round 3):   bond by bond 5.37, whole half-step 6.60 (bandwidth-bound: every round streams the block)
+    #   Gram-only sweeps on 32-row blocks (csrc/tpa_svd_b32c.inc): bond by bond 4.31, groups of 4 / 8 / 16: 2.62 / 2.49 / 2.44,
+    #   whole half-step (32 bonds, 64 blocks in one tpa_svd_batch): 2.34 -- the solve of a round occupies 32 CUs per bond and the
+    #   pivoted-QR chain is latency-bound, both are shared by the whole group; the MFMA tile updates scale with the group.
+    # Same truncation error and entropies to the last digit (bench line `tebd_parity`).  On by default.
+    batch_bonds_default = True
 
     def update_bonds_batched(self, bonds, U):
         psi = self.psi
@@ -115,7 +116,9 @@ class TEBDEngine:
             U = self._gates(frac)
             bonds = [i for i in range(1, L) if i % 2 == (1 - parity)]        # bond (i-1, i) with even i-1 <=> parity 0
             if batch:
-                self.update_bonds_batched(bonds, U)
+                group = len(bonds) if batch is True else max(int(batch), 1)      # True: the whole half-step; k: k bonds per device call
+                for g0 in range(0, len(bonds), group):
+                    self.update_bonds_batched(bonds[g0:g0 + group], U)
             else:
                 for i in bonds:
                     self.update_bond(i, U[i])
