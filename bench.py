@@ -328,7 +328,7 @@ def run(argv=None, emit=True):
     if not is_tebd:
         eng.phase_time = {k: 0. for k in eng.phase_time}
     # ---- timed region: exactly K steps
-    for tm in (npc.gemm_timer, npc.svd_timer):
+    for tm in (npc.gemm_timer, npc.svd_timer, npc.eigh_timer):
         tm.keep = bool(os.environ.get('TPA_BENCH_SVD_RECORDS')) and tm is npc.svd_timer
         tm.reset()
         tm.enabled = True
@@ -352,7 +352,7 @@ def run(argv=None, emit=True):
     if dist is not None:
         dist.barrier()
     elapsed = time.time() - t0
-    for tm in (npc.gemm_timer, npc.svd_timer):
+    for tm in (npc.gemm_timer, npc.svd_timer, npc.eigh_timer):
         tm.enabled = False
         tm.collect()
     if os.environ.get('TPA_BENCH_SVD_RECORDS'):       # diagnostic: HIP-event time, kind, sweeps and largest block of every timed SVD call
@@ -398,6 +398,10 @@ def run(argv=None, emit=True):
                          "flop_model": "4 m^2 n + 8 m n^2 + 9 n^3 per block (m >= n), x4 for complex128 (SURVEY 8(d))"})
         roof_gemm = roof(npc.gemm_timer, "gemm_chain_kernel<f64 | c128> (grouped chained MFMA GEMM: tensordot / Lanczos matvec / env update)",
                          {"flop_model": "sum over GEMM links of c m k n, c = 2 real / 8 complex"})
+        roof_eigh = None
+        if npc.eigh_timer.n_launch:
+            roof_eigh = roof(npc.eigh_timer, "tpa_eigh_batch (two-sided block Jacobi eigensolver of Hermitian blocks: _eig_based_svd / density-matrix mixer)",
+                             {"flop_model": "9 n^3 per Hermitian n x n block, x4 for complex128"})
         n_upd = (L - 1) if is_tebd else 2 * (L - 2)
         unit = "s/step" if is_tebd else "s/sweep"
         what = "TEBD evolve_step time (s), TFI" if is_tebd else \
@@ -416,6 +420,10 @@ def run(argv=None, emit=True):
                           "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge "
                                                                     "blocks distributed (LPT + all-gather), env update replicated" % world},
                "prep_s": t_prep, "roofline": roof_svd, "roofline_gemm": roof_gemm, "energy_err": None}
+        if roof_eigh is not None:
+            out["roofline_eigh"] = roof_eigh
+            if roof_eigh["time_share_of_timed_region"] > roof_svd["time_share_of_timed_region"]:      # --eig-svd: the eigensolver is the dominant family
+                out["roofline"], out["roofline_svd"] = roof_eigh, roof_svd
         if is_tebd:
             out["tebd_route"] = ("QR-based truncation (decompose_theta_qr_based%s)" % (" + _eig_based_svd" if args.eig_svd else "")) if args.qr \
                 else "block SVD of theta (svd_theta)"
@@ -423,6 +431,10 @@ def run(argv=None, emit=True):
             out["norm"] = float(eng.norm)
             out["S_mid_entropy"] = float(-np.sum(np.asarray(eng.psi.get_SL(L // 2)) ** 2 * np.log(np.asarray(eng.psi.get_SL(L // 2)) ** 2 + 1e-300)))
             tref_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_cpu_reference_tebd.json')
+            qr_ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_cpu_reference_tebd_qr.json')
+            like_for_like = not args.qr
+            if args.qr and not args.eig_svd and os.path.exists(qr_ref):      # the reference's own QRBasedTEBDEngine, run offline (round 4)
+                tref_file, like_for_like = qr_ref, True
             n_done = args.warmup + args.steps
             if os.path.exists(tref_file) and world == 1:
                 with open(tref_file) as f:
@@ -430,7 +442,7 @@ def run(argv=None, emit=True):
                 if tref.get('L') == L and tref.get('chi') == chi:
                     out["cpu_baseline"] = {"value": tref['s_per_step_best'], "unit": "s/step", "cores": tref.get('cores'), "kind": "reference",
                                            "where": "offline: build container, %s host cores" % tref.get('cores'),
-                                           "sample": "TeNPy's own TEBDEngine (order 2, compiled _npc_helper) on the same synthetic state: best of "
+                                           "sample": "TeNPy's own " + tref.get('engine', 'TEBDEngine').split(' ')[0] + " (order 2, compiled _npc_helper) on the same synthetic state: best of "
                                                      "%d full steps (%s)" % (len(tref['steps']), os.path.basename(tref_file))}
                     rs = [r for r in tref['steps'] if r['step'] == n_done]
                     if rs:          # the reference has the state after exactly this many steps: compare what the line reports
@@ -442,8 +454,10 @@ def run(argv=None, emit=True):
                             "trunc_err_eps_rel_err": abs(out["trunc_err_eps"] - r['trunc_err_eps']) / max(abs(r['trunc_err_eps']), 1e-300),
                             "schmidt_top8_max_abs_err": float(np.max(np.abs(Sd[:8] - np.asarray(r['schmidt_top8'])))),
                             "chi_mid": [int(len(Sd)), int(r['chi_mid'])],
-                            "note": "TeNPy's TEBDEngine run offline on the same seeded state (scripts/cpu_reference_tebd.py); the QR-based routes are "
-                                    "different truncations and are expected to agree only to the size of the truncation error"}
+                            "like_for_like": like_for_like,
+                            "note": "TeNPy's %s run offline on the same seeded state (scripts/cpu_reference_tebd.py)%s"
+                                    % (tref.get('engine', 'TEBDEngine'), "" if like_for_like else "; the QR-based routes are different truncations "
+                                       "and are expected to agree with the SVD-based reference only to the size of the truncation error")}
                     else:
                         out["tebd_parity"] = {"after_steps": n_done, "note": "the offline reference holds steps %s only: run with --warmup W --steps K, "
                                               "W + K among them, for the comparison" % [r['step'] for r in tref['steps']]}
@@ -619,10 +633,11 @@ def extras(out, eng, args):
     # ---- the other BASELINE configurations, in this process (no second import of torch), one warm-up step + two timed steps each
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_gemm", "energy_err",
             "energy_err_note", "sv_max_rel_err", "sv_max_rel_err_individual", "svd_isometry_defect", "matvec_max_rel_err", "E0_rel_err",
-            "tebd_parity", "tebd_route", "cpu_baseline", "prep_s", "svd_stats")
+            "tebd_parity", "tebd_route", "cpu_baseline", "prep_s", "svd_stats", "roofline_eigh", "roofline_svd")
     others = {}
     for name, argv in (("xxz512", ["--config", "xxz512"]), ("hubbard1024", ["--config", "hubbard1024"]),
-                       ("tebd1024", ["--config", "tebd1024"]), ("tebd1024_qr", ["--config", "tebd1024", "--qr"])):
+                       ("tebd1024", ["--config", "tebd1024"]), ("tebd1024_qr", ["--config", "tebd1024", "--qr"]),
+                       ("tebd1024_qr_eig", ["--config", "tebd1024", "--qr", "--eig-svd"])):
         t0 = time.time()
         try:
             is_t = name.startswith("tebd")

@@ -2011,6 +2011,16 @@ class _Work:
 svd_timer = KernelTimer()
 
 
+# `tpa_eigh_batch` (the `_eig_based_svd` route of the QR-based TEBD, the density-matrix mixer): 9 n^3 flops per Hermitian n x n block
+# (tridiagonalisation 4/3 n^3 + vectors; the symmetric share of the gesdd model above), x4 complex; bytes_min = itemsize (2 n^2 + n).
+eigh_timer = KernelTimer()
+
+
+def eigh_work(ns, itemsize, cplx):
+    n = np.asarray(ns, dtype=np.float64)
+    return _Work(float(np.sum(9. * n ** 3)) * (4. if cplx else 1.), float(itemsize * np.sum(2. * n * n + n)))
+
+
 def svd_work(ms, ns, itemsize, cplx):
     big, small = np.maximum(ms, ns).astype(np.float64), np.minimum(ms, ns).astype(np.float64)
     flops = np.sum(4. * big * big * small + 8. * big * small * small + 9. * small ** 3) * (4. if cplx else 1.)
@@ -2583,6 +2593,8 @@ def _svd_y_side_cold(ms, ns, cplx):
     plane rotations / Householder reflections and orthonormal by construction): True -> VH, False -> U.  Mirrors
     ``tpa_svd_batch`` (csrc/tpa_svd.hip): with the rank-revealing QR (blocks >= 32, the default chain entry) X = A (m >= n) or
     A^T is factorised and the rows of R are orthogonalised; without it the rows of A (m < n) or of A^T."""
+    if SVD_ALGORITHM_CHAIN[0] & (1 | 512):      # head of the chain without the pivoted QR (measurement knobs): the predicate below does
+        return None                              # not describe that call -- both factors get the clean-up (ADVICE r3)
     rmax_pad = int(np.max((np.minimum(ms, ns) + 1) // 2 * 2))
     dim_max = int(max(np.max(ms), np.max(ns)))
     if rmax_pad >= 32 and dim_max <= (2048 if cplx else 8192):
@@ -3367,8 +3379,10 @@ def eigh(a, UPLO='L', sort=None):
         wb = L.tpa_eigh_worksize(code, jobs.ctypes.data, nblk)
         work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
         sweeps = dev.c_int()
+        ev = eigh_timer.begin()
         dev.check(L.tpa_eigh_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), W_dev.data_ptr(), V_arena.data_ptr(),
                                    work.data_ptr(), int(wb), 60, 0.0, dev.byref(sweeps), dev.stream()), "eigh_batch")
+        eigh_timer.end(ev, eigh_work(ms, a.dtype.itemsize, a.dtype.kind == 'c'))
         W_host = dev.to_host(W_dev)
         perm_full = np.arange(a.shape[0], dtype=np.int64)
         need_perm = False
