@@ -381,19 +381,21 @@ def run(argv=None, emit=True):
                  "time_share_of_timed_region": sec / max(elapsed, 1e-12)}
             r.update(extra)
             return r
-        pmc_note = {"traffic_note": "no PMC summary for this workload (profiles/r03_svd_call_pmc.json is the chi=2048 Heisenberg call)"}
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_svd_call_pmc.json')
+        pmc_note = {"traffic_note": "no PMC summary for this workload (profiles/r04_svd_call_pmc.json is the chi=2048 Heisenberg call)"}
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_svd_call_pmc.json')
         if args.config == 'heis2048' and os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 pmc = json.load(f)
             pmc_note = {"traffic": pmc["bytes_per_call_corrected"],
                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes of the same call (FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; "
-                                        "profiles/r03_svd_call_pmc.json: one COLD call on the saturated centre-bond theta), not collected in this "
+                                        "profiles/r04_svd_call_pmc.json: one COLD call on the saturated centre-bond theta), not collected in this "
                                         "run -- rocprofv3 counters cannot be read from inside the timed process; fabric-side counters incl. "
-                                        "Infinity-Cache hits: three passes over the row blocks per Jacobi round, on-die"}
+                                        "Infinity-Cache hits: the Gram matrices and accumulated transforms of the Gram-only rounds + the trailing updates of the pivoted QR, on-die"}
         roof_svd = roof(npc.svd_timer, "block SVD of one npc.svd call, all charge blocks together: cold = tpa_svd_batch (rank-revealing pivoted QR "
-                                       "qrp_panel / qrp_update + one-sided Jacobi on 32-row blocks svd_b32_gram / _solve / _apply + Q application), "
-                                       "warm = 3 grouped GEMMs + the same Jacobi without the QR; + Loewdin clean-up GEMMs",
+                                       "qrp_panel / qrp_update + one-sided Jacobi on 32-row blocks: Gram-only sweeps = Gram GEMM, svd_b32_round (solve + Gram / Qtot "
+                                       "tile updates, one launch per round; complex: svd_b32_solve_c + svd_b32_gupdate_c), apply GEMM; + Q application), "
+                                       "warm = failed or successful warm attempt (3 grouped GEMMs + the same Jacobi without the QR); + Loewdin clean-up GEMMs + "
+                                       "basis store: ONE timer entry per npc.svd",
                         {**pmc_note,
                          "flop_model": "4 m^2 n + 8 m n^2 + 9 n^3 per block (m >= n), x4 for complex128 (SURVEY 8(d))"})
         roof_gemm = roof(npc.gemm_timer, "gemm_chain_kernel<f64 | c128> (grouped chained MFMA GEMM: tensordot / Lanczos matvec / env update)",
