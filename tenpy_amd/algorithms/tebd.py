@@ -11,7 +11,7 @@ matrices built once on the host (``_calc_U_bond`` :585 does the same through ``n
 import numpy as np
 
 from ..linalg import np_conserved as npc
-from ..linalg.truncation import svd_theta, svd_theta_batched, TruncationError, decompose_theta_qr_based
+from ..linalg.truncation import svd_theta, svd_theta_batched, TruncationError, decompose_theta_qr_based, decompose_theta_qr_based_batched
 
 __all__ = ['TEBDEngine', 'QRBasedTEBDEngine', 'bond_gate']
 
@@ -132,7 +132,42 @@ class TEBDEngine:
 class QRBasedTEBDEngine(TEBDEngine):
     """TEBD with the QR-based truncation (reference ``QRBasedTEBDEngine.update_bond``, tebd.py:685-738; options
     ``cbe_expand`` (0.1), ``cbe_expand_0``, ``cbe_min_block_increase`` (1), ``use_eig_based_svd``, ``compute_err``)."""
-    batch_bonds_default = False      # (its update_bond is a different decomposition: bond by bond)
+    # the bond matrices Xi of a half-step are decomposed in one batched block SVD (truncation.decompose_theta_qr_based_batched); the
+    # `use_eig_based_svd` flavour stays bond by bond
+    batch_bonds_default = True
+
+    def update_bonds_batched(self, bonds, U):
+        if self.options.get('use_eig_based_svd', False):
+            for i in bonds:
+                self.update_bond(i, U[i])
+            return
+        psi = self.psi
+        Cs, items = [], []
+        for i in bonds:
+            i0, i1 = i - 1, i
+            expand = self._expansion_rate(i)
+            C = psi.get_theta(i0, n=2, formL=0.)
+            C = npc.tensordot(U[i], C, axes=(['p0*', 'p1*'], ['p0', 'p1']))
+            C.itranspose(['vL', 'p0', 'p1', 'vR'])
+            theta = C.scale_axis(psi.get_SL(i0), 'vL')
+            theta = theta.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])
+            old_B_L, old_B_R = psi.get_B(i0, 'B'), psi.get_B(i1, 'B')
+            Cs.append(C)
+            items.append((old_B_L.qtotal, old_B_R.qtotal, old_B_R.get_leg('vL'), theta, False, expand,
+                          self.options.get('cbe_min_block_increase', 1)))
+        res = decompose_theta_qr_based_batched(items, self.trunc_params, self.options.get('compute_err', True), False)
+        for i, C, it, (_, S, B_R, form, err, renorm) in zip(bonds, Cs, items, res):
+            i0, i1 = i - 1, i
+            assert form[1] == 'B'
+            B_L = npc.tensordot(C.combine_legs(('p1', 'vR'), pipes=it[3].legs[1]), B_R.conj(), axes=[['(p1.vR)'], ['(p*.vR*)']])
+            B_L.iscale_prefactor(1. / renorm)
+            B_L.ireplace_labels(['p0', 'vL*'], ['p', 'vR'])
+            B_R = B_R.split_legs(1)
+            self.norm *= renorm
+            psi.set_B(i0, B_L, form='B')
+            psi.set_SL(i1, S)
+            psi.set_B(i1, B_R, form='B')
+            self.trunc_err = self.trunc_err + err
 
     def _expansion_rate(self, i):
         expand = self.options.get('cbe_expand', 0.1)

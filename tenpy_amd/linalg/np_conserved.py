@@ -3080,7 +3080,51 @@ def _qr_rank_cut(a, cutoff):
     return tensordot(U, q, axes=1), R
 
 
-def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=False, qtotal_Q=None, inner_qconj=+1):
+def qr_batched(arrays, inner_labels=[None, None], inner_qconj=+1):
+    """``[qr(a, inner_labels=inner_labels, inner_qconj=inner_qconj) for a in arrays]`` (reduced mode) for INDEPENDENT matrices -- the
+    bonds of one Trotter half-step of the QR-based TEBD, reference ``algorithms/tebd.py:374-414`` / ``truncation.py:611-640`` -- with
+    the charge blocks of all of them in ONE ``tpa_qr_batch`` call: the blocked Householder QR is a chain of panel / update launches
+    that keeps a few CUs busy per matrix, independent matrices share the chain.  The inputs stay where they are (job offsets are
+    taken relative to the lowest arena address); per matrix the result is bit-identical to :func:`qr`."""
+    n = len(arrays)
+    if n == 0:
+        return []
+    dtype = arrays[0].dtype
+    blocked = [a.as_completely_blocked() for a in arrays]
+    if n == 1 or any(ab.stored_blocks == 0 or ab.dtype != dtype for _, ab in blocked):
+        return [qr(a, inner_labels=inner_labels, inner_qconj=inner_qconj) for a in arrays]
+    isz = np.dtype(dtype).itemsize
+    base = min(ab._arena.data_ptr() for _, ab in blocked)
+    jobs_all, per = [], []
+    q_base = r_base = 0
+    for _, ab in blocked:
+        offs, ms, ns = _blocked_matrix_jobs(ab)
+        rel = ab._arena.data_ptr() - base
+        if rel % isz:            # (cannot happen with torch's 256-B aligned allocations; views into arenas keep element alignment)
+            return [qr(a, inner_labels=inner_labels, inner_qconj=inner_qconj) for a in arrays]
+        ks = np.minimum(ms, ns)
+        q_offs = np.concatenate([[0], np.cumsum(ms * ks)])
+        r_offs = np.concatenate([[0], np.cumsum(ks * ns)])
+        jobs = np.zeros((len(ms), 8), dtype=np.int64)
+        jobs[:, 0], jobs[:, 1], jobs[:, 2] = offs + rel // isz, ms, ns
+        jobs[:, 3], jobs[:, 4] = q_base + q_offs[:-1], r_base + r_offs[:-1]
+        jobs_all.append(jobs)
+        per.append((q_base, q_offs, r_base, r_offs, ms, ns, ks))
+        q_base += int(q_offs[-1])
+        r_base += int(r_offs[-1])
+    jobs_all = np.ascontiguousarray(np.concatenate(jobs_all, axis=0))
+    Q_big, R_big = dev.empty(q_base, dtype), dev.empty(r_base, dtype)
+    dev.check(dev.lib().tpa_qr_batch(dev.code(dtype), jobs_all.ctypes.data, len(jobs_all), base, Q_big.data_ptr(), R_big.data_ptr(),
+                                     dev.stream()), "qr_batch")
+    out = []
+    for a, blk, (qb, q_offs, rb, r_offs, ms, ns, ks) in zip(arrays, blocked, per):
+        res = (Q_big[qb:qb + int(q_offs[-1])], q_offs, R_big[rb:rb + int(r_offs[-1])], r_offs, ms, ns, ks)
+        out.append(qr(a, inner_labels=inner_labels, inner_qconj=inner_qconj, _blocked=blk, _device=res))
+    return out
+
+
+def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=False, qtotal_Q=None, inner_qconj=+1, _blocked=None,
+       _device=None):
     """Block-wise QR ``a = Q R`` (reference np_conserved.py:4139): Householder panels / compact-WY updates on the device
     for all charge blocks at once.  ``mode='complete'``: ``Q`` is completed to square unitary blocks (plus identity
     blocks for the sectors of the first leg in which ``a`` vanishes, reference :4244-4262) and ``R`` padded with zero
@@ -3091,7 +3135,7 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
         raise ValueError("unknown mode " + repr(mode))
     a_labels = a._labels
     label_Q, label_R = inner_labels
-    piped_axes, a = a.as_completely_blocked()
+    piped_axes, a = a.as_completely_blocked() if _blocked is None else _blocked
     chinfo = a.chinfo
     qtotal_Q_given = qtotal_Q is not None
     qtotal_Q = chinfo.make_valid(qtotal_Q)
@@ -3123,7 +3167,7 @@ def qr(a, mode='reduced', inner_labels=[None, None], cutoff=None, pos_diag_R=Fal
         ns = a.legs[1].get_block_sizes()[qi_R].astype(np.int64)
         del order_q
     elif a.stored_blocks:
-        Q_arena, q_offs, R_arena, r_offs, ms, ns, ks = _qr_device(a)
+        Q_arena, q_offs, R_arena, r_offs, ms, ns, ks = _qr_device(a) if _device is None else _device      # (_device: qr_batched)
         q_offs_b, r_offs_b = q_offs[:-1].astype(np.int64), r_offs[:-1].astype(np.int64)
     else:
         ms = ns = ks = q_offs_b = r_offs_b = np.zeros(0, np.int64)

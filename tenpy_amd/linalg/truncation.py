@@ -227,14 +227,9 @@ def _qr_theta_Y0(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, ex
     return Y0
 
 
-def decompose_theta_qr_based(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase,
-                             use_eig_based_svd, trunc_params, compute_err, return_both_T):
-    """``theta`` [(vL.p0), (p1.vR)] ~= renormalization * T_Lc . diag(S) . T_Rc without an SVD of theta itself: two block
-    QRs give isometries A (left) and B (right) around a small bond matrix ``Xi``, which alone is decomposed (block SVD,
-    or ``_eig_based_svd``).  Same arguments and returned tuple ``(T_Lc, S, T_Rc, form, trunc_err, renormalization)`` as the
-    reference (truncation.py:533-711); everything is block GEMM / block QR on the device."""
-    want_both = bool(return_both_T or compute_err)
-
+def _decompose_qr_prepare(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase):
+    """First half of :func:`decompose_theta_qr_based`: the two block QRs -> isometries ``A_L``, ``B_R`` and the small bond matrix
+    ``Xi`` (reference truncation.py:611-640)."""
     def onto_right(mat, iso):        # mat . iso^dagger : [(vL.p0), (p1.vR)] -> [(vL.p0), vR]
         return npc.tensordot(mat, iso.conj(), ['(p1.vR)', '(p1*.vR*)']).ireplace_label('vL*', 'vR')
 
@@ -255,11 +250,12 @@ def decompose_theta_qr_based(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, mo
     else:                            # guess spans the right space
         A_L, _ = left_isometry(onto_right(theta, guess))
         B_R, Xi = right_isometry(onto_left(A_L, theta))
-    if use_eig_based_svd:            # only the factor on the side we move to comes out of the eigen-decomposition
-        U, S, Vd, _, renormalization = _eig_based_svd(Xi, need_U=move_right, need_Vd=not move_right,
-                                                      inner_labels=['vR', 'vL'], trunc_params=trunc_params)
-    else:
-        U, S, Vd, _, renormalization = svd_theta(Xi, trunc_params)
+    return A_L, B_R, Xi
+
+
+def _decompose_qr_finish(theta, A_L, B_R, Xi, U, S, Vd, renormalization, move_right, compute_err, return_both_T):
+    """Second half of :func:`decompose_theta_qr_based`: the factors of theta from the decomposed bond matrix (reference :641-711)."""
+    want_both = bool(return_both_T or compute_err)
 
     def left_factor():               # -> (tensor, canonical form)
         if U is not None:
@@ -292,3 +288,59 @@ def decompose_theta_qr_based(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, mo
     if T_Rc is not None:
         T_Rc.ireplace_label('(p1.vR)', '(p.vR)')
     return T_Lc, S, T_Rc, form, trunc_err, renormalization
+
+
+def decompose_theta_qr_based(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase,
+                             use_eig_based_svd, trunc_params, compute_err, return_both_T):
+    """``theta`` [(vL.p0), (p1.vR)] ~= renormalization * T_Lc . diag(S) . T_Rc without an SVD of theta itself: two block
+    QRs give isometries A (left) and B (right) around a small bond matrix ``Xi``, which alone is decomposed (block SVD,
+    or ``_eig_based_svd``).  Same arguments and returned tuple ``(T_Lc, S, T_Rc, form, trunc_err, renormalization)`` as the
+    reference (truncation.py:533-711); everything is block GEMM / block QR on the device."""
+    A_L, B_R, Xi = _decompose_qr_prepare(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase)
+    if use_eig_based_svd:            # only the factor on the side we move to comes out of the eigen-decomposition
+        U, S, Vd, _, renormalization = _eig_based_svd(Xi, need_U=move_right, need_Vd=not move_right,
+                                                      inner_labels=['vR', 'vL'], trunc_params=trunc_params)
+    else:
+        U, S, Vd, _, renormalization = svd_theta(Xi, trunc_params)
+    return _decompose_qr_finish(theta, A_L, B_R, Xi, U, S, Vd, renormalization, move_right, compute_err, return_both_T)
+
+
+def _decompose_qr_prepare_batched(items):
+    """:func:`_decompose_qr_prepare` for independent items ``(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand,
+    min_block_increase)`` with a common ``move_right``: both block QRs of all items in one batched device call each."""
+    move_right = items[0][4]
+    assert all(it[4] == move_right for it in items)
+    thetas = [it[3] for it in items]
+    guesses = [_qr_theta_Y0(*it) for it in items]
+
+    def onto_right(mat, iso):
+        return npc.tensordot(mat, iso.conj(), ['(p1.vR)', '(p1*.vR*)']).ireplace_label('vL*', 'vR')
+
+    def onto_left(iso, mat):
+        return npc.tensordot(iso.conj(), mat, ['(vL*.p0*)', '(vL.p0)']).ireplace_label('vR*', 'vL')
+
+    def left_isometries(mats):
+        return npc.qr_batched(mats, inner_labels=['vR', 'vL'])
+
+    def right_isometries(mats):
+        res = npc.qr_batched([m.itranspose(['(p1.vR)', 'vL']) for m in mats], inner_labels=['vL', 'vR'], inner_qconj=-1)
+        return [(q.itranspose(['vL', '(p1.vR)']), r.itranspose(['vL', 'vR'])) for q, r in res]
+
+    if move_right:
+        B_Rs = [b for b, _ in right_isometries([onto_left(g, t) for g, t in zip(guesses, thetas)])]
+        AX = left_isometries([onto_right(t, b) for t, b in zip(thetas, B_Rs)])
+        return [(A_L, B_R, Xi) for (A_L, Xi), B_R in zip(AX, B_Rs)]
+    A_Ls = [q for q, _ in left_isometries([onto_right(t, g) for t, g in zip(thetas, guesses)])]
+    BX = right_isometries([onto_left(A_L, t) for A_L, t in zip(A_Ls, thetas)])
+    return [(A_L, B_R, Xi) for A_L, (B_R, Xi) in zip(A_Ls, BX)]
+
+
+def decompose_theta_qr_based_batched(items, trunc_params, compute_err, return_both_T):
+    """:func:`decompose_theta_qr_based` (block SVD of the bond matrix) for several INDEPENDENT two-site wave functions -- the bonds of one
+    Trotter half-step -- with the two block QRs and the bond matrices of all of them in ONE batched device call each (``np_conserved.qr_batched``,
+    ``svd_theta_batched``); ``items`` = list of
+    ``(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase)``.  Same results item by item."""
+    prep = _decompose_qr_prepare_batched(items)
+    res = svd_theta_batched([p[2] for p in prep], trunc_params)
+    return [_decompose_qr_finish(it[3], A_L, B_R, Xi, U, S, Vd, renorm, it[4], compute_err, return_both_T)
+            for it, (A_L, B_R, Xi), (U, S, Vd, _, renorm) in zip(items, prep, res)]

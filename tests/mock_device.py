@@ -364,10 +364,12 @@ class MockLib:
     def tpa_qr_batch(self, code, jobs_p, n_jobs, a_p, q_p, r_p, stream):
         dt = _npdt(code)
         jobs = _host(jobs_p, (n_jobs, 8))
-        A, Q, R = REG.view(a_p, dt), REG.view(q_p, dt), REG.view(r_p, dt)
+        Q, R = REG.view(q_p, dt), REG.view(r_p, dt)
+        isz = np.dtype(dt).itemsize
         for a_off, m, n, q_off, r_off, _, _, _ in jobs:
             k = min(m, n)
-            q, r = np.linalg.qr(A[a_off:a_off + m * n].reshape(m, n), mode='reduced')
+            A = REG.view(a_p + int(a_off) * isz, dt)      # (np_conserved.qr_batched: the blocks of several arenas, offsets from one base address)
+            q, r = np.linalg.qr(A[:m * n].reshape(m, n), mode='reduced')
             Q[q_off:q_off + m * k] = q.reshape(-1)
             R[r_off:r_off + k * n] = r.reshape(-1)
         return 0

@@ -326,3 +326,30 @@ def test_svd_batched_equals_svd_per_matrix(backend):
             np.testing.assert_allclose(S, S1, rtol=0, atol=1e-13 * S1.max())
             rec = npc.tensordot(U.scale_axis(S, 'i'), VH, axes=['i', 'j'])
             np.testing.assert_allclose(rec.to_ndarray(), a.to_ndarray(), rtol=0, atol=1e-12 * S1.max())
+
+
+def test_qr_batched_equals_qr_per_matrix(backend):
+    """``qr_batched`` (one device call over the charge blocks of several independent matrices that stay in their own arenas: the
+    bonds of a half-step of the QR-based TEBD) returns per matrix what ``qr`` returns: same legs, qdata, factors."""
+    from tenpy_amd.linalg.charges import ChargeInfo, LegCharge
+    rng = np.random.RandomState(9)
+    ch = ChargeInfo([2])
+    for cplx in (False, True):
+        arrs = []
+        for k in range(4):
+            la = LegCharge.from_qflat(ch, rng.randint(0, 2, size=(40 + 9 * k, 1)), 1).bunch()[1]
+            lb = LegCharge.from_qflat(ch, rng.randint(0, 2, size=(18 + 5 * k, 1)), -1).bunch()[1]
+            f = (lambda sh: rng.standard_normal(sh) + 1.j * rng.standard_normal(sh)) if cplx else rng.standard_normal
+            arrs.append(npc.Array.from_func(f, [la, lb], dtype=np.complex128 if cplx else np.float64, qtotal=[k % 2]).iset_leg_labels(['x', 'y']))
+        for qconj in (+1, -1):
+            got = npc.qr_batched(arrs, inner_labels=['i', 'j'], inner_qconj=qconj)
+            for a, (Q, R) in zip(arrs, got):
+                Q1, R1 = npc.qr(a, inner_labels=['i', 'j'], inner_qconj=qconj)
+                Q.test_sanity()
+                R.test_sanity()
+                assert Q.get_leg_labels() == Q1.get_leg_labels() and R.get_leg_labels() == R1.get_leg_labels()
+                np.testing.assert_array_equal(Q._qdata, Q1._qdata)
+                np.testing.assert_array_equal(R._qdata, R1._qdata)
+                np.testing.assert_array_equal(Q.to_ndarray(), Q1.to_ndarray())
+                np.testing.assert_array_equal(R.to_ndarray(), R1.to_ndarray())
+                np.testing.assert_allclose(npc.tensordot(Q, R, axes=['i', 'j']).to_ndarray(), a.to_ndarray(), rtol=0, atol=1e-12)

@@ -37,17 +37,18 @@ def test_tebd_quench(backend, name, batch):
     assert psi.get_B(0, None).dtype == np.complex128
 
 
+@pytest.mark.parametrize("batch", [True, False])
 @pytest.mark.parametrize("name", ['tfi_quench_L10_parity', 'tfi_quench_L10_None'])
-def test_qr_tebd_quench(backend, name):
+def test_qr_tebd_quench(backend, name, batch):
     """QR-based TEBD (two tensordots + two block QRs + SVD of the small bond matrix) vs the reference's
-    QRBasedTEBDEngine on the same quench."""
+    QRBasedTEBDEngine on the same quench.  ``batch``: the bond matrices of a half-step in one batched block SVD (the default)."""
     from tenpy_amd.algorithms.tebd import QRBasedTEBDEngine
     rec = [r for r in golden('tebd.pkl') if r['name'] == name][0]
     L = rec['L']
     _, p = spin_half_leg(rec['conserve'])
     up = dict(rec['state_labels'])['up']
     psi = MPS.from_product_state([p] * L, [up] * L, dtype=np.complex128)
-    eng = QRBasedTEBDEngine(psi, rec['h_bond'], {'dt': rec['dt'], 'cbe_expand': 0.5,
+    eng = QRBasedTEBDEngine(psi, rec['h_bond'], {'dt': rec['dt'], 'cbe_expand': 0.5, 'batch_bonds': batch,
                                                  'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}})
     for step in range(len(rec['chi_qr'])):
         eng.evolve_step_order2()
