@@ -334,6 +334,7 @@ def run(argv=None, emit=True):
         tm.enabled = True
     n0 = 0 if is_tebd else len(eng.update_stats['E_total'])
     from tenpy_amd.linalg import _svd_warm as _sw
+    npc.svd_stats['max_block'] = 0          # (a running maximum: the other configurations of the extras run in this process too)
     svd_calls0, svd_sweeps0, warm0 = npc.svd_stats['calls'], npc.svd_stats['sweeps'], dict(_sw.stats)
     import ctypes as _ct
     _ref8 = (_ct.c_int64 * 8)()
