@@ -18,7 +18,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 from oracle import build_ref  # noqa: E402
 
-build_ref.load()
+# TPA_TEBD_ON_DEVICE=1: the SAME script with TeNPy's engines on the MI355X through the module form (install(fused=True)): what
+# `profiles/r04_module_form_tebd*.json` hold
+DEVICE = bool(os.environ.get('TPA_TEBD_ON_DEVICE'))
+if DEVICE:
+    sys.path.insert(0, build_ref.reference_root())
+    import tenpy_amd.install as ti
+    ti.install(fused=os.environ.get('TPA_TEBD_FUSED', '1') != '0')
+else:
+    build_ref.load()
 import numpy as np  # noqa: E402
 import tenpy  # noqa: E402
 import tenpy.linalg.np_conserved as npc  # noqa: E402
@@ -29,7 +37,7 @@ from tenpy.networks.mps import MPS  # noqa: E402
 from tenpy.tools import optimization  # noqa: E402
 import tebd_state  # noqa: E402
 
-assert optimization.have_cython_functions, "compiled _npc_helper not active"
+assert DEVICE or optimization.have_cython_functions, "compiled _npc_helper not active"
 optimization.set_level(3)
 chi = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -45,16 +53,27 @@ psi = MPS(sites, Bs, Ss, bc='finite', form='B')
 t_state = time.time() - t0
 print("state built in %.1f s, chi = %s" % (t_state, max(psi.chi)), flush=True)
 QR = os.environ.get('TPA_CPU_REF_ENGINE', 'svd') == 'qr'       # the like-for-like reference of `bench.py --config tebd1024 --qr`
+if DEVICE:
+    OUT = os.environ.get('TPA_CPU_REF_OUT') or os.path.join(ROOT, 'gpurun_out', 'r04_module_form_tebd%s.json' % ('_qr' if QR else ''))
 if QR:
-    OUT = os.environ.get('TPA_CPU_REF_OUT') or os.path.join(ROOT, 'profiles', 'r04_cpu_reference_tebd_qr.json')
+    if not DEVICE:
+        OUT = os.environ.get('TPA_CPU_REF_OUT') or os.path.join(ROOT, 'profiles', 'r04_cpu_reference_tebd_qr.json')
     eng = tebd.QRBasedTEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 1, 'compute_err': True, 'cbe_expand': 0.1,
                                           'use_eig_based_svd': False, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
 else:
     eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 1, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
 steps = []
+def _sync():
+    if DEVICE:
+        import torch
+        torch.cuda.synchronize()
+
+
 for k in range(n_steps):
+    _sync()
     t0 = time.time()
     eng.run()
+    _sync()
     dt = time.time() - t0
     S = np.asarray(psi.get_SL(L // 2))
     steps.append({"step": k + 1, "s": dt, "trunc_err_eps": float(sum(e.eps for e in eng._trunc_err_bonds)),
@@ -68,6 +87,7 @@ for k in range(n_steps):
            "what": "TeNPy %s TEBD engine (order 2, dt 0.05, one step per run(), svd_min 1e-12) on the synthetic state of bench.py --config tebd1024: "
                    "TFIChain L=%d J=1 g=1.5 conserve=parity, random right-canonical MPS chi=%d complex128 seed 1 (scripts/tebd_state.py)"
                    % (tenpy.__version__, L, chi),
+           "where": ("MI355X, module form: tenpy_amd.install.install(fused=%s), TeNPy's engine unmodified" % (os.environ.get('TPA_TEBD_FUSED', '1') != '0')) if DEVICE else "host cores",
            "cores": os.cpu_count(), "blas_threads": os.environ.get('OMP_NUM_THREADS', 'default (all cores)'),
            "helper": "compiled _npc_helper (oracle/_ref), scipy.linalg.cython_blas", "numpy": np.__version__, "scipy": scipy.__version__,
            "bond_updates_per_step": 3 * (L // 2) - 1 if L % 2 == 0 else None, "L": L, "chi": chi, "steps": steps,

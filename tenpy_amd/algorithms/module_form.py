@@ -121,3 +121,84 @@ def hinted_mixed_svd(ref_mixed_svd):
     mixed_svd.__doc__ = ref_mixed_svd.__doc__
     mixed_svd._tpa_wrapped = True
     return mixed_svd
+
+
+def batched_tebd_evolve_step(ref_tebd):
+    """Fused caller for the reference's ``TEBDEngine.evolve_step`` (algorithms/tebd.py:374-414): the bonds of one half-step do not
+    share a site, so their decompositions go to the device as ONE batched call each (``np_conserved.svd_batched`` for
+    ``TEBDEngine.update_bond``, tebd.py:416-483; ``qr_batched`` + ``svd_batched`` for ``QRBasedTEBDEngine.update_bond``, :685-738).
+    The per-bond statements before and after the decomposition are the reference's, in the reference's order; engines whose
+    ``update_bond`` is not one of those two (subclasses, ``use_eig_based_svd``), and everything else, run the reference's loop."""
+    import numpy as np
+    from ..linalg import truncation as dev_trunc
+    ref_evolve_step = ref_tebd.TEBDEngine.evolve_step
+    ref_update = ref_tebd.TEBDEngine.update_bond
+    ref_update_qr = ref_tebd.QRBasedTEBDEngine.update_bond
+    TruncationError = ref_tebd.TruncationError
+
+    def evolve_step(self, U_idx_dt, odd):
+        upd = type(self).update_bond
+        qr_based = upd is ref_update_qr
+        if not (upd is ref_update or qr_based) or not getattr(self.psi, 'finite', False) \
+                or (qr_based and self.options.get('use_eig_based_svd', False, bool)):
+            return ref_evolve_step(self, U_idx_dt, odd)
+        Us = self._U[U_idx_dt]
+        bonds = [int(i) for i in np.arange(int(odd) % 2, self.psi.L, 2) if Us[i] is not None]
+        if len(bonds) < 2:
+            return ref_evolve_step(self, U_idx_dt, odd)
+        psi = self.psi
+        Cs, thetas, extra = [], [], []
+        for i in bonds:
+            i0, i1 = i - 1, i
+            C = psi.get_theta(i0, n=2, formL=0.0)
+            C = npc.tensordot(Us[i], C, axes=(['p0*', 'p1*'], ['p0', 'p1']))
+            C.itranspose(['vL', 'p0', 'p1', 'vR'])
+            theta = C.scale_axis(psi.get_SL(i0), 'vL')
+            theta = theta.combine_legs([('vL', 'p0'), ('p1', 'vR')], qconj=[+1, -1])
+            Cs.append(C)
+            thetas.append(theta)
+            if qr_based:
+                old_B_L, old_B_R = psi.get_B(i0, 'B'), psi.get_B(i1, 'B')
+                extra.append((old_B_L.qtotal, old_B_R.qtotal, old_B_R.get_leg('vL'), theta, False, self._expansion_rate(i),
+                              self.options.get('cbe_min_block_increase', 1, int)))
+            else:
+                extra.append([psi.get_B(i0, None).qtotal, None])
+        total = TruncationError()
+        if qr_based:
+            compute_err = self.options.get('compute_err', True, bool)
+            res = dev_trunc.decompose_theta_qr_based_batched(extra, self.trunc_params, compute_err, False)
+            for i, C, theta, (_, S, B_R, form, err, renormalize) in zip(bonds, Cs, thetas, res):
+                i0, i1 = i - 1, i
+                assert form[1] == 'B'
+                err = TruncationError(err.eps, err.ov)
+                B_L = npc.tensordot(C.combine_legs(('p1', 'vR'), pipes=theta.legs[1]), B_R.conj(), axes=[['(p1.vR)'], ['(p*.vR*)']]) / renormalize
+                B_L.ireplace_labels(['p0', 'vL*'], ['p', 'vR'])
+                B_R = B_R.split_legs(1)
+                psi.norm *= renormalize
+                psi.set_B(i0, B_L, form='B')
+                psi.set_SL(i1, S)
+                psi.set_B(i1, B_R, form='B')
+                self._trunc_err_bonds[i] = self._trunc_err_bonds[i] + err
+                total += err
+        else:
+            npc.svd_engine_floor = True
+            res = dev_trunc.svd_theta_batched(thetas, self.trunc_params, extra, inner_labels=['vR', 'vL'])
+            for i, C, theta, (U, S, V, err, renormalize) in zip(bonds, Cs, thetas, res):
+                i0, i1 = i - 1, i
+                err = TruncationError(err.eps, err.ov)
+                B_R = V.split_legs(1).ireplace_label('p1', 'p')
+                B_L = npc.tensordot(C.combine_legs(('p1', 'vR'), pipes=theta.legs[1]), V.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
+                B_L.ireplace_labels(['vL*', 'p0'], ['vR', 'p'])
+                B_L /= renormalize
+                psi.norm *= renormalize
+                psi.set_SR(i0, S)
+                psi.set_B(i0, B_L, form='B')
+                psi.set_B(i1, B_R, form='B')
+                self._trunc_err_bonds[i] = self._trunc_err_bonds[i] + err
+                total += err
+        self._update_index = None
+        return total
+
+    evolve_step.__doc__ = ref_evolve_step.__doc__
+    evolve_step._tpa_wrapped = True
+    return evolve_step

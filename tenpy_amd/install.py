@@ -101,6 +101,8 @@ def use_fused_callers():
       ``tenpy_amd/algorithms/module_form.py`` (cached plans, fused ``LHeff`` build; ``combine=False``: factored matvec), which
       hands bonds it does not cover back to the reference's class;
     * ``TwoSiteDMRGEngine.mixed_svd`` (``dmrg.py:876``) is wrapped to pass the bond index to the block SVD (warm start).
+    * ``TEBDEngine.evolve_step`` (``tebd.py:374``; inherited by ``QRBasedTEBDEngine``) -> the bonds of a half-step decomposed in one
+      batched device call (``module_form.batched_tebd_evolve_step``; the per-bond statements stay the reference's).
     """
     import tenpy.algorithms.dmrg as ref_dmrg
     import tenpy.algorithms.mps_common as ref_mc
@@ -116,3 +118,6 @@ def use_fused_callers():
         ref_dmrg.TwoSiteDMRGEngine.EffectiveH = dev_cls
     if not getattr(ref_dmrg.TwoSiteDMRGEngine.mixed_svd, '_tpa_wrapped', False):
         ref_dmrg.TwoSiteDMRGEngine.mixed_svd = module_form.hinted_mixed_svd(ref_dmrg.TwoSiteDMRGEngine.mixed_svd)
+    import tenpy.algorithms.tebd as ref_tebd
+    if not getattr(ref_tebd.TEBDEngine.evolve_step, '_tpa_wrapped', False):
+        ref_tebd.TEBDEngine.evolve_step = module_form.batched_tebd_evolve_step(ref_tebd)

@@ -25,7 +25,7 @@ def _activate():
         import mock_device
         mock_device.install(_Setter)
     import tenpy_amd.install as ti
-    ti.install()
+    ti.install(fused=bool(os.environ.get('TPA_REFSUITE_FUSED')))      # fused callers: test_reference_suite.py::test_reference_tebd_with_fused_callers
     import tenpy
     import tenpy_amd.linalg.np_conserved as mirror
     assert tenpy.linalg.np_conserved is mirror, "import hook not active"

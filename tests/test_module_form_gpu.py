@@ -56,9 +56,21 @@ print('RESULT ' + json.dumps({'E': E, 'S': [float(x) for x in psi.get_SL(L // 2)
 TEBD = r"""
 import json, sys, warnings
 warnings.simplefilter('ignore')
-DEVICE = %(device)r
+DEVICE, FUSED, QR = %(device)r, %(fused)r, %(qr)r
+calls = {'svd_batched': 0, 'qr_batched': 0}
 if DEVICE:
     import refsuite_plugin
+    if FUSED:                                 # TEBDEngine.evolve_step -> one batched decomposition per half-step
+        import tenpy_amd.install as ti
+        ti.use_fused_callers()
+        import tenpy_amd.linalg.np_conserved as dnpc
+        for name in calls:
+            def wrap(f, name=name):
+                def g(*a, **k):
+                    calls[name] += 1
+                    return f(*a, **k)
+                return g
+            setattr(dnpc, name, wrap(getattr(dnpc, name)))
 import numpy as np
 from tenpy.algorithms import tebd
 from tenpy.models.tf_ising import TFIChain
@@ -66,12 +78,15 @@ from tenpy.networks.mps import MPS
 L = 16
 M = TFIChain({'L': L, 'J': 1., 'g': 1.5, 'bc_MPS': 'finite', 'conserve': 'parity', 'sort_charge': True})
 psi = MPS.from_product_state(M.lat.mps_sites(), ['up'] * L, bc='finite')
-eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 4, 'trunc_params': {'chi_max': 40, 'svd_min': 1e-12}})
+if QR:
+    eng = tebd.QRBasedTEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 4, 'cbe_expand': 0.5, 'trunc_params': {'chi_max': 40, 'svd_min': 1e-12}})
+else:
+    eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 4, 'trunc_params': {'chi_max': 40, 'svd_min': 1e-12}})
 out = []
 for k in range(5):
     eng.run()
     out.append([float(x) for x in psi.entanglement_entropy()])
-print('RESULT ' + json.dumps({'S': out}))
+print('RESULT ' + json.dumps({'S': out, 'calls': calls, 'trunc_err': float(eng.trunc_err.eps)}))
 """
 
 
@@ -106,9 +121,17 @@ def test_tenpy_dmrg_engine_with_mixer_on_the_device(where, combine):
 
 
 @pytest.mark.parametrize("where", WHERE)
-def test_tenpy_tebd_engine_on_the_device(where):
+@pytest.mark.parametrize("qr", [False, True])
+@pytest.mark.parametrize("fused", [False, True])
+def test_tenpy_tebd_engine_on_the_device(where, fused, qr):
+    """The reference's own ``TEBDEngine`` / ``QRBasedTEBDEngine`` on the device mirror against the plain reference in a second process;
+    ``fused``: ``install.use_fused_callers`` rebinds ``evolve_step`` to the batched form (all bonds of a half-step in one device call)."""
     _needs(where)
-    got = _run(TEBD % {'device': True}, True)
-    ref = _run(TEBD % {'device': False}, False)
+    got = _run(TEBD % {'device': True, 'fused': fused, 'qr': qr}, True)
+    ref = _run(TEBD % {'device': False, 'fused': False, 'qr': qr}, False)
     import numpy as np
     np.testing.assert_allclose(got['S'], ref['S'], rtol=0, atol=1e-10)
+    assert abs(got['trunc_err'] - ref['trunc_err']) <= 1e-12 + 1e-8 * abs(ref['trunc_err'])
+    if fused:
+        assert got['calls']['svd_batched'] >= 40, got['calls']          # one per half-step (order 2 merges neighbouring half-steps: 5 runs x 9)
+        assert (got['calls']['qr_batched'] > 0) == qr

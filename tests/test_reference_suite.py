@@ -39,8 +39,9 @@ def _needs(where):
         pytest.skip("a GPU is visible: the 'gpu' variant of this case runs instead")
 
 
-def run_reference_tests(args, timeout=3000, plugin='refsuite_plugin'):
+def run_reference_tests(args, timeout=3000, plugin='refsuite_plugin', extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env['PYTHONPATH'] = os.pathsep.join([HERE, ROOT, REF, env.get('PYTHONPATH', '')])
     cmd = [sys.executable, '-m', 'pytest', '-p', plugin, '-p', 'no:cacheprovider', '-q'] + ([] if '-n' in args else ['-x']) + list(args)
     res = subprocess.run(cmd, cwd=os.path.join(REF, 'tests'), env=env, capture_output=True, text=True, timeout=timeout)
@@ -74,6 +75,15 @@ def test_reference_linalg_tests_on_mirror(args, where):
         # pinned by tests/test_eig_svd.py[gpu] and tests/test_qr_theta_golden.py[gpu]; on the device the SVD flavour of the case runs.
         args = ['test_truncation.py', '-k', 'truncate or (decompose and 45-True-parity-False)']
     out = run_reference_tests(args)
+    assert ' passed' in out and ' failed' not in out
+
+
+@pytest.mark.parametrize("where", WHERE)
+def test_reference_tebd_with_fused_callers(where):
+    """The reference's ``test_tebd.py`` (finite cases: standard and QR-based engines, real and imaginary time) with
+    ``install(fused=True)``: ``TEBDEngine.evolve_step`` is the batched form of ``module_form.batched_tebd_evolve_step``."""
+    _needs(where)
+    out = run_reference_tests(['test_tebd.py', '-k', 'finite'], extra_env={'TPA_REFSUITE_FUSED': '1'})
     assert ' passed' in out and ' failed' not in out
 
 
