@@ -218,7 +218,10 @@ int tpa_svd_set_rank_cap(int cap);
 
 /* ---- K6: batched Householder QR (np.linalg.qr per block, np_conserved.py:4190) ----------
  * jobs : int64[n_jobs][8] = {a_off, m, n, q_off, r_off, 0,0,0} (HOST); reduced mode:
- *   Q_b m x k row-major, R_b k x n row-major, k = min(m,n).  A not overwritten. */
+ *   Q_b m x k row-major, R_b k x n row-major, k = min(m,n).  A not overwritten.
+ *   a_off is a signed element offset from a_base: the blocks of SEVERAL arenas may be factorised in one call by taking the
+ *   lowest arena address as a_base (np_conserved.qr_batched: the bonds of one half-step of the QR-based TEBD, reference
+ *   algorithms/tebd.py:374-414 / truncation.py:611-640). */
 int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base,
                  void *r_base, void *stream);
 /* Test hook: bit 0 = always use the one-workgroup Householder kernel (default: blocked compact-WY QR on the matrix

@@ -689,8 +689,13 @@ class LegPipe(LegCharge):
         never modified after construction (``conj`` etc. make new ones)."""
         k = self.__dict__.get('_ckey')
         if k is None or k[0] is not self.q_map:
-            k = self.__dict__['_ckey'] = (self.q_map, hash((self.q_map.tobytes(), self.q_map_slices.tobytes(), self.slices.tobytes(),
-                                                             int(self.qconj), tuple(self.subqshape), tuple(self.subshape))))
+            from hashlib import blake2b
+            h = blake2b(digest_size=16)      # (128-bit digest instead of Python's 64-bit hash(): the key is the plan's only identity)
+            for part in (np.ascontiguousarray(self.q_map), np.ascontiguousarray(self.q_map_slices), np.ascontiguousarray(self.slices),
+                         np.array((int(self.qconj),) + tuple(self.subqshape) + tuple(self.subshape), dtype=np.int64)):
+                h.update(np.array(part.shape, dtype=np.int64).tobytes())
+                h.update(part.tobytes())
+            k = self.__dict__['_ckey'] = (self.q_map, h.digest())
         return k[1]
 
     def _fuse(self, sort, bunch):

@@ -21,6 +21,7 @@ from collections import OrderedDict
 import os
 
 import numpy as np
+from hashlib import blake2b as _blake2b
 
 from . import _device as dev
 from .charges import QTYPE, ChargeInfo, DipolarChargeInfo, LegCharge, LegPipe, _find_row_differences, _partial_qtotal
@@ -179,8 +180,16 @@ class Array:
     def _struct_key(self):
         """Hashable key of everything a contraction plan depends on (blocks, offsets, leg block sizes)."""
         if self._skey is None:
-            legs = tuple((leg.ind_len, leg.block_number, leg.slices.tobytes()) for leg in self.legs)
-            self._skey = hash((self._qdata.tobytes(), self._offsets.tobytes(), legs, self.rank))
+            # a 128-bit digest of the bytes, not Python's 64-bit hash(): cached plans are replayed on a key hit without a second look
+            # (ADVICE r3), so the identity has to be collision-free for all practical purposes
+            h = _blake2b(digest_size=16)
+            h.update(np.array([self.rank, len(self._qdata)], dtype=np.int64).tobytes())
+            h.update(np.ascontiguousarray(self._qdata).tobytes())
+            h.update(np.ascontiguousarray(self._offsets).tobytes())
+            for leg in self.legs:
+                h.update(np.array([leg.ind_len, leg.block_number], dtype=np.int64).tobytes())
+                h.update(np.ascontiguousarray(leg.slices).tobytes())
+            self._skey = h.digest()
         return self._skey
 
     def _same_structure(self, other):
@@ -1398,7 +1407,7 @@ class Array:
         res._skey = None
         if self.stored_blocks == 0:
             return res
-        pkey = ('proj', self._struct_key(), int(axis), hash(np.ascontiguousarray(mask).tobytes()))
+        pkey = ('proj', self._struct_key(), int(axis), _blake2b(np.ascontiguousarray(mask).tobytes(), digest_size=16).digest())
         plan = _reshape_plan_get(pkey)
         if plan is not None:
             res._adopt_blocks(plan[0], plan[1], dev.empty(plan[2], self.dtype), self._qdata_sorted)

@@ -409,10 +409,12 @@ def install(monkeypatch):
         return REG.add(torch.from_numpy(np.array(arr, copy=True, order='C')))
 
     def reduction_buffers():
-        if 'mock' not in dev._scratch:
-            dev._scratch['mock'] = (REG.add(torch.zeros(4, dtype=torch.float64)),
-                                    REG.add(torch.zeros(4096, dtype=torch.float64)))
-        return dev._scratch['mock']
+        import threading
+        key = ('mock', threading.get_ident())      # per thread, like _device.reduction_buffers (tests/test_threads.py)
+        if key not in dev._scratch:
+            dev._scratch[key] = (REG.add(torch.zeros(4, dtype=torch.float64)),
+                                 REG.add(torch.zeros(4096, dtype=torch.float64)))
+        return dev._scratch[key]
 
     class _T:
         """torch facade: allocation helpers register their tensors."""
