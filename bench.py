@@ -262,6 +262,10 @@ def build_tebd(args):
         return QRBasedTEBDEngine(psi, h_bonds, {'dt': 0.05, 'compute_err': True, 'cbe_expand': 0.1, 'use_eig_based_svd': bool(args.eig_svd),
                                                 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
     opts = {'dt': 0.05, 'compute_err': False, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}}
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not os.environ.get('TPA_TEBD_REPLICAS'):
+        # N > 1: the bonds of every half-step dealt over the ranks, new tensors broadcast from their owners (algorithms/sharded.py)
+        from tenpy_amd.algorithms.sharded import ShardedTEBDEngine
+        return ShardedTEBDEngine(psi, h_bonds, opts)
     if os.environ.get('TPA_TEBD_BATCH'):          # measurement knob: k bonds of a half-step per batched SVD call (tebd.py: update_bonds_batched)
         opts['batch_bonds'] = int(os.environ['TPA_TEBD_BATCH'])
     return TEBDEngine(psi, h_bonds, opts)
@@ -420,8 +424,11 @@ def run(argv=None, emit=True):
                                             "two-site DMRG sweep, Lanczos N=%d per bond, svd_min=1e-14, no mixer, combine=True "
                                             "interface (theta fused for the SVD)" % args.lanczos_N), n_upd),
                           "name": args.config,
-                          "parallelism": "1 GPU" if world == 1 else "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge "
-                                                                    "blocks distributed (LPT + all-gather), env update replicated" % world},
+                          "parallelism": "1 GPU" if world == 1 else
+                          ("bonds of every half-step dealt over %d GPUs, one broadcast per new tensor" % world if (is_tebd and not args.qr) else
+                           "%d replicas" % world if is_tebd else
+                           "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge blocks distributed (LPT + all-gather), "
+                           "env update replicated" % world)},
                "prep_s": t_prep, "roofline": roof_svd, "roofline_gemm": roof_gemm, "energy_err": None}
         if roof_eigh is not None:
             out["roofline_eigh"] = roof_eigh

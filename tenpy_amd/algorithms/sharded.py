@@ -26,7 +26,7 @@ from ..linalg import _device as dev
 from ..linalg import np_conserved as npc
 from .mps_common import TwoSiteH
 
-__all__ = ['ShardedTwoSiteH', 'row_partition', 'restrict_plan_rows', 'lanczos_row_panels', 'RowPanelOps']
+__all__ = ['ShardedTwoSiteH', 'row_partition', 'restrict_plan_rows', 'lanczos_row_panels', 'RowPanelOps', 'ShardedTEBDEngine']
 
 
 def _dist():
@@ -586,3 +586,72 @@ def lanczos_row_panels(H, theta0, options):
     res = ops.gather(psi)
     res.iset_leg_labels(list(theta0.get_leg_labels()) if theta0.rank == res.rank else list(res.get_leg_labels()))
     return E0, res, N
+
+
+# ---- TEBD: the bonds of a half-step over the ranks (round 4) ---------------------------------------------------------------------------
+from .tebd import TEBDEngine  # noqa: E402
+
+
+def _broadcast_array(arr, src, group):
+    """One npc Array from rank ``src`` to every rank: the integer bookkeeping (legs, ``_qdata``, offsets, labels, ``qtotal``) as a
+    pickled shell without data, the arena as ONE device-to-device broadcast (RCCL; ``gloo`` in the CPU tests)."""
+    dist = _dist()
+    rank = dist.get_rank(group)
+    box = [None]
+    if rank == src:
+        shell = arr.copy(deep=False)
+        n = 0 if arr._arena is None else int(arr._arena.numel())
+        shell._arena = None
+        box[0] = (shell, n)
+    dist.broadcast_object_list(box, src=src, group=group)
+    shell, n = box[0]
+    if rank == src:
+        arena = arr._arena
+    else:
+        arena = dev.empty(n, shell.dtype) if n else None
+    if n:
+        t = arena
+        import torch
+        dist.broadcast(torch.view_as_real(t) if t.is_complex() else t, src=src, group=group)
+    if rank == src:
+        return arr
+    shell._arena = arena
+    return shell
+
+
+class ShardedTEBDEngine(TEBDEngine):
+    """Order-2 TEBD with the bonds of every half-step dealt over the ranks (the one workload of the path that shards
+    without an Amdahl wall: reference ``algorithms/tebd.py:374-414`` loops over independent bonds).  Rank r decomposes bonds
+    r, r + N, ... of the half-step in ONE batched device call (``TEBDEngine._decompose_bonds``), then every new ``B_L``, ``B_R`` and the
+    Schmidt values travel once from their owner to all ranks (one broadcast per tensor; the deterministic kernels make the state
+    bit-identical everywhere) and are committed in bond order, so norms and truncation errors accumulate in the same order as on
+    one GPU."""
+
+    def __init__(self, psi, h_bonds_dense, options, group=None):
+        super().__init__(psi, h_bonds_dense, options)
+        dist = _dist()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def update_bonds_batched(self, bonds, U):
+        dist = _dist()
+        bonds = list(bonds)
+        mine = bonds[self.rank::self.world]
+        local = {r[0]: r for r in self._decompose_bonds(mine, U)}
+        results = []
+        for k, i in enumerate(bonds):
+            src = k % self.world
+            r = local.get(i)
+            head = [None]
+            if self.rank == src:
+                head[0] = (np.asarray(r[1]), float(r[4]), r[5])
+            dist.broadcast_object_list(head, src=src, group=self.group)       # Schmidt values, renormalisation, truncation error (host data)
+            S, renorm, err = head[0]
+            B_L = _broadcast_array(r[2] if r is not None else None, src, self.group)
+            B_R = _broadcast_array(r[3] if r is not None else None, src, self.group)
+            results.append((i, S, B_L, B_R, renorm, err))
+        self._commit_bonds(results)
+
+    def evolve_step_order2(self):
+        self.options['batch_bonds'] = True        # the sharding IS the batching: whole half-steps
+        super().evolve_step_order2()

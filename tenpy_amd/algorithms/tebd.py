@@ -82,6 +82,12 @@ class TEBDEngine:
     batch_bonds_default = True
 
     def update_bonds_batched(self, bonds, U):
+        self._commit_bonds(self._decompose_bonds(bonds, U))
+
+    def _decompose_bonds(self, bonds, U):
+        """New tensors of the given (independent) bonds from the CURRENT state, nothing written back:
+        ``[(i, S, B_L, B_R, renormalization, trunc_err), ...]`` (``algorithms/sharded.ShardedTEBDEngine`` deals the bonds of a
+        half-step over the ranks with this)."""
         psi = self.psi
         Cs, thetas, qLRs = [], [], []
         for i in bonds:
@@ -94,14 +100,23 @@ class TEBDEngine:
             Cs.append(C)
             thetas.append(theta)
             qLRs.append([psi.get_B(i0, None).qtotal, None])
+        if not bonds:
+            return []
         npc.svd_engine_floor = True
         res = svd_theta_batched(thetas, self.trunc_params, qLRs, inner_labels=['vR', 'vL'])
+        out = []
         for i, C, theta, (Um, S, V, err, renorm) in zip(bonds, Cs, thetas, res):
-            i0, i1 = i - 1, i
             B_R = V.split_legs(1).ireplace_label('p1', 'p')
             B_L = npc.tensordot(C.combine_legs(('p1', 'vR'), pipes=theta.legs[1]), V.conj(), axes=['(p1.vR)', '(p1*.vR*)'])
             B_L.ireplace_labels(['vL*', 'p0'], ['vR', 'p'])
             B_L.iscale_prefactor(1. / renorm)
+            out.append((i, S, B_L, B_R, renorm, err))
+        return out
+
+    def _commit_bonds(self, results):
+        psi = self.psi
+        for i, S, B_L, B_R, renorm, err in results:
+            i0, i1 = i - 1, i
             self.norm *= renorm
             psi.set_SR(i0, S)
             psi.set_B(i0, B_L, form='B')

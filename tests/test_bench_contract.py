@@ -63,7 +63,7 @@ def _bench_worker(rank, world, port, ret):
         import torch
         mp.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
         mp.setattr(torch.cuda, 'set_device', lambda *a, **k: None)
-        sys.argv = ['bench.py', '--gpus', str(world), '--L', '12', '--chi', '16', '--steps', '1', '--warmup', '1']
+        sys.argv = ['bench.py', '--gpus', str(world), '--L', '12', '--chi', '16', '--steps', '1', '--warmup', '1'] + os.environ.get('TPA_TEST_BENCH_ARGS', '').split()
         import bench
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
@@ -91,6 +91,23 @@ def test_bench_two_ranks_gloo():
     assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and 'cpu_baseline' not in out
     assert 'sharded' in out['config']['parallelism'] and out['value'] > 0
     assert abs(out['E'] - (-5.142090632841)) < 1e-6
+
+
+def test_bench_two_ranks_gloo_tebd(monkeypatch):
+    """``bench.py --config tebd1024 --gpus 2`` (tiny chain, emulated device): the bond-sharded TEBD engine under the bench's N > 1
+    control flow; the line reports the state every rank holds."""
+    import os
+    import torch.multiprocessing as tmp
+    monkeypatch.setenv('TPA_TEST_BENCH_ARGS', '--config tebd1024 --no-cpu-baseline')
+    world = 2
+    port = 29300 + (os.getpid() % 200)
+    mgr = tmp.Manager()
+    ret = mgr.dict()
+    tmp.spawn(_bench_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert not any(str(ret.get(r, 'FAIL')).startswith('FAIL') for r in range(world)), dict(ret)
+    out = json.loads([l for l in ret[0].splitlines() if l.strip()][0])
+    assert out['n_gpus'] == 2 and out['unit'] == 's/step' and 'dealt over 2 GPUs' in out['config']['parallelism']
+    assert out['S_mid_entropy'] > 0 and out['value'] > 0
 
 
 def test_smoke_runs_on_the_emulated_device(monkeypatch, capsys):

@@ -136,6 +136,65 @@ def test_sharded_matvec_gloo_world2():
     assert all(ret.get(r) == 'ok' for r in range(world)), dict(ret)
 
 
+def _tebd_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from _pytest.monkeypatch import MonkeyPatch
+        import mock_device
+        mp = MonkeyPatch()
+        mock_device.install(mp)
+        from helpers import golden
+        from tenpy_amd.algorithms.sharded import ShardedTEBDEngine
+        from tenpy_amd.algorithms.tebd import TEBDEngine
+        from tenpy_amd.models.spin_chains import spin_half_leg
+        from tenpy_amd.networks.mps import MPS
+        rec = [r for r in golden('tebd.pkl') if r['name'] == 'tfi_quench_L10_parity'][0]
+        L = rec['L']
+        _, p = spin_half_leg(rec['conserve'])
+        up = dict(rec['state_labels'])['up']
+        opts = {'dt': rec['dt'], 'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}}
+        psi_s = MPS.from_product_state([p] * L, [up] * L, dtype=np.complex128)
+        psi_r = MPS.from_product_state([p] * L, [up] * L, dtype=np.complex128)
+        eng_s, eng_r = ShardedTEBDEngine(psi_s, rec['h_bond'], dict(opts)), TEBDEngine(psi_r, rec['h_bond'], dict(opts))
+        calls = [0]
+        orig = eng_s._decompose_bonds
+        eng_s._decompose_bonds = lambda bonds, U: (calls.__setitem__(0, calls[0] + len(bonds)), orig(bonds, U))[1]
+        for step in range(6):
+            eng_s.evolve_step_order2()
+            eng_r.evolve_step_order2()
+            np.testing.assert_array_equal(psi_s.entanglement_entropy(), psi_r.entanglement_entropy())     # bit-identical on every rank
+            assert eng_s.norm == eng_r.norm and eng_s.trunc_err.eps == eng_r.trunc_err.eps
+        for i in range(L):
+            np.testing.assert_array_equal(psi_s.get_B(i, 'B').to_ndarray(), psi_r.get_B(i, 'B').to_ndarray())
+        # every rank decomposed only its share: 6 steps x (5 + 4 + 5) bonds, dealt r, r + N, ...
+        per_step = sum(len(list(range(1, L))[q::2][rank::world]) for q in (0, 1, 0))
+        assert calls[0] == 6 * per_step, (calls[0], per_step)
+        ret[rank] = 'ok'
+    except Exception:  # pragma: no cover
+        import traceback
+        ret[rank] = 'FAIL: ' + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_tebd_gloo_world2():
+    """Bond-sharded TEBD (``algorithms/sharded.ShardedTEBDEngine``): the bonds of every half-step dealt over 2 ``gloo`` ranks, tensors
+    broadcast from their owners -- the state on every rank bit-identical to the single-process engine, each rank decomposing half of
+    the bonds."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29700 + (os.getpid() % 1000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tebd_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) == 'ok' for r in range(world)), dict(ret)
+
+
 def test_row_partition_balanced():
     sys.path.insert(0, ROOT)
     from tenpy_amd.algorithms.sharded import row_partition
