@@ -298,8 +298,23 @@ extern "C" int tpa_gemm_chain(int dtype, int cfg, const int64_t *tasks_dev, cons
     if (n_tiles <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == TPA_F64) {
-        if (cfg == 1 && (g_large_variant & 2))
+        if (cfg == 1 && (g_large_variant & 4))       // one wavefront owns the whole 64 x 64 tile (4 x 4 MFMA tiles: 0.5 LDS reads per MFMA)
+            launch<false, 64, 64, 4, 4, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (cfg == 1 && (g_large_variant & 8))  // two wavefronts, 64 x 32 each (4 x 2: 0.75 reads per MFMA)
+            launch<false, 64, 64, 4, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (cfg == 1 && (g_large_variant & 16))  // eight wavefronts, 16 x 32 each (1 x 2: 1.5 reads per MFMA, twice the waves per tile)
+            launch<false, 64, 64, 1, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (cfg == 1 && (g_large_variant & 32))  // sixteen wavefronts, one MFMA tile each
+            launch<false, 64, 64, 1, 1, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (cfg == 1 && (g_large_variant & 2))
             launch<false, 64, 64, 2, 2, 32>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+        else if (cfg == 1 && n_tiles <= 512 && !(g_large_variant & 64))
+            // few tiles (chi <= 512, ramp sweeps, edge bonds): every tile is resident at once and the launch lasts as long as ONE tile's
+            // chain -- eight wavefronts per tile (16 x 32 each) halve that chain.  Measured (scripts/gemm_bench.py): matvec at chi = 512
+            // 6.9 -> 8.0 TFLOP/s (step 2, 69 tiles: 0.089 -> 0.075 ms), no difference at chi = 2048 (831 / 4005 tiles).  The opposite
+            // direction -- ONE wavefront per 64 x 64 tile (4 x 4 MFMA tiles, half the LDS reads per MFMA) or two (4 x 2) -- is slower
+            // everywhere: 24.6 / 30.8 instead of 38.7 TFLOP/s at chi = 2048: the tile's chain, not the LDS bandwidth, is the limit.
+            launch<false, 64, 64, 1, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else if (cfg == 1)
             launch<false, 64, 64, 2, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else if (g_large_variant & 1)
