@@ -13,6 +13,8 @@
 * ``hinted_mixed_svd(ref_mixed_svd)`` wraps ``TwoSiteDMRGEngine.mixed_svd`` (``dmrg.py:876``) to tell the block SVD which
   bond it decomposes (``np_conserved.svd_hint``), which enables the warm start of ``linalg/_svd_warm.py``.
 """
+import os
+
 import numpy as np
 
 from ..linalg import np_conserved as npc
@@ -147,6 +149,18 @@ def batched_tebd_evolve_step(ref_tebd):
         if len(bonds) < 2:
             return ref_evolve_step(self, U_idx_dt, odd)
         psi = self.psi
+        # groups of bonds whose work areas fit the device together (algorithms/tebd.batch_group_size: ~24x the dense theta each)
+        cap = int(float(os.environ.get('TPA_TEBD_BATCH_GB', '96')) * 2**30)
+        worst = max(24 * 16 * (psi.sites[i - 1].dim * len(psi.get_SL(i - 1))) * (psi.sites[i].dim * len(psi.get_SR(i))) for i in bonds)
+        group = int(max(1, min(len(bonds), cap // max(worst, 1))))
+        total = TruncationError()
+        for g0 in range(0, len(bonds), group):
+            total += _half_step_group(self, bonds[g0:g0 + group], Us, qr_based)
+        self._update_index = None
+        return total
+
+    def _half_step_group(self, bonds, Us, qr_based):
+        psi = self.psi
         Cs, thetas, extra = [], [], []
         for i in bonds:
             i0, i1 = i - 1, i
@@ -196,7 +210,6 @@ def batched_tebd_evolve_step(ref_tebd):
                 psi.set_B(i1, B_R, form='B')
                 self._trunc_err_bonds[i] = self._trunc_err_bonds[i] + err
                 total += err
-        self._update_index = None
         return total
 
     evolve_step.__doc__ = ref_evolve_step.__doc__

@@ -27,6 +27,24 @@ def bond_gate(h_bond_dense, p_leg, dt, imaginary=False):
                                   labels=['p0', 'p1', 'p0*', 'p1*'], cutoff=1e-14, raise_wrong_sector=True)
 
 
+BATCH_BYTES_CAP = int(float(__import__('os').environ.get('TPA_TEBD_BATCH_GB', '96')) * 2**30)
+
+
+def batch_group_size(psi, bonds, itemsize=16, cap=None):
+    """How many bonds of a half-step go into one batched decomposition: all of them unless their work areas would not fit.  The block
+    SVD needs ~24x the bytes of theta (two images of [W | G], Gram matrix, accumulated transform, split-K partials, outputs); theta is
+    bounded by its dense size (d chi_L) x (d chi_R) -- charge conservation only makes it smaller.  ``TPA_TEBD_BATCH_GB`` (96) caps the sum."""
+    cap = BATCH_BYTES_CAP if cap is None else cap
+    if not bonds:
+        return 1
+    worst = 0
+    for i in bonds:
+        d0, d1 = psi.p_legs[i - 1].ind_len, psi.p_legs[i].ind_len
+        chi_l, chi_r = len(psi.get_SL(i - 1)), len(psi.get_SR(i))
+        worst = max(worst, 24 * itemsize * (d0 * chi_l) * (d1 * chi_r))
+    return int(max(1, min(len(bonds), cap // max(worst, 1))))
+
+
 class TEBDEngine:
     def __init__(self, psi, h_bonds_dense, options):
         """``h_bonds_dense[i]`` couples sites (i-1, i) (``None`` for i = 0), shape (d, d, d, d)."""
@@ -131,7 +149,8 @@ class TEBDEngine:
             U = self._gates(frac)
             bonds = [i for i in range(1, L) if i % 2 == (1 - parity)]        # bond (i-1, i) with even i-1 <=> parity 0
             if batch:
-                group = len(bonds) if batch is True else max(int(batch), 1)      # True: the whole half-step; k: k bonds per device call
+                # True: the whole half-step (as far as the work areas fit, batch_group_size); k: k bonds per device call
+                group = batch_group_size(self.psi, bonds) if batch is True else max(int(batch), 1)
                 for g0 in range(0, len(bonds), group):
                     self.update_bonds_batched(bonds[g0:g0 + group], U)
             else:
