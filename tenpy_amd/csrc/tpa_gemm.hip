@@ -308,10 +308,10 @@ extern "C" int tpa_gemm_chain(int dtype, int cfg, const int64_t *tasks_dev, cons
             launch<false, 64, 64, 1, 1, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else if (cfg == 1 && (g_large_variant & 2))
             launch<false, 64, 64, 2, 2, 32>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
-        else if (cfg == 1 && n_tiles <= 512 && !(g_large_variant & 64))
+        else if (cfg == 1 && n_tiles <= 1024 && !(g_large_variant & 64))
             // few tiles (chi <= 512, ramp sweeps, edge bonds): every tile is resident at once and the launch lasts as long as ONE tile's
             // chain -- eight wavefronts per tile (16 x 32 each) halve that chain.  Measured (scripts/gemm_bench.py): matvec at chi = 512
-            // 6.9 -> 8.0 TFLOP/s (step 2, 69 tiles: 0.089 -> 0.075 ms), no difference at chi = 2048 (831 / 4005 tiles).  The opposite
+            // 6.9 -> 8.0 TFLOP/s (step 2, 69 tiles: 0.089 -> 0.075 ms), at chi = 2048 step 2 (831 tiles) 0.710 -> 0.687 ms, step 1 (4005 tiles) 0.660 -> 0.680 ms: hence the limit of 1024 tiles.  The opposite
             // direction -- ONE wavefront per 64 x 64 tile (4 x 4 MFMA tiles, half the LDS reads per MFMA) or two (4 x 2) -- is slower
             // everywhere: 24.6 / 30.8 instead of 38.7 TFLOP/s at chi = 2048: the tile's chain, not the LDS bandwidth, is the limit.
             launch<false, 64, 64, 1, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
