@@ -54,3 +54,16 @@ def test_qr_tebd_quench(backend, name, batch):
         eng.evolve_step_order2()
         assert max(psi.chi) == rec['chi_qr'][step]
         np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_qr'][step], rtol=0, atol=1e-9)
+
+
+def test_batch_group_size_respects_the_memory_cap(backend):
+    """``batch_bonds=True`` batches a whole half-step only as far as the SVD work areas (~24x the dense theta per bond) fit the cap."""
+    from tenpy_amd.algorithms.tebd import batch_group_size
+    _, p = spin_half_leg('parity')
+    psi = MPS.from_product_state([p] * 10, [0] * 10, dtype=np.complex128)
+    bonds = [1, 3, 5, 7, 9]
+    per_bond = 24 * 16 * (2 * 1) * (2 * 1)               # chi = 1 everywhere, d = 2
+    assert batch_group_size(psi, bonds, cap=10**9) == 5
+    assert batch_group_size(psi, bonds, cap=3 * per_bond) == 3
+    assert batch_group_size(psi, bonds, cap=1) == 1
+    assert batch_group_size(psi, [], cap=1) == 1
