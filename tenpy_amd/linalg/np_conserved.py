@@ -2666,12 +2666,17 @@ def _svd_warm_store(a, key, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
 # Measured on the chi = 2048 theta (round 3): the second batch is a second dependent chain of Jacobi rounds whose length is set by
 # the ROWS of its largest block (~3 ms for blocks of ~150 rows), so mixed calls lose; default: all or nothing.
 SVD_WARM_MAX_COLD_FRACTION = 0.0
+# Skipping 1-3 visits after a stale attempt was right while a stale attempt cost 9.3 ms (round 3 / early round 4: it decomposed the blocks
+# that had passed before it gave up); at 0.5 ms per failed attempt against ~7 ms saved by a hit it only throws hits away.  Measured at the
+# end of round 4 (5 + 6 sweeps at chi = 2048, profiles/r04_bench_heis2048_no_cooldown_5_6.json): 65 % instead of 43 % of the calls go
+# warm, 2.91 s per sweep (with the cool-down: 3.01 on 5 + 20, 3.05 on 3 + 3 sweeps).  Off by default; TPA_SVD_WARM_COOLDOWN=1 restores it.
+SVD_WARM_COOLDOWN = os.environ.get('TPA_SVD_WARM_COOLDOWN', '0') != '0'
 
 
 def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_offs, sweeps):
     """Warm-started decomposition if the cache holds a basis for ``hint``; None -> cold path for the whole call."""
     key, side = hint
-    wait = _svd_warm.cooldown.get(key, 0)
+    wait = _svd_warm.cooldown.get(key, 0) if SVD_WARM_COOLDOWN else 0
     if wait > 0:                          # the last attempt under this key found a stale basis: theta is still changing
         _svd_warm.cooldown[key] = wait - 1
         _svd_warm.stats['skipped'] = _svd_warm.stats.get('skipped', 0) + 1
