@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument('--qr', action='store_true', help="tebd1024: QR-based truncation (decompose_theta_qr_based, reference "
                     "algorithms/tebd.py:685) instead of the block SVD of theta")
     ap.add_argument('--eig-svd', action='store_true', help="with --qr: _eig_based_svd for the bond matrix (truncation.py:473)")
+    ap.add_argument('--force-dist', action='store_true', help="world size 1 only: still initialise torch.distributed (RCCL on the GPU) and run the "
+                    "row-sharded engine, so that the collective of the N > 1 path executes on a one-GPU box (TPA_BENCH_FORCE_DIST=1 does the same)")
     ap.add_argument('--no-extras', action='store_true', help="heis2048 on one GPU: skip the legs after the headline (adaptive Lanczos sweep, "
                     "other BASELINE configurations, TeNPy's own engine on the device, vector-kernel roofline)")
     return ap.parse_args(argv)
@@ -102,6 +104,7 @@ def parity_and_port(eng, args, gpu_bond_s):
     spread = [L // 2 - 1, 2, L // 4, L // 2, 3 * L // 4]
     bonds = spread[:n_b] if n_b <= len(spread) else [L // 2 - 1 + i for i in range(n_b)]
     t_cpu, n_centre, mv_err, sv_err, e0_err, sv_ind, iso = 0., 0, [], [], [], [], []
+    n_kept = n_kept_bad = 0
     for i0 in bonds:
         eff = TwoSiteH(eng.env, i0, factored=False)       # the fused form LHeff . theta . RHeff that the oracle restates
         theta = eff.combine_theta(eng.psi.get_theta(i0, n=2))
@@ -133,6 +136,12 @@ def parity_and_port(eng, args, gpu_bond_s):
         sv_err.append(float(np.max(np.abs(a[:n] - b[:n])) / b[0]))
         big = b[:n] > 1.e-8 * b[0]
         sv_ind.append(float(np.max(np.abs(a[:n][big] - b[:n][big]) / b[:n][big])))
+        # what DMRG keeps of this bond: the chi_max largest values above svd_min (relative to the norm) -- how many of THOSE are off by
+        # more than 1e-10 of their own size (makes the "relative to sigma_max" reading of north_star's 1e-10 checkable)
+        keep_n = min(n, int(eng.trunc_params.get('chi_max', n)))
+        kept = b[:keep_n] > float(eng.trunc_params.get('svd_min', 0.)) * np.linalg.norm(b)
+        n_kept += int(kept.sum())
+        n_kept_bad += int(np.sum(np.abs(a[:keep_n][kept] - b[:keep_n][kept]) > 1.e-10 * b[:keep_n][kept]))
         # isometry defect over all kept vectors (sigma > 1e-14 sigma_max, what svd_min = 1e-14 keeps)
         Ud, Vd = U.to_ndarray(), VH.to_ndarray()
         kept = np.asarray(S_dev) > 1.e-14 * np.max(S_dev)
@@ -145,7 +154,8 @@ def parity_and_port(eng, args, gpu_bond_s):
             "sample": "%d centre bond update(s) (%d-step Lanczos + block SVD each) with the numpy oracle on the same state, "
                       "%.2f s CPU per bond, extrapolated x%d bonds; GPU same bonds %.4f s per bond"
                       % (max(n_centre, 1), args.lanczos_N, per_bond, n_bonds, gpu_bond_s)}
-    parity = {"sv_max_rel_err": max(sv_err), "sv_max_rel_err_individual": max(sv_ind), "svd_isometry_defect": max(iso),
+    parity = {"sv_max_rel_err": max(sv_err), "sv_max_rel_err_individual": max(sv_ind), "sv_kept": n_kept,
+              "sv_kept_rel_err_over_1e-10": n_kept_bad, "svd_isometry_defect": max(iso),
               "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err),
               "parity_sample": "bonds %r (centre, edge, quarter) of the timed state: device block SVD vs LAPACK (oracle; sv_max_rel_err = max |dS| / S_max, "
                                "..._individual = max |dS_i| / S_i over S_i > 1e-8 S_max, svd_isometry_defect = max(|U^H U - 1|, |VH VH^H - 1|) "
@@ -295,8 +305,13 @@ def run(argv=None, emit=True):
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     backend = os.environ.get('TPA_BENCH_BACKEND', 'nccl')     # 'gloo': CPU dry run of the N>1 control flow (tests/test_bench_contract.py)
-    if world > 1:
+    force_dist = world == 1 and (args.force_dist or bool(os.environ.get('TPA_BENCH_FORCE_DIST')))
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist:              # a one-rank group: the collectives of the N > 1 path run (RCCL on the GPU) with nobody to talk to
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', TPA_SHARD_FORCE='1')
         if backend == 'nccl':
             torch.cuda.set_device(local)
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
@@ -315,7 +330,7 @@ def run(argv=None, emit=True):
         eng, ramp_E = build_tebd(args), []
         step = eng.evolve_step_order2
     else:
-        eng, ramp_E = build_dmrg(args, world, args.config)
+        eng, ramp_E = build_dmrg(args, 2 if force_dist else world, args.config)
         step = eng.sweep
     sweep_E = list(ramp_E)
     n_ramp = len(ramp_E)
@@ -387,15 +402,22 @@ def run(argv=None, emit=True):
             r.update(extra)
             return r
         pmc_note = {"traffic_note": "no PMC summary for this workload (profiles/r04_svd_call_pmc.json is the chi=2048 Heisenberg call)"}
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_svd_call_pmc.json')
-        if args.config == 'heis2048' and os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, 'profiles', 'r05_svd_call_pmc.json')
+        if not os.path.exists(pmc_file):
+            pmc_file = os.path.join(ROOT, 'profiles', 'r04_svd_call_pmc.json')
+        if args.config == 'heis2048' and chi == CONFIGS['heis2048'][1] and os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 pmc = json.load(f)
             pmc_note = {"traffic": pmc["bytes_per_call_corrected"],
+                        # numerator and denominator of the SAME call (the sweep-average bytes are a different workload)
+                        "traffic_call_algorithmic_bytes": pmc.get("algorithmic_bytes_same_call"),
+                        "traffic_over_algorithmic": (pmc["bytes_per_call_corrected"] / pmc["algorithmic_bytes_same_call"])
+                        if pmc.get("algorithmic_bytes_same_call") else None,
                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes of the same call (FETCH_SIZE x 2 (gfx950) + WRITE_SIZE; "
-                                        "profiles/r04_svd_call_pmc.json: one COLD call on the saturated centre-bond theta), not collected in this "
+                                        "%s: one COLD call on the saturated centre-bond theta), not collected in this "
                                         "run -- rocprofv3 counters cannot be read from inside the timed process; fabric-side counters incl. "
-                                        "Infinity-Cache hits: the Gram matrices and accumulated transforms of the Gram-only rounds + the trailing updates of the pivoted QR, on-die"}
+                                        "Infinity-Cache hits: the Gram matrices and accumulated transforms of the Gram-only rounds + the trailing updates of the pivoted QR, on-die"
+                                        % ("profiles/" + os.path.basename(pmc_file))}
         roof_svd = roof(npc.svd_timer, "block SVD of one npc.svd call, all charge blocks together: cold = tpa_svd_batch (rank-revealing pivoted QR "
                                        "qrp_panel / qrp_update + one-sided Jacobi on 32-row blocks: Gram-only sweeps = Gram GEMM, svd_b32_round (solve + Gram / Qtot "
                                        "tile updates, one launch per round; complex: svd_b32_solve_c + svd_b32_gupdate_c), apply GEMM; + Q application), "
@@ -427,8 +449,8 @@ def run(argv=None, emit=True):
                           "parallelism": "1 GPU" if world == 1 else
                           ("bonds of every half-step dealt over %d GPUs, one broadcast per new tensor" % world if (is_tebd and not args.qr) else
                            "%d replicas" % world if is_tebd else
-                           "matvec row-sharded over %d GPUs (all-gather per matvec), SVD charge blocks distributed (LPT + all-gather), "
-                           "env update replicated" % world)},
+                           "strong scaling of ONE chain: matvec row-sharded over %d GPUs (1 all-gather each), SVD blocks dealt out (LPT + all-gather), rest "
+                           "replicated; predicted Amdahl bound at chi=2048: 1.5x/1.6x/1.7x on 2/4/8 GPUs (DESIGN 5)" % world)},
                "prep_s": t_prep, "roofline": roof_svd, "roofline_gemm": roof_gemm, "energy_err": None}
         if roof_eigh is not None:
             out["roofline_eigh"] = roof_eigh
@@ -547,12 +569,169 @@ def run(argv=None, emit=True):
                 extras(out, eng, args)
             except Exception as e:      # the extra legs must never kill the bench line
                 out["extras_error"] = repr(e)
+        if force_dist:
+            out["config"]["parallelism"] = ("1 GPU, torch.distributed group of ONE rank over %s with the row-sharded operator forced: the all-gather of "
+                                            "the N > 1 path runs as op kind 3 of tpa_lanczos_run (%d native sharded Lanczos runs)"
+                                            % ("RCCL" if backend == 'nccl' else backend, out.get("lanczos_stats", {}).get("n_native_sharded", 0)))
         if emit:
-            print(json.dumps(out), flush=True)
+            emit_lines(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+# ---- output: the driver parses the LAST stdout line and keeps only the tail of stdout, so the contract line must be short and
+# ---- last (round 4's single 27 KB line was cut off: BENCH_r04.json "parsed": null).  Everything long goes out BEFORE it.
+MAX_LINE = 4000
+
+
+def _r(x, sig=6):
+    """Floats to `sig` significant digits (JSON size), containers recursively; everything else unchanged."""
+    if isinstance(x, float):
+        return float('%.*g' % (sig, x)) if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _roof_compact(r, name):
+    if not isinstance(r, dict):
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "algorithmic_flops_per_launch",
+            "algorithmic_bytes_per_launch", "time_share_of_timed_region", "traffic_call_algorithmic_bytes", "traffic_over_algorithmic")
+    c = {k: r[k] for k in keep if k in r}
+    c["kernel"] = name
+    return c
+
+
+def compact(out):
+    """The contract line: the keys the driver and the judge read, numbers only, no prose beyond short labels (< MAX_LINE bytes,
+    asserted by tests/test_bench_contract.py on round 4's full line)."""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype") if k in out}
+    c["data"] = "synthetic"
+    cfg = out.get("config", {})
+    c["config"] = {"workload": (cfg.get("workload") or "")[:230], "name": cfg.get("name"), "parallelism": (cfg.get("parallelism") or "")[:200]}
+    tebd = str(out.get("unit")) == "s/step"
+    c["roofline"] = _roof_compact(out.get("roofline"), "tpa_svd_batch (+warm start, clean-up): one entry per npc.svd, all charge blocks")
+    if "roofline_eigh" in out and out.get("roofline") is out.get("roofline_eigh"):
+        c["roofline"]["kernel"] = "tpa_eigh_batch: Hermitian block eigensolver (_eig_based_svd)"
+    c["roofline_gemm"] = _roof_compact(out.get("roofline_gemm"), "gemm_chain_kernel<f64|c128>: grouped chained MFMA GEMM")
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = {k: (cb[k][:200] if isinstance(cb[k], str) else cb[k]) for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+        off = cb.get("offline_full_sweep")
+        if isinstance(off, dict):
+            c["cpu_baseline"]["offline_full_sweep"] = {"value": off.get("value"), "cores": off.get("cores")}
+        port = cb.get("port")
+        if isinstance(port, dict):
+            c["cpu_baseline"]["port"] = {"value": port.get("value"), "cores": port.get("cores")}
+    for k in ("energy_err", "E", "chi_reached", "sv_max_rel_err", "sv_max_rel_err_individual", "sv_kept", "sv_kept_rel_err_over_1e-10",
+              "svd_isometry_defect", "matvec_max_rel_err", "E0_rel_err", "trunc_err_eps", "S_mid_entropy", "tebd_route", "prep_s"):
+        if k in out:
+            c[k] = out[k]
+    tp = out.get("tebd_parity")
+    if isinstance(tp, dict):
+        c["tebd_parity"] = {k: tp[k] for k in ("after_steps", "S_mid_entropy_abs_err", "trunc_err_eps_rel_err", "schmidt_top8_max_abs_err",
+                                               "like_for_like") if k in tp}
+    ss = out.get("svd_stats")
+    if isinstance(ss, dict):
+        w = ss.get("warm", {})
+        c["svd_stats"] = {"calls": ss.get("calls_timed"), "jacobi_sweeps_per_call": ss.get("jacobi_sweeps_per_call"), "max_block": ss.get("max_block"),
+                          "warm_calls": w.get("warm_calls"), "cold_calls": w.get("cold_calls"), "fb_stale": w.get("fb_stale"),
+                          "abs_floor": ss.get("abs_floor")}
+    ls = out.get("lanczos_stats")
+    if isinstance(ls, dict):
+        c["lanczos_stats"] = {k: v for k, v in ls.items() if k != "note"}
+    if "untimed_sweeps" in out:
+        c["untimed_sweeps_s"] = [r_["s"] for r_ in out["untimed_sweeps"]]
+    fs = out.get("first_sweeps_at_target_chi")
+    if isinstance(fs, dict):
+        c["first_sweeps_at_target_chi_s"] = fs.get("s")
+    la = out.get("lanczos_adaptive")
+    if isinstance(la, dict):
+        c["lanczos_adaptive"] = {"s_per_sweep": la.get("s_per_sweep"), "matvecs_per_bond": la.get("matvecs_per_bond"), "E": la.get("E")}
+    rv = out.get("roofline_vec")
+    if isinstance(rv, dict) and "frac" in rv:
+        c["roofline_vec"] = {"bound": "hbm", "achieved": rv.get("achieved"), "peak": rv.get("peak"), "unit": rv.get("unit"), "frac": rv.get("frac"),
+                             "MB": rv.get("MB"), "kernels_frac": {k: v.get("frac") for k, v in rv.get("kernels", {}).items()}}
+    oc = out.get("other_configs")
+    if isinstance(oc, dict):
+        c["other_configs"] = {}
+        for name, o in oc.items():
+            if "error" in o:
+                c["other_configs"][name] = {"error": str(o["error"])[:80]}
+                continue
+            e = {"value": o.get("value"), "unit": o.get("unit")}
+            for rk, ek in (("roofline", "frac"), ("roofline_gemm", "gemm_frac"), ("roofline_svd", "svd_frac")):
+                if isinstance(o.get(rk), dict):
+                    e[ek] = o[rk].get("frac")
+            if isinstance(o.get("roofline"), dict):
+                e["ms_per_call"] = o["roofline"].get("avg_launch_ms")
+            for k in ("energy_err", "sv_max_rel_err"):
+                if o.get(k) is not None:
+                    e[k] = o[k]
+            if isinstance(o.get("tebd_parity"), dict) and "S_mid_entropy_abs_err" in o["tebd_parity"]:
+                e["entropy_abs_err"] = o["tebd_parity"]["S_mid_entropy_abs_err"]
+            c["other_configs"][name] = e
+    mf = out.get("module_form")
+    if isinstance(mf, dict):
+        c["module_form"] = {k: mf[k] for k in ("s_per_sweep_steady", "s_per_sweep_at_target_chi", "ramp_sweeps_s", "E", "svd_warm", "vs_standalone",
+                                               "skipped", "error") if k in mf}
+        if "error" in c["module_form"]:
+            c["module_form"]["error"] = str(c["module_form"]["error"])[:120]
+    for k in ("extras_s", "extras_error"):
+        if k in out:
+            c[k] = out[k] if k == "extras_s" else str(out[k])[:120]
+    c["detail"] = "earlier stdout lines {\"bench_detail\": ...}; builder copy under profiles/"
+    c = _r(c)
+    for k in ("E",):                        # energies keep every digit (the parity claim is 1e-10 relative)
+        if k in out:
+            c[k] = out[k]
+    if isinstance(la, dict) and "lanczos_adaptive" in c:
+        c["lanczos_adaptive"]["E"] = la.get("E")
+    if isinstance(mf, dict) and "E" in mf and "module_form" in c:
+        c["module_form"]["E"] = mf["E"]
+    line = json.dumps(c, separators=(',', ':'))
+    if len(line) > MAX_LINE:                 # never let optional parts cost the headline: drop them in this order
+        for k in ("untimed_sweeps_s", "lanczos_stats", "roofline_vec", "svd_stats", "other_configs", "module_form", "cpu_baseline"):
+            if k == "cpu_baseline":
+                c[k] = {kk: vv for kk, vv in c.get(k, {}).items() if kk != "sample"}
+            else:
+                c.pop(k, None)
+            line = json.dumps(c, separators=(',', ':'))
+            if len(line) <= MAX_LINE:
+                break
+    return c, line
+
+
+def emit_lines(out):
+    """stdout: first the long material, one JSON object per line, each tagged ``bench_detail`` (the full headline with its notes, every
+    extra leg); then -- LAST -- the compact contract line.  A copy of everything goes to gpurun_out/bench_full.json when that
+    directory exists (builder runs; it is what lands under profiles/)."""
+    big = ("other_configs", "module_form", "lanczos_adaptive", "roofline_vec", "first_sweeps_at_target_chi")
+    head = {k: v for k, v in out.items() if k not in big}
+    print(json.dumps({"bench_detail": "headline", **head}), flush=True)
+    for k in big:
+        if k not in out:
+            continue
+        if k == "other_configs" and isinstance(out[k], dict):
+            for name, o in out[k].items():
+                print(json.dumps({"bench_detail": "other_configs." + name, **o}), flush=True)
+        else:
+            print(json.dumps({"bench_detail": k, k: out[k]}), flush=True)
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        if os.path.isdir(d):
+            with open(os.path.join(d, 'bench_full.json'), 'w') as f:
+                json.dump(out, f)
+    except Exception:
+        pass
+    _, line = compact(out)
+    print(line, flush=True)
 
 
 def vector_roofline(n_elems, reps=20):
@@ -671,28 +850,51 @@ def extras(out, eng, args):
         else:
             t0 = time.time()
             pr = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'module_form_bench.py'), '--chi', str(args.chi), '--L',
-                                 str(args.L), '--sweeps', '2'], capture_output=True, text=True, timeout=400)
+                                 str(args.L), '--sweeps', '5'], capture_output=True, text=True, timeout=400)
             line = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
             if pr.returncode != 0 or not line:
                 out["module_form"] = {"error": (pr.stderr or pr.stdout)[-400:]}
             else:
                 m = json.loads(line[-1])
                 tgt = [r for r in m["sweeps"] if r["kind"].startswith("target")]
+                ts = [r["s"] for r in tgt]
+                steady = float(np.mean(ts[-3:])) if len(ts) >= 5 else None
                 out["module_form"] = {
-                    "what": m["what"], "s_per_sweep_at_target_chi": [r["s"] for r in tgt], "E": tgt[-1]["E"] if tgt else None,
+                    "what": m["what"], "s_per_sweep_at_target_chi": ts, "E": tgt[-1]["E"] if tgt else None,
+                    # VERDICT r4 task 7: TeNPy's own engine in the regime the headline is quoted in (>= 5 sweeps at the target chi, mean of the last 3)
+                    "s_per_sweep_steady": steady, "vs_standalone": (steady / out["value"]) if steady else None,
                     "ramp_sweeps_s": [r["s"] for r in m["sweeps"] if not r["kind"].startswith("target")],
                     "two_site_h": m.get("two_site_h"),
                     "svd_warm": {k: v for k, v in (m.get("svd_warm") or {}).items() if k in ("warm_calls", "cold_calls", "fallbacks", "fb_stale", "fb_nomatch")},
                     "leg_s": round(time.time() - t0, 1),
                     "note": "tenpy.algorithms.dmrg.TwoSiteDMRGEngine of the reference archive, unmodified, tenpy_amd.install.install(fused=True): "
-                            "the bench protocol (Neel state, mixer on during the chi ramp, then 2 sweeps at the target chi with Lanczos N=8) in a "
+                            "the bench protocol (Neel state, mixer on during the chi ramp, then 5 sweeps at the target chi with Lanczos N=8; "
+                            "s_per_sweep_steady = mean of the last 3, vs_standalone = that / `value`) in a "
                             "second process of this run; energies comparable with `untimed_sweeps` / profiles/r02_cpu_reference.json"}
     except Exception as e:
         out["module_form"] = {"error": repr(e)}
     out["extras_s"] = round(time.time() - t_all, 1)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
 def main():
+    """``python bench.py --gpus N`` with N > 1 and no rendezvous in the environment launches its own N ranks (one per GPU) through
+    ``torch.distributed.run`` on 127.0.0.1 and passes the command line on; under the driver's launcher (WORLD_SIZE set) it is a rank."""
+    args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs and what n_gpus reports\n" % (args.gpus, world))
     run()
 
 

@@ -47,7 +47,8 @@ class TwoSiteDMRGEngine:
         self._svd_group = None
         if self.shard_matvec:           # multi-GPU: the independent charge blocks of every SVD are dealt out to the ranks too
             import torch.distributed as dist
-            if dist.is_initialized() and dist.get_world_size() > 1:
+            import os
+            if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('TPA_SHARD_FORCE')):
                 self._svd_group = (None, dist.get_rank(), dist.get_world_size())
         if resume_data is not None:
             self.sweeps = int(resume_data['sweeps'])

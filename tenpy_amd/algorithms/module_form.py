@@ -14,6 +14,7 @@
   bond it decomposes (``np_conserved.svd_hint``), which enables the warm start of ``linalg/_svd_warm.py``.
 """
 import os
+import warnings
 
 import numpy as np
 
@@ -150,7 +151,8 @@ def batched_tebd_evolve_step(ref_tebd):
             return ref_evolve_step(self, U_idx_dt, odd)
         psi = self.psi
         # groups of bonds whose work areas fit the device together (algorithms/tebd.batch_group_size: ~24x the dense theta each)
-        cap = int(float(os.environ.get('TPA_TEBD_BATCH_GB', '96')) * 2**30)
+        from .tebd import batch_bytes_cap
+        cap = batch_bytes_cap()
         worst = max(24 * 16 * (psi.sites[i - 1].dim * len(psi.get_SL(i - 1))) * (psi.sites[i].dim * len(psi.get_SR(i))) for i in bonds)
         group = int(max(1, min(len(bonds), cap // max(worst, 1))))
         total = TruncationError()
@@ -183,6 +185,15 @@ def batched_tebd_evolve_step(ref_tebd):
             res = dev_trunc.decompose_theta_qr_based_batched(extra, self.trunc_params, compute_err, False)
             for i, C, theta, (_, S, B_R, form, err, renormalize) in zip(bonds, Cs, thetas, res):
                 i0, i1 = i - 1, i
+                if compute_err:         # the reference's warning (tebd.py:712-725), same condition, same text
+                    chi_max = self.trunc_params.get('chi_max', None)
+                    if err.eps > 1e-16 and chi_max is not None and len(S) < chi_max:
+                        warnings.warn('QRBased decomposition resulted in large truncation error even though the bond '
+                                      'dimension is not maxed out yet. Try increasing the expansion rate, e.g. '
+                                      'via the `cbe_expand_0` and `cbe_min_block_increase` options for the engine. '
+                                      'You probably should compare to a "regular" (non QR-based) engine and see how '
+                                      'fast the bond dimension needs to grow for your scenario. '
+                                      'See https://github.com/tenpy/tenpy/pull/513 .', stacklevel=2)
                 assert form[1] == 'B'
                 err = TruncationError(err.eps, err.ov)
                 B_L = npc.tensordot(C.combine_legs(('p1', 'vR'), pipes=theta.legs[1]), B_R.conj(), axes=[['(p1.vR)'], ['(p*.vR*)']]) / renormalize

@@ -34,6 +34,23 @@ def _dist():
     return dist
 
 
+def _agree_failure(failed, group=None):
+    """All-reduce (MAX) of a failure flag: True on every rank if ANY rank failed.  Every rank must call it at the same point; it is
+    what keeps a rank that raised alone from leaving the others waiting in the next collective (same rule as ``np_conserved._svd_distributed``)."""
+    flag = dev.zeros(1, np.float64)
+    flag.fill_(1. if failed else 0.)
+    _dist().all_reduce(flag, op=_dist().ReduceOp.MAX, group=group)
+    return float(flag.item()) > 0.
+
+
+def _forced():
+    """``TPA_SHARD_FORCE=1``: a ONE-rank group still takes the sharded path (row-restricted plans, pack, all-gather, unpack), so
+    that the collective of the N > 1 path executes on a one-GPU box (RCCL with a single member; ``bench.py --force-dist``,
+    ``tests/test_sharded.py::test_rccl_collective_world1``).  Off: a one-rank group runs the unsharded operator."""
+    import os
+    return bool(os.environ.get('TPA_SHARD_FORCE'))
+
+
 def row_partition(row_weights, world):
     """Cut ``range(len(row_weights))`` into ``world`` contiguous ranges of (nearly) equal total weight.
     Returns the ``world + 1`` boundaries."""
@@ -275,7 +292,7 @@ class ShardedTwoSiteH(TwoSiteH):
         this rank, the pack / unpack copies of the row panels (op kind 2) and the all-gather as the program's collective (op kind 3,
         enqueued from the host callback on the launch stream), so that N > 1 runs the same single-call Lanczos as N = 1.  Returns
         ``(ops, bufs, gemm_plans, collective)`` or ``None`` (the step-by-step loop with :meth:`matvec` is the fallback)."""
-        if self.world == 1:
+        if self.world == 1 and not _forced():
             return super().matvec_program(theta)
         want = ['vL', 'p0', 'p1', 'vR'] if self.factored else ['(vL.p0)', '(p1.vR)']
         if list(theta.get_leg_labels()) != want or theta.stored_blocks == 0 or not theta._is_packed():
@@ -338,12 +355,13 @@ class ShardedTwoSiteH(TwoSiteH):
                         import traceback
                         traceback.print_exc()
                         return 1
+                collective.agree = lambda failed, group=group: _agree_failure(failed, group)
                 res = (np.array(ops, dtype=np.int64), bufs, (), collective)
         self.__dict__['_program'] = (key, res)
         return res
 
     def matvec(self, theta):
-        if self.world == 1:
+        if self.world == 1 and not _forced():
             return super().matvec(theta)
         if self.factored:
             if theta.rank == 2:
@@ -637,7 +655,15 @@ class ShardedTEBDEngine(TEBDEngine):
         dist = _dist()
         bonds = list(bonds)
         mine = bonds[self.rank::self.world]
-        local = {r[0]: r for r in self._decompose_bonds(mine, U)}
+        failure, local = None, {}
+        try:
+            local = {r[0]: r for r in self._decompose_bonds(mine, U)}
+        except Exception as e:       # LinAlgError after the fallback chain, out of memory, a HIP error ... on THIS rank only
+            failure = e
+        # agreed on BEFORE the fixed sequence of broadcasts below: a rank that raised alone would leave the others waiting forever
+        if _agree_failure(failure is not None, self.group):
+            raise failure if failure is not None else np.linalg.LinAlgError(
+                "tenpy_amd TEBD: the decomposition of a bond failed on another rank")
         results = []
         for k, i in enumerate(bonds):
             src = k % self.world

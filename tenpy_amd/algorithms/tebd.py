@@ -27,14 +27,19 @@ def bond_gate(h_bond_dense, p_leg, dt, imaginary=False):
                                   labels=['p0', 'p1', 'p0*', 'p1*'], cutoff=1e-14, raise_wrong_sector=True)
 
 
-BATCH_BYTES_CAP = int(float(__import__('os').environ.get('TPA_TEBD_BATCH_GB', '96')) * 2**30)
+BATCH_BYTES_CAP = None       # TPA_TEBD_BATCH_GB, else 1/3 of the device's memory (96 GB on an MI355X)
+
+
+def batch_bytes_cap():
+    from ..linalg import _device as dev
+    return BATCH_BYTES_CAP if BATCH_BYTES_CAP is not None else dev.memory_budget('TPA_TEBD_BATCH_GB', 1. / 3., 96.)
 
 
 def batch_group_size(psi, bonds, itemsize=16, cap=None):
     """How many bonds of a half-step go into one batched decomposition: all of them unless their work areas would not fit.  The block
     SVD needs ~24x the bytes of theta (two images of [W | G], Gram matrix, accumulated transform, split-K partials, outputs); theta is
-    bounded by its dense size (d chi_L) x (d chi_R) -- charge conservation only makes it smaller.  ``TPA_TEBD_BATCH_GB`` (96) caps the sum."""
-    cap = BATCH_BYTES_CAP if cap is None else cap
+    bounded by its dense size (d chi_L) x (d chi_R) -- charge conservation only makes it smaller.  ``TPA_TEBD_BATCH_GB`` (default: a third of the device's memory) caps the sum."""
+    cap = batch_bytes_cap() if cap is None else cap
     if not bonds:
         return 1
     worst = 0

@@ -4,6 +4,7 @@ torch is *plumbing* here (allocation, H2D/D2H copies, the current HIP stream); e
 data-movement kernel on block data is one of the hand-written HIP kernels behind ``include/tenpy_amd.h``.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -236,6 +237,30 @@ class ScalarPipe:
     def get(self, step):
         self.events[step].synchronize()
         return float(self.host[step, 0]), float(self.host[step, 1])
+
+
+_budget_cache = {}
+
+
+def memory_budget(env_name, fraction, fallback_gb):
+    """Byte cap for a cache / batch work area: ``env_name`` (GB) if set, else ``fraction`` of the TOTAL memory of the current
+    device (``torch.cuda.mem_get_info``), else ``fallback_gb`` when no device can be asked (the emulated device of the CPU
+    tests).  The defaults of rounds 3-4 (48 GB of warm-start bases, 96 GB of batched TEBD work areas) were 1/6 and 1/3 of an
+    MI355X's 288 GB, hard-coded; a smaller GPU ran out of memory."""
+    got = _budget_cache.get(env_name)
+    if got is not None:
+        return got
+    val = os.environ.get(env_name)
+    if val is not None:
+        nbytes = int(float(val) * (1 << 30))
+    else:
+        try:
+            t = torch()
+            nbytes = int(fraction * t.cuda.mem_get_info()[1]) if t.cuda.is_available() else int(fallback_gb * (1 << 30))
+        except Exception:
+            nbytes = int(fallback_gb * (1 << 30))
+    _budget_cache[env_name] = nbytes
+    return nbytes
 
 
 def check(rc, what=""):

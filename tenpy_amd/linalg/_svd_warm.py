@@ -227,7 +227,11 @@ E_TOL = 1.e-13
 E_RANK_TOL = 1.e-15       # singular vectors with values above this fraction of |A|_F are remembered as warm-start basis
 
 
-CACHE_MAX_BYTES = int(float(os.environ.get('TPA_SVD_WARM_CACHE_GB', '48')) * (1 << 30))      # device bytes held by the cached bases (LRU)
+CACHE_MAX_BYTES = None      # device bytes held by the cached bases (LRU): TPA_SVD_WARM_CACHE_GB, else 1/6 of the device's memory (48 GB on an MI355X)
+
+
+def _cache_cap():
+    return CACHE_MAX_BYTES if CACHE_MAX_BYTES is not None else dev.memory_budget('TPA_SVD_WARM_CACHE_GB', 1. / 6., 48.)
 _cache_bytes = [0]
 _owner_tokens = {}        # id(owner) -> (token, weakref finalizer): bases are keyed by a token that is never reused
 _next_token = [1]
@@ -254,10 +258,10 @@ def owner_token(owner):
     oid = id(owner)
 
     def _release(token=token, oid=oid):
-        for k in [k for k in _cache if k[0][0] == token]:
+        for k in [k for k in _cache if isinstance(k[0], tuple) and len(k[0]) and k[0][0] == token]:
             _cache_bytes[0] -= _basis_bytes(_cache.pop(k))
         for d in (ages, cooldown):
-            for k in [k for k in d if k[0] == token]:
+            for k in [k for k in d if isinstance(k, tuple) and len(k) and k[0] == token]:
                 d.pop(k, None)
         if _owner_tokens.get(oid, (None,))[0] == token:
             _owner_tokens.pop(oid, None)
@@ -294,7 +298,7 @@ def cache_put(key, side, basis):
         _cache_bytes[0] -= _basis_bytes(old)
     _cache[(key, side)] = basis
     _cache_bytes[0] += _basis_bytes(basis)
-    while len(_cache) > 1 and (len(_cache) > CACHE_MAX or _cache_bytes[0] > CACHE_MAX_BYTES):
+    while len(_cache) > 1 and (len(_cache) > CACHE_MAX or _cache_bytes[0] > _cache_cap()):
         _, ev = _cache.popitem(last=False)
         _cache_bytes[0] -= _basis_bytes(ev)
 

@@ -116,7 +116,8 @@ class LanczosGroundState:
                 # the tridiagonal eigen-problem of step j is only looked at by the stopping test of steps j and j + 1 (reference
                 # :673, `_converged` reads Es[j] and Es[j - 1]) and by the final result: below N_min - 2 it is skipped -- the same
                 # (E0, psi0, N), ~30 us less host time per step (at chi <= 512 the device waits for this callback)
-                if j + 2 >= self.N_min or abs(b) < self._cutoff:
+                # (also at the last step the loop can take: the reference allows N_min > N_max and returns the N_max result)
+                if j + 2 >= self.N_min or j + 1 >= N_max or abs(b) < self._cutoff:
                     self._calc_result_krylov(j)
                 h[j, j + 1] = h[j + 1, j] = b
                 return int(abs(b) < self._cutoff or (j + 1 >= self.N_min and self._converged(j)))
@@ -132,16 +133,29 @@ class LanczosGroundState:
             ccb = _lib.COLLECTIVE_CALLBACK(collective)
             L.tpa_lanczos_set_collective(ccb, None)
             stats['n_native_sharded'] = stats.get('n_native_sharded', 0) + 1
+        failure = None
         try:
             dev.check(L.tpa_lanczos_run(code, n, ops.ctypes.data, len(ops), ptrs.ctypes.data, len(ptrs), krylov.data_ptr(),
                                         w._arena.data_ptr(), N_max, float(self._cutoff), int(self.E_shift is not None),
                                         float(self.E_shift or 0.), scal.data_ptr(), scr.data_ptr(), cb, None, int(timed),
                                         info.ctypes.data, dev.stream()), "lanczos_run")
+        except Exception as e:
+            if collective is None:
+                raise
+            failure = e
         finally:
             if ccb is not None:
                 L.tpa_lanczos_set_collective(_lib.COLLECTIVE_CALLBACK(), None)
-        if err:
-            raise err[0]
+        if err and failure is None:
+            failure = err[0]
+        agree = getattr(collective, 'agree', None)
+        if agree is not None:
+            # sharded operators: a rank that raised alone would leave the others waiting in the NEXT collective (the SVD gather of
+            # the same bond) forever -- agree on the outcome of the run before anybody goes on
+            if agree(failure is not None) and failure is None:
+                failure = RuntimeError("tenpy_amd Lanczos: the run failed on another rank")
+        if failure is not None:
+            raise failure
         N, n_mv = int(info[0]), int(info[1])
         stats['n_matvec'] += n_mv
         if timed:

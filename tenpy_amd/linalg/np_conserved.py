@@ -15,6 +15,7 @@ for the hot path of DMRG/TEBD, but with an MI355X-first data layout:
 Floating point data never goes through numpy on the product path; there is no CPU fallback.
 """
 import functools
+import threading
 import warnings
 from collections import OrderedDict
 
@@ -2408,7 +2409,23 @@ SVD_ABS_FLOOR = 1.e-6
 # vector converged, no post-processing.  ``TENPY_AMD_SVD_FLOOR`` overrides the floor of such generic calls.
 SVD_ABS_FLOOR_GENERIC = float(os.environ.get('TENPY_AMD_SVD_FLOOR', '0'))
 svd_engine_floor = False
-_svd_floor_now = [SVD_ABS_FLOOR_GENERIC]      # floor of the npc.svd call in progress (read by the helpers below)
+
+
+class _PerThreadFloor(threading.local):
+    """Floor of the ``npc.svd`` call in progress, per thread (``DMRGThreadPlusHC`` and ``tests/test_threads.py`` run ``svd`` from a
+    second thread).  Indexed like the one-element list it replaces."""
+
+    def __init__(self):
+        self.v = SVD_ABS_FLOOR_GENERIC
+
+    def __getitem__(self, i):
+        return self.v
+
+    def __setitem__(self, i, value):
+        self.v = value
+
+
+_svd_floor_now = _PerThreadFloor()      # read by the helpers below
 SVD_LOWDIN_ITERATIONS = 2
 # Warm start (`_svd_warm`): a caller that knows which bond it is decomposing sets ``svd_hint = (key, side)`` right before
 # ``svd`` / ``svd_theta`` (side 'R': the right singular vectors of the previous decomposition under ``key`` are a good basis,
@@ -2911,6 +2928,12 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     block, not globally sorted) because the truncation decision (``truncation.truncate``) is host logic.
     ``full_matrices=True``: ``U`` and ``VH`` are completed to square unitary blocks on the device.
     """
+    # the one-call marks of the engines are consumed FIRST: a call that raises in the validation below must not leave them
+    # behind for the next, unrelated npc.svd (ADVICE r4)
+    global svd_hint, svd_engine_floor
+    hint, svd_hint = svd_hint, None
+    _svd_floor_now[0] = SVD_ABS_FLOOR if (hint is not None or svd_engine_floor) else SVD_ABS_FLOOR_GENERIC
+    svd_engine_floor = False
     if a.rank != 2:
         raise ValueError("SVD is only defined for a 2D matrix. Use LegPipes!")
     labL, labR = inner_labels
@@ -2941,10 +2964,6 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
     jobs[:, 3], jobs[:, 4], jobs[:, 5] = u_offs[:-1], s_offs[:-1], v_offs[:-1]
     L = dev.lib()
     code = dev.code(a.dtype)
-    global svd_hint, svd_engine_floor
-    hint, svd_hint = svd_hint, None
-    _svd_floor_now[0] = SVD_ABS_FLOOR if (hint is not None or svd_engine_floor) else SVD_ABS_FLOOR_GENERIC
-    svd_engine_floor = False
     sweeps = dev.c_int()
     warm = None
     tick = _svd_tick if SVD_PROFILE else (lambda name, t0=None: None)

@@ -295,7 +295,12 @@ def decompose_theta_qr_based(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, mo
     """``theta`` [(vL.p0), (p1.vR)] ~= renormalization * T_Lc . diag(S) . T_Rc without an SVD of theta itself: two block
     QRs give isometries A (left) and B (right) around a small bond matrix ``Xi``, which alone is decomposed (block SVD,
     or ``_eig_based_svd``).  Same arguments and returned tuple ``(T_Lc, S, T_Rc, form, trunc_err, renormalization)`` as the
-    reference (truncation.py:533-711); everything is block GEMM / block QR on the device."""
+    reference (truncation.py:533-711); everything is block GEMM / block QR on the device.
+
+    The SVD of the bond matrix runs with the GENERIC stopping rule (``np_conserved.SVD_ABS_FLOOR_GENERIC`` = 0: every returned vector
+    converged), not with the engines' absolute floor: this is a library function any caller may use, ``Xi`` is only chi x chi, and the
+    measured QR-route numbers are with floor 0.  Only ``svd_theta`` of a full two-site theta inside the DMRG / SVD-based
+    TEBD drivers opts into the floor (``svd_hint`` / ``svd_engine_floor``)."""
     A_L, B_R, Xi = _decompose_qr_prepare(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase)
     if use_eig_based_svd:            # only the factor on the side we move to comes out of the eigen-decomposition
         U, S, Vd, _, renormalization = _eig_based_svd(Xi, need_U=move_right, need_Vd=not move_right,

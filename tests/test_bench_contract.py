@@ -23,20 +23,26 @@ def test_bench_json_contract(monkeypatch):
     with contextlib.redirect_stdout(buf):
         bench.main()
     lines = [l for l in buf.getvalue().splitlines() if l.strip()]
-    assert len(lines) == 1, "exactly ONE JSON line on stdout"
-    out = json.loads(lines[0])
+    # the contract line is the LAST line and short; everything long precedes it, tagged (round 4's single 27 KB line was cut off
+    # by the driver's capture: BENCH_r04.json "parsed": null)
+    assert all(json.loads(l).get('bench_detail') for l in lines[:-1])
+    assert len(lines[-1]) < 4096
+    out = json.loads(lines[-1])
+    assert 'bench_detail' not in out
+    detail = json.loads(lines[0])
+    assert detail['bench_detail'] == 'headline' and 'svd' in detail['roofline']['kernel'] and detail['value'] == pytest.approx(out['value'], rel=1e-5)
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
               'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in out, k
     assert out['n_gpus'] == 1 and out['steps'] == 2 and out['warmup'] == 1
     assert out['higher_is_better'] is False and out['vs_baseline'] is None and out['dtype'] == 'f64'
-    assert out['unit'] == 's/sweep' and out['value'] > 0 and abs(out['ms_per_step'] - 1e3 * out['value']) < 1e-6
+    assert out['unit'] == 's/sweep' and out['value'] > 0 and abs(out['ms_per_step'] - 1e3 * out['value']) < 1e-3 * out['ms_per_step']
     assert 'workload' in out['config'] and 'model' not in out['config']
     r = out['roofline']
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r, k
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and r['peak'] > 0
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-4 * r['frac']
     c = out['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
@@ -46,6 +52,55 @@ def test_bench_json_contract(monkeypatch):
     assert 'energy_err' in out and 'roofline_gemm' in out
     assert 'svd' in r['kernel'] and r['launches'] > 0
     assert abs(out['E'] - (-5.142090632841)) < 1e-6          # XXZ Jz=1, L=12 ground state energy (exact: -5.1420906328)
+    assert out['sv_kept'] > 0 and out['sv_kept_rel_err_over_1e-10'] == 0
+
+
+def test_compact_line_fits_with_all_extras():
+    """Round 4's full line (profiles/r04_bench_heis2048.json: headline + every extra leg, 27 KB) through `bench.compact`: the contract
+    line stays under 4 KB and still carries the contract keys, both rooflines, the CPU baseline, the parity fields and one number
+    per extra leg."""
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'profiles', 'r04_bench_heis2048.json')) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    c, line = bench.compact(full)
+    assert len(line) < 4096 and json.loads(line) == c
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'roofline_gemm', 'cpu_baseline', 'energy_err', 'sv_max_rel_err', 'matvec_max_rel_err',
+              'E0_rel_err', 'other_configs', 'module_form', 'lanczos_adaptive'):
+        assert k in c, k
+    assert c['E'] == full['E']                                      # energies are not rounded
+    assert abs(c['roofline']['frac'] - full['roofline']['frac']) < 1e-5 * full['roofline']['frac']
+    assert set(c['other_configs']) == set(full['other_configs']) and c['other_configs']['xxz512']['value'] > 0
+    assert c['lanczos_adaptive']['s_per_sweep'] > 0 and len(c['roofline']['kernel']) <= 120
+    # the guard of last resort: optional parts go before the line grows
+    full['config']['workload'] = full['config']['workload'] * 20
+    full['other_configs'] = {('cfg%d' % i): dict(v) for i, v in enumerate(list(full['other_configs'].values()) * 20)}
+    c2, line2 = bench.compact(full)
+    assert len(line2) < 4096 and 'roofline' in c2 and 'value' in c2
+
+
+def test_bench_gpus_flag_launches_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver may run it: NO rendezvous variables in the environment -- bench.py launches its own two
+    ranks (torch.distributed.run on 127.0.0.1) and rank 0 prints the contract line with n_gpus == 2.  gloo + the emulated device
+    (tests/mock_site/sitecustomize.py); on the MI355X node the same code path runs RCCL."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(PYTHONPATH=os.path.join(root, 'tests', 'mock_site') + os.pathsep + env.get('PYTHONPATH', ''), TPA_TEST_MOCK_DEVICE='1',
+               TPA_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1')
+    pr = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--L', '12', '--chi', '16', '--steps', '1', '--warmup', '1'],
+                        env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith('{')]
+    out = json.loads(lines[-1])
+    assert 'bench_detail' not in out and out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['value'] > 0
+    assert 'Amdahl' in out['config']['parallelism']
+    assert out['lanczos_stats']['n_native_sharded'] > 0             # the one-call Lanczos with the collective as a program op, on both ranks
+    assert abs(out['E'] - (-5.142090632841)) < 1e-6
 
 
 def _bench_worker(rank, world, port, ret):
@@ -86,8 +141,8 @@ def test_bench_two_ranks_gloo():
     tmp.spawn(_bench_worker, args=(world, port, ret), nprocs=world, join=True)
     assert not any(str(ret.get(r, 'FAIL')).startswith('FAIL') for r in range(world)), dict(ret)
     lines = [l for l in ret[0].splitlines() if l.strip()]
-    assert len(lines) == 1 and ret[1].strip() == ''
-    out = json.loads(lines[0])
+    assert len(lines) >= 1 and ret[1].strip() == ''
+    out = json.loads(lines[-1])
     assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and 'cpu_baseline' not in out
     assert 'sharded' in out['config']['parallelism'] and out['value'] > 0
     assert abs(out['E'] - (-5.142090632841)) < 1e-6
@@ -105,7 +160,7 @@ def test_bench_two_ranks_gloo_tebd(monkeypatch):
     ret = mgr.dict()
     tmp.spawn(_bench_worker, args=(world, port, ret), nprocs=world, join=True)
     assert not any(str(ret.get(r, 'FAIL')).startswith('FAIL') for r in range(world)), dict(ret)
-    out = json.loads([l for l in ret[0].splitlines() if l.strip()][0])
+    out = json.loads([l for l in ret[0].splitlines() if l.strip()][-1])
     assert out['n_gpus'] == 2 and out['unit'] == 's/step' and 'dealt over 2 GPUs' in out['config']['parallelism']
     assert out['S_mid_entropy'] > 0 and out['value'] > 0
 
