@@ -641,7 +641,9 @@ def compact(out):
     if isinstance(ss, dict):
         w = ss.get("warm", {})
         c["svd_stats"] = {"calls": ss.get("calls_timed"), "jacobi_sweeps_per_call": ss.get("jacobi_sweeps_per_call"), "max_block": ss.get("max_block"),
-                          "warm_calls": w.get("warm_calls"), "cold_calls": w.get("cold_calls"), "fb_stale": w.get("fb_stale"),
+                          "warm_calls": w.get("warm_calls"), "sketch_calls": w.get("sketch_calls"), "cold_calls": w.get("cold_calls"),
+                          "sk_residual": w.get("sk_residual"), "fb_stale": w.get("fb_stale"),
+                          "sweeps_per_call": {k: round(w.get(k + "_sweeps", 0) / max(w.get(k + "_calls", 0), 1), 2) for k in ("warm", "sketch", "cold")},
                           "abs_floor": ss.get("abs_floor")}
     ls = out.get("lanczos_stats")
     if isinstance(ls, dict):
@@ -865,7 +867,7 @@ def extras(out, eng, args):
                     "s_per_sweep_steady": steady, "vs_standalone": (steady / out["value"]) if steady else None,
                     "ramp_sweeps_s": [r["s"] for r in m["sweeps"] if not r["kind"].startswith("target")],
                     "two_site_h": m.get("two_site_h"),
-                    "svd_warm": {k: v for k, v in (m.get("svd_warm") or {}).items() if k in ("warm_calls", "cold_calls", "fallbacks", "fb_stale", "fb_nomatch")},
+                    "svd_warm": {k: v for k, v in (m.get("svd_warm") or {}).items() if k in ("warm_calls", "sketch_calls", "cold_calls", "fallbacks", "fb_stale", "fb_nomatch", "sk_residual")},
                     "leg_s": round(time.time() - t0, 1),
                     "note": "tenpy.algorithms.dmrg.TwoSiteDMRGEngine of the reference archive, unmodified, tenpy_amd.install.install(fused=True): "
                             "the bench protocol (Neel state, mixer on during the chi ramp, then 5 sweeps at the target chi with Lanczos N=8; "

@@ -49,14 +49,18 @@ struct Stage {
     int i0, istep, lim;   // row (A) / column (B) index of element r = i0 + r * istep, valid while < lim
 };
 
-template <bool CPLX, int BM, int BN, int TM, int TN, int BK_>
+// DB (round 5): two LDS images of the operand tiles.  The stores of k-tile t + 1 go to the image the MFMAs are NOT reading, so one
+// barrier per k-tile is left (the single-image loop needs two: stores -> reads, reads -> next stores) and the LDS stores overlap the
+// matrix pipe instead of preceding it.  40 KB for the real 64 x 64 tile: four workgroups per CU, as the registers allow anyway.
+template <bool CPLX, int BM, int BN, int TM, int TN, int BK_, bool DB>
 __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN, BK_>::NT)) void gemm_chain_kernel(
     const Task *__restrict__ tasks, const Link *__restrict__ links, const int4 *__restrict__ tiles,
     const double *__restrict__ Abase, const double *__restrict__ Bbase, double *__restrict__ Cbase) {
     using C = Cfg<CPLX, BM, BN, TM, TN, BK_>;
     constexpr int NT = C::NT, EA = C::EA, EB = C::EB, PL = C::PLANES, BK = C::BK;
     constexpr int ES = CPLX ? 2 : 1;  // doubles per element
-    __shared__ double lds[PL * (C::A_LDS + C::B_LDS)];
+    constexpr int IMG = PL * (C::A_LDS + C::B_LDS);      // doubles per LDS image
+    __shared__ double lds[(DB ? 2 : 1) * IMG];
     double *As = lds;
     double *Bs = lds + PL * C::A_LDS;
 
@@ -163,12 +167,54 @@ __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN, BK_>::NT)) void gemm_cha
         v.b.p += v.b.kstep;
     };
 
+    auto store_tile = [&](const LinkView &v, double *Ad, double *Bd) {      // registers -> one LDS image, in link v's layout
+#pragma unroll
+        for (int r = 0; r < EA; ++r)
+#pragma unroll
+            for (int p = 0; p < PL; ++p) Ad[p * C::A_LDS + v.a.lbase + r * v.a.lstep] = ra[p][r];
+#pragma unroll
+        for (int r = 0; r < EB; ++r)
+#pragma unroll
+            for (int p = 0; p < PL; ++p) Bd[p * C::B_LDS + v.b.lbase + r * v.b.lstep] = rb[p][r];
+    };
+    auto mma_tile = [&](const double *Aw, const double *Bw, int sa_i, int sa_k, int sb_j, int sb_k) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            double a[PL][TM], b[PL][TN];
+#pragma unroll
+            for (int p = 0; p < PL; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[p][i] = Aw[p * C::A_LDS + i * 16 * sa_i + ks * 4 * sa_k];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[p][j] = Bw[p * C::B_LDS + j * 16 * sb_j + ks * 4 * sb_k];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (CPLX) {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[PL - 1][i], b[PL - 1][j], acc[0][i][j], 0, 0, 0);
+                        acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[PL - 1][j], acc[PL - 1][i][j], 0, 0, 0);
+                        acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[PL - 1][i], b[0][j], acc[PL - 1][i][j], 0, 0, 0);
+                    } else {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
     int li = 0;
     while (li < nl && lk[li].k <= 0) ++li;
     if (li < nl) {
         LinkView cur, nxt;
         open_link(li, cur);
         load_tile(cur, 0);
+        int img = 0;                 // DB: the image the MFMAs read in the current k-tile
+        if (DB) {
+            store_tile(cur, As, Bs);
+            __syncthreads();
+        }
         while (true) {
             // the next non-empty link is opened BEFORE the k loop of this one, so that the last k-tile of this link can
             // prefetch the first k-tile of the next (no drained load pipeline at a link boundary) while everything the k loop
@@ -179,48 +225,34 @@ __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN, BK_>::NT)) void gemm_cha
             if (has_next) open_link(lj, nxt);
             const int K = cur.K;
             const int sa_i = cur.sa_i, sa_k = cur.sa_k, sb_j = cur.sb_j, sb_k = cur.sb_k;
-            const int la0 = cur.a.lbase, las = cur.a.lstep, lb0 = cur.b.lbase, lbs = cur.b.lstep;
-            const double *Aw = As + (wr * TM * 16 + l15) * sa_i + l4 * sa_k;
-            const double *Bw = Bs + (wc * TN * 16 + l15) * sb_j + l4 * sb_k;
-            for (int k0 = 0; k0 < K; k0 += BK) {
-#pragma unroll
-                for (int r = 0; r < EA; ++r)
-#pragma unroll
-                    for (int p = 0; p < PL; ++p) As[p * C::A_LDS + la0 + r * las] = ra[p][r];
-#pragma unroll
-                for (int r = 0; r < EB; ++r)
-#pragma unroll
-                    for (int p = 0; p < PL; ++p) Bs[p * C::B_LDS + lb0 + r * lbs] = rb[p][r];
-                __syncthreads();
-                if (k0 + BK < K)
-                    load_tile(cur, k0 + BK);      // prefetch the next k-tile into registers
-                else if (has_next)
-                    load_tile(nxt, 0);            // ... or the first k-tile of the next link
-#pragma unroll
-                for (int ks = 0; ks < BK / 4; ++ks) {
-                    double a[PL][TM], b[PL][TN];
-#pragma unroll
-                    for (int p = 0; p < PL; ++p) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) a[p][i] = Aw[p * C::A_LDS + i * 16 * sa_i + ks * 4 * sa_k];
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) b[p][j] = Bw[p * C::B_LDS + j * 16 * sb_j + ks * 4 * sb_k];
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if (CPLX) {
-                                acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
-                                acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[PL - 1][i], b[PL - 1][j], acc[0][i][j], 0, 0, 0);
-                                acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[PL - 1][j], acc[PL - 1][i][j], 0, 0, 0);
-                                acc[PL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[PL - 1][i], b[0][j], acc[PL - 1][i][j], 0, 0, 0);
-                            } else {
-                                acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[0][i][j], 0, 0, 0);
-                            }
-                        }
+            const int fa = (wr * TM * 16 + l15) * sa_i + l4 * sa_k, fb = (wc * TN * 16 + l15) * sb_j + l4 * sb_k;
+            if (DB) {
+                for (int k0 = 0; k0 < K; k0 += BK) {
+                    const bool more = (k0 + BK < K);
+                    if (more)
+                        load_tile(cur, k0 + BK);      // global -> registers: the next k-tile of this link ...
+                    else if (has_next)
+                        load_tile(nxt, 0);            // ... or the first k-tile of the next one
+                    mma_tile(As + img * IMG + fa, Bs + img * IMG + fb, sa_i, sa_k, sb_j, sb_k);
+                    // registers -> the OTHER image (nobody reads it: every wavefront passed the barrier that ended the k-tile which did)
+                    if (more)
+                        store_tile(cur, As + (img ^ 1) * IMG, Bs + (img ^ 1) * IMG);
+                    else if (has_next)
+                        store_tile(nxt, As + (img ^ 1) * IMG, Bs + (img ^ 1) * IMG);
+                    __syncthreads();
+                    img ^= 1;
                 }
-                __syncthreads();
+            } else {
+                for (int k0 = 0; k0 < K; k0 += BK) {
+                    store_tile(cur, As, Bs);
+                    __syncthreads();
+                    if (k0 + BK < K)
+                        load_tile(cur, k0 + BK);      // prefetch the next k-tile into registers
+                    else if (has_next)
+                        load_tile(nxt, 0);            // ... or the first k-tile of the next link
+                    mma_tile(As + fa, Bs + fb, sa_i, sa_k, sb_j, sb_k);
+                    __syncthreads();
+                }
             }
             if (!has_next) break;
             cur = nxt;
@@ -281,11 +313,11 @@ extern "C" int tpa_gemm_tile_shape(int dtype, int cfg, int *bm, int *bn) {
     return 0;
 }
 
-template <bool CPLX, int BM, int BN, int TM, int TN, int BK_>
+template <bool CPLX, int BM, int BN, int TM, int TN, int BK_, bool DB = false>
 static void launch(const int64_t *tasks_dev, const int64_t *links_dev, const int32_t *tiles_dev, int n_tiles,
                    const void *Abase, const void *Bbase, void *Cbase, hipStream_t st) {
     using C = Cfg<CPLX, BM, BN, TM, TN, BK_>;
-    gemm_chain_kernel<CPLX, BM, BN, TM, TN, BK_><<<n_tiles, C::NT, 0, st>>>(
+    gemm_chain_kernel<CPLX, BM, BN, TM, TN, BK_, DB><<<n_tiles, C::NT, 0, st>>>(
         (const Task *)tasks_dev, (const Link *)links_dev, (const int4 *)tiles_dev, (const double *)Abase,
         (const double *)Bbase, (double *)Cbase);
 }
@@ -314,9 +346,16 @@ extern "C" int tpa_gemm_chain(int dtype, int cfg, const int64_t *tasks_dev, cons
             // 6.9 -> 8.0 TFLOP/s (step 2, 69 tiles: 0.089 -> 0.075 ms), at chi = 2048 step 2 (831 tiles) 0.710 -> 0.687 ms, step 1 (4005 tiles) 0.660 -> 0.680 ms: hence the limit of 1024 tiles.  The opposite
             // direction -- ONE wavefront per 64 x 64 tile (4 x 4 MFMA tiles, half the LDS reads per MFMA) or two (4 x 2) -- is slower
             // everywhere: 24.6 / 30.8 instead of 38.7 TFLOP/s at chi = 2048: the tile's chain, not the LDS bandwidth, is the limit.
-            launch<false, 64, 64, 1, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+            (g_large_variant & 128) ? launch<false, 64, 64, 1, 2, 16, true>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st)
+                                    : launch<false, 64, 64, 1, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else if (cfg == 1)
-            launch<false, 64, 64, 2, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
+            // the default of the DMRG path.  Bit 7 (128) of tpa_gemm_set_variant switches the double-buffered loop ON (DB, round 5).
+            // Measured on the MI355X (scripts/gemm_bench.py, profiles/r05_gemm_double_buffer.txt): dense 4096^3 on 64 x 64 tiles 50.0 ->
+            // 46.2 TFLOP/s, matvec at chi = 2048 38.6 -> 35.5, at chi = 512 8.0 -> 6.8: SLOWER.  The second image takes the workgroups
+            // per CU from six (registers) to four (40 KB of LDS each), and the loop is bound by latency hiding across workgroups, not
+            // by its two barriers -- the same finding as the BK = 32 variant of round 3 (half the barriers, lower occupancy, slower).
+            (g_large_variant & 128) ? launch<false, 64, 64, 2, 2, 16, true>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st)
+                                    : launch<false, 64, 64, 2, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else if (g_large_variant & 1)
             launch<false, 128, 128, 4, 2, 16>(tasks_dev, links_dev, tiles_dev, n_tiles, Abase, Bbase, Cbase, st);
         else

@@ -219,6 +219,20 @@ extern "C" int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, con
                             void *q_base, void *r_base, void *stream) {
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
+    {   // The work areas come from hipMallocAsync / hipFreeAsync.  The default pool gives freed memory back to the OS at the next
+        // synchronisation (release threshold 0), so every call would map its ~100 MB afresh: keep what the pool has handed out.
+        static bool pool_kept = false;
+        if (!pool_kept) {
+            int devid = 0;
+            hipMemPool_t pool;
+            if (hipGetDevice(&devid) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, devid) == hipSuccess) {
+                uint64_t thr = UINT64_MAX;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+            }
+            (void)hipGetLastError();
+            pool_kept = true;
+        }
+    }
     {   // large blocks: blocked compact-WY QR on the matrix cores (tpa_svd.hip); this file's one-workgroup kernel is
         // launch-cheaper for small blocks but streams the whole trailing matrix through ONE CU per column
         int64_t kmax = 0, dmax = 0;

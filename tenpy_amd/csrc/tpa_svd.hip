@@ -2816,7 +2816,9 @@ struct PinStage {
             // sort of the singular values reads a block taken before the one that triggered the growth
             if (base != nullptr) retired.push_back(base);
             base = nullptr;
-            cap = std::max<size_t>(2 * (need + bytes), (size_t)4 << 20);
+            // (32 MB floor: a hipHostMalloc of a few MB costs ~80 ms on the MI355X box -- measured in round 5 as the one-off 80 - 90 ms
+            //  calls of scripts/svd_sketch_bench.py -- so the arena must not grow in 4 MB steps during the first calls of a process)
+            cap = std::max<size_t>(2 * (need + bytes), (size_t)32 << 20);
             if (hipHostMalloc((void **)&base, cap, hipHostMallocDefault) != hipSuccess) {
                 base = nullptr;
                 cap = 0;

@@ -31,7 +31,8 @@ from . import _device as dev
 COPY_MAXDIM = 6
 _tables = OrderedDict()
 _TABLES_MAX = 8192
-stats = {'warm_calls': 0, 'cold_calls': 0, 'e_handled': 0, 'fallbacks': 0, 'warm_sweeps': 0, 'cold_sweeps': 0,
+last_kind = 'warm'      # which warm-started variant served the most recent call ('warm': projection on the basis, 'sketch': basis as a sketch)
+stats = {'sketch_calls': 0, 'sketch_sweeps': 0, 'sk_residual': 0, 'sk_unfit': 0, 'sk_svd': 0, 'warm_calls': 0, 'cold_calls': 0, 'e_handled': 0, 'fallbacks': 0, 'warm_sweeps': 0, 'cold_sweeps': 0,
          'fb_shape': 0, 'fb_rank': 0, 'fb_svd': 0, 'fb_nomatch': 0, 'fb_stale': 0, 'mixed_calls': 0, 'e_rank_sum': 0, 'e_rel_max': 0.}
 
 
@@ -514,3 +515,190 @@ def _warm_plan_b(dtype, cplx, side, A, keep, u_off_all, v_off_all):
     return dict(idx=idx, kq=kq, kk=kk, js_off=js_off, jjobs=np.ascontiguousarray(jjobs), nJU=int(ju_off[-1]), nJV=int(jv_off[-1]),
                 nJS=int(js_off[-1]), nZ=int(zb_off[-1]), gemm_Z=gemm_Z, lowdin_args=(zb_off[:-1].copy(), kq, l, l, one),
                 copy_1=copy_1, copy_2=copy_2)
+
+
+# ======================================================================================================================
+# Round 5: the stale basis as a SKETCH -- range finder + unpivoted QR instead of the rank-revealing pivoted QR
+# ======================================================================================================================
+# A warm attempt fails when the state has moved by more than rounding noise since the bond's previous visit: the old singular
+# vectors Bq then span the ROW space of X only to ~1e-9, and the part E that they miss has no low rank (every old vector tilts a
+# little).  But the COLUMN space of X is captured exactly by a sketch through (nearly) the same vectors: with Omega = [Bq; G]
+# (G: a few random rows) the columns of Y = X Omega^H span range(X) to sigma_{k+s+1} whatever the tilt of Bq is (randomised
+# range finder with an excellent test matrix: |X - Q Q^H X| <= sigma_{r+1} (1 + |Omega_2 Omega_1^+|^2)^(1/2), and Omega_2 ~ tilt).
+#     Y = X Omega^H (p x q)          one grouped GEMM
+#     Y = Q R                          UNPIVOTED Householder QR (compact-WY panels on the MFMA; no pivot search, no norm
+#                                      downdates, and none of the pivoted QR's 8-column panels with exact norm recomputation)
+#     C = Q^H X (q x len)              one GEMM; |X - Q C|_F <= E_TOL |X|_F is CHECKED (else the call goes the cold way)
+#     C = U' S VH'                     one-sided Jacobi on the q rows of C, no further preconditioner: the Gram matrix of the rows
+#                                      of C is that of R, and R is the QR factor of nearly orthogonal columns sorted by size --
+#                                      what the pivoted QR of X would have produced (measured on the chi = 2048 blocks with the
+#                                      numpy emulation of the iteration: 4 / 6 sweeps against 7 / 6 of the cold path)
+#     X = (Q U') S VH'
+# The same stopping rule, the same clean-up, the same result layout as the cold path; the basis only decides how fast it goes.
+SKETCH = os.environ.get('TPA_SVD_SKETCH', '1') != '0'
+SKETCH_EXTRA = int(os.environ.get('TPA_SVD_SKETCH_EXTRA', '32'))        # random rows appended to the basis (covers a growing rank)
+SKETCH_RANK_TOL = float(os.environ.get('TPA_SVD_SKETCH_RANK_TOL', '1e-15'))   # rows of the small factor below this fraction of |X_b|_F are noise
+_sketch_noise = {}
+
+
+def _noise(dtype, n):
+    """``n`` i.i.d. standard normal numbers on the device (real; one seeded stream, grown on demand: any slice of it is i.i.d.)."""
+    have = _sketch_noise.get('arena')
+    if have is None or have.numel() < n:
+        n_new = max(int(n), 1 << 16)
+        rs = np.random.RandomState(20260926)
+        host = rs.standard_normal(n_new)
+        _sketch_noise['arena'] = dev.to_device(host)
+        _sketch_noise['arena_c'] = dev.to_device(host.astype(np.complex128))
+    return _sketch_noise['arena_c' if np.dtype(dtype).kind == 'c' else 'arena']
+
+
+def _sketch_plan(dtype, cplx, side, numel, offs, ms, ns, b_off, b_k, b_len, u_off_all, v_off_all, extra):
+    nb = len(ms)
+    R = side == 'R'
+    ps_all, ls_all, kk_all = (ms, ns, np.minimum(ms, ns)) if R else (ns, ms, np.minimum(ms, ns))
+    fit = (b_k > 0) & (b_k <= kk_all) & (b_len == ls_all)
+    pl = dict(ok=False)
+    if not np.all(fit):
+        return pl
+    if not (np.array_equal(offs, np.concatenate([[0], np.cumsum(ms * ns)[:-1]])) and int(np.sum(ms * ns)) == numel):
+        return pl
+    o, m, n, p, l, kk, k, boff = offs, ms, ns, ps_all, ls_all, kk_all, b_k, b_off
+    z = np.zeros(nb, dtype=np.int64)
+    one = z + 1
+    q = np.minimum(k + extra, kk)                       # sketch columns = rows of the Jacobi problem
+    s = q - k
+    x_rs, x_cs = (n, one) if R else (one, n)            # X(j, c) = A[o + j x_rs + c x_cs]
+    om_off = np.concatenate([[0], np.cumsum(q * l)])
+    y_off = np.concatenate([[0], np.cumsum(p * q)])
+    c_off = np.concatenate([[0], np.cumsum(q * l)])
+    ju_off = np.concatenate([[0], np.cumsum(q * q)])
+    js_off = np.concatenate([[0], np.cumsum(q)])
+    conjA, conjB = (1 if cplx else 0), (2 if cplx else 0)
+    # Omega = [Bq ; G]
+    copy_B = copy_table(copy_jobs_2d(om_off[:-1], l, one, boff, l, one, k, l))
+    g_src = np.concatenate([[0], np.cumsum(s * l)])
+    copy_G = copy_table(copy_jobs_2d(om_off[:-1] + k * l, l, one, g_src[:-1], l, one, s, l))
+    # Y = X Omega^H (p x q, row-major)
+    gemm_Y = gemm_table(dtype, np.stack([y_off[:-1], p, q, q, o, x_rs, x_cs, om_off[:-1], one, l, l, z + conjB], axis=1))
+    # QR jobs of tpa_qr_batch: (a_off, m, n, q_off, r_off) -- Q (p x q) and R (q x q) in their own arenas
+    r_off = np.concatenate([[0], np.cumsum(q * q)])
+    qr_jobs = np.zeros((nb, 8), dtype=np.int64)
+    qr_jobs[:, 0], qr_jobs[:, 1], qr_jobs[:, 2], qr_jobs[:, 3], qr_jobs[:, 4] = y_off[:-1], p, q, y_off[:-1], r_off[:-1]      # (Q in the layout of Y)
+    # C = Q^H X (q x l)
+    gemm_C = gemm_table(dtype, np.stack([c_off[:-1], q, l, l, y_off[:-1], one, q, o, x_rs, x_cs, p, z + conjA], axis=1))
+    # P = Q C in the layout of A (for E = A - P on the flat arena)
+    if R:
+        gemm_P = gemm_table(dtype, np.stack([o, m, n, n, y_off[:-1], q, one, c_off[:-1], l, one, q, z], axis=1))
+    else:       # P_A = (Q C)^T = C^T Q^T   (m x n = l x p)
+        gemm_P = gemm_table(dtype, np.stack([o, m, n, n, c_off[:-1], one, l, y_off[:-1], one, q, q, z], axis=1))
+    # Jacobi on the rows of C
+    jjobs = np.zeros((nb, 8), dtype=np.int64)
+    jjobs[:, 0], jjobs[:, 1], jjobs[:, 2] = c_off[:-1], q, l
+    jjobs[:, 3], jjobs[:, 4], jjobs[:, 5] = ju_off[:-1], js_off[:-1], c_off[:-1]
+    jjobs[:, 6] = 1
+    u_off, v_off = np.asarray(u_off_all, dtype=np.int64), np.asarray(v_off_all, dtype=np.int64)
+    if R:       # U_A = Q U' (m x q into m x kk),  VH_A = VH' (q x n)
+        gemm_T = gemm_table(dtype, np.stack([u_off, p, q, kk, y_off[:-1], q, one, ju_off[:-1], q, one, q, z], axis=1))
+        copy_V = copy_table(copy_jobs_2d(v_off, n, one, c_off[:-1], l, one, q, l))
+    else:       # A = X^T = VH'^T S (Q U')^T:  U_A[r][i] = VH'[i][r],  VH_A = U'^T Q^T (q x n)
+        gemm_T = gemm_table(dtype, np.stack([v_off, q, p, n, ju_off[:-1], one, q, y_off[:-1], one, q, q, z], axis=1))
+        copy_V = copy_table(copy_jobs_2d(u_off, kk, one, c_off[:-1], one, l, l, q))
+    pl.update(ok=True, q=q, kk=kk, nOm=int(om_off[-1]), nY=int(y_off[-1]), nC=int(c_off[-1]), nR=int(r_off[-1]), nJU=int(ju_off[-1]),
+              nJS=int(js_off[-1]), nG=int(g_src[-1]), js_off=js_off, copy_B=copy_B, copy_G=copy_G, gemm_Y=gemm_Y,
+              qr_jobs=np.ascontiguousarray(qr_jobs), gemm_C=gemm_C, gemm_P=gemm_P, jjobs=np.ascontiguousarray(jjobs), gemm_T=gemm_T,
+              copy_V=copy_V, norms=_row_norms_plan(o, m, n), crow=_row_norms_plan(c_off[:-1], q, l),
+              cut_jobs=dev.to_device(np.stack([c_off[:-1], one, q, l, js_off[:-1], z], axis=1)), cut_max=int(np.max(q * l)))
+    return pl
+
+
+def svd_blocks_sketch(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, side, run_svd, out):
+    """Block SVD with the cached bases used as a SKETCH (see the comment above): all blocks or none.  Arguments as
+    :func:`svd_blocks_warm`; returns ``S`` (list of per-block singular values, zero-padded to ``min(m, n)``) or None -> cold path."""
+    dtype = np.dtype(dtype)
+    cplx = dtype.kind == 'c'
+    offs, ms, ns, b_off, b_k, b_len = (np.ascontiguousarray(x, dtype=np.int64) for x in (offs, ms, ns, b_off, b_k, b_len))
+    U_arena, V_arena, u_off_all, v_off_all = out
+    key = _key('sketch', dtype.str, side, int(a_arena.numel()), offs, ms, ns, b_off, b_k, b_len,
+               np.ascontiguousarray(u_off_all, dtype=np.int64), np.ascontiguousarray(v_off_all, dtype=np.int64), SKETCH_EXTRA)
+    pl = _plan_get(key)
+    if pl is None:
+        pl = _plan_put(key, _sketch_plan(dtype, cplx, side, int(a_arena.numel()), offs, ms, ns, b_off, b_k, b_len, u_off_all, v_off_all,
+                                         SKETCH_EXTRA))
+    if not pl['ok']:
+        stats['sk_unfit'] = stats.get('sk_unfit', 0) + 1
+        return None
+    if PROFILE:
+        _tick(None)
+    L = dev.lib()
+    Om = dev.scratch('sk_Om', pl['nOm'], dtype)
+    run_copy(dtype, pl['copy_B'], b_arena, Om)
+    if pl['nG']:
+        run_copy(dtype, pl['copy_G'], _noise(dtype, pl['nG']), Om)
+    Y = dev.scratch('sk_Y', pl['nY'], dtype)
+    run_gemm(dtype, pl['gemm_Y'], a_arena, Om, Y)
+    Rq = dev.scratch('sk_R', pl['nR'], dtype)
+    nb = len(ms)
+    Q = dev.scratch('sk_Q', pl['nY'], dtype)
+    dev.check(L.tpa_qr_batch(dev.code(dtype), pl['qr_jobs'].ctypes.data, nb, Y.data_ptr(), Q.data_ptr(), Rq.data_ptr(), dev.stream()), "qr_batch")
+    C = dev.scratch('sk_C', pl['nC'], dtype)
+    run_gemm(dtype, pl['gemm_C'], Q, a_arena, C)
+    P = dev.scratch('warm_P', a_arena.numel(), dtype)
+    run_gemm(dtype, pl['gemm_P'], Q if side == 'R' else C, C if side == 'R' else Q, P)
+    E = dev.scratch('warm_E', a_arena.numel(), dtype)
+    E.copy_(a_arena)
+    _axpy(dtype, -1.0, P, E)
+    nE = _row_norms_launch(dtype, E, pl['norms'])
+    nA = _row_norms_launch(dtype, a_arena, pl['norms'])
+    nC = _row_norms_launch(dtype, C, pl['crow'])
+    nrm, nrmA = _row_norms_read(nE, pl['norms']), _row_norms_read(nA, pl['norms'])        # (one wait for the three)
+    c_rows = dev.to_host(nC)[:pl['crow'][3]]
+    ok = np.isfinite(nrm) & np.isfinite(nrmA) & (nrmA > 0.)
+    e_rel = np.where(ok, np.sqrt(np.where(ok, nrm, 0.) / np.where(ok, nrmA, 1.)), np.inf)
+    stats['sk_e_rel_last'] = float(np.max(np.where(np.isfinite(e_rel), e_rel, 1.)))
+    if DEBUG:
+        print('sketch e_rel', np.array2string(e_rel, precision=1), 'q', pl['q'], 'kk', pl['kk'], flush=True)
+    if PROFILE:
+        _tick('t_sketch_qr')
+    if not np.all(e_rel <= E_TOL):
+        stats['sk_residual'] = stats.get('sk_residual', 0) + 1
+        return None
+    # numerical rank: the rows of C below SKETCH_RANK_TOL |X_b|_F are rounding noise of the sketch (it is k + extra wide, the rank is
+    # not) -- set to exact zeros, which the iteration skips (null-row cut of the stopping rule).  Left in, the iteration spends its
+    # sweeps making that noise orthogonal to itself (measured on the chi = 2048 theta: 9 sweeps instead of 4 - 6).  It is the decision the
+    # pivoted QR of the cold path takes with its residual column norms (QRP_RANK_TOL, same 1e-15): what is dropped has
+    # Frobenius mass <= sqrt(q) 1e-15 |X_b|_F, inside E_TOL.
+    keep_rows = c_rows > (SKETCH_RANK_TOL ** 2) * np.repeat(nrmA, pl['q'])
+    stats['sk_rows_cut'] = stats.get('sk_rows_cut', 0) + int(np.sum(~keep_rows))
+    if not np.all(keep_rows):
+        mask = dev.to_device(keep_rows.astype(np.float64))
+        dev.check(L.tpa_scale_axis_batch(dev.code(dtype), pl['cut_jobs'].data_ptr(), nb, pl['cut_max'], C.data_ptr(), mask.data_ptr(), 0,
+                                         dev.stream()), "scale_axis")
+    if PROFILE:
+        _tick('t_sketch_cut')
+    JU = dev.scratch('warm_JU', pl['nJU'], dtype)
+    JS = dev.scratch('warm_JS', pl['nJS'], np.float64)
+    JV = dev.scratch('warm_JV', pl['nC'], dtype)
+    if PROFILE:
+        _tick('t_sketch_scratch')
+    S_J = run_svd(pl['jjobs'], C, JU, JS, JV, False)
+    if PROFILE:
+        _tick('t_sketch_jacobi')
+    if S_J is None:
+        stats['sk_svd'] = stats.get('sk_svd', 0) + 1
+        return None
+    if side == 'R':
+        run_gemm(dtype, pl['gemm_T'], Q, JU, U_arena)
+        run_copy(dtype, pl['copy_V'], JV, V_arena)
+    else:
+        run_gemm(dtype, pl['gemm_T'], JU, Q, V_arena)
+        run_copy(dtype, pl['copy_V'], JV, U_arena)
+    if PROFILE:
+        _tick('t_sketch_out')
+    js_off, q, kk = pl['js_off'], pl['q'], pl['kk']
+    S_out = []
+    for b in range(nb):
+        sb = np.zeros(int(kk[b]), dtype=np.float64)
+        sb[:q[b]] = S_J[js_off[b]:js_off[b + 1]]
+        S_out.append(sb)
+    return S_out

@@ -2557,6 +2557,8 @@ def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, swe
     chain = SVD_ALGORITHM_CHAIN if chain is None else chain
     wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
     work = dev.scratch('svd_work', int(wb), np.uint8)
+    if _svd_warm.PROFILE:
+        _svd_warm._tick('t_svd_worksize_scratch')
     tried = []
     last_err = None
     for hop, alg in enumerate(chain):
@@ -2575,6 +2577,8 @@ def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, swe
         finally:
             if hop or alg != SVD_ALGORITHM_CHAIN[0]:
                 L.tpa_svd_set_algorithm(SVD_ALGORITHM_CHAIN[0])
+            if _svd_warm.PROFILE:
+                _svd_warm._tick('t_svd_batch_call')
         svd_robust_stats['last_chain'] = tuple(tried)
         if rc == dev.E_NOCONV:
             last_err = "no convergence"
@@ -2739,6 +2743,24 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
                                                (U_arena, V_arena, u_offs[:-1], v_offs[:-1]),
                                                lowdin_basis=(age % 8 == 0), need_all=(SVD_WARM_MAX_COLD_FRACTION <= 0.))
     cold = np.nonzero(~done)[0]
+    if len(cold) and _svd_warm.SKETCH and np.all(found) and not np.any(done):
+        # stale basis (the state moved since the bond's previous visit): it still is an excellent SKETCH of the column space --
+        # range finder + unpivoted QR + Jacobi on the small factor instead of the pivoted QR of the cold path (round 5, _svd_warm.py)
+        S_blocks = _svd_warm.svd_blocks_sketch(a.dtype, a._arena, offs, ms, ns, basis.arena, b_off, b_k, b_len, side, run_svd,
+                                               (U_arena, V_arena, u_offs[:-1], v_offs[:-1]))
+        if S_blocks is not None:
+            S_host = np.concatenate(S_blocks) if len(S_blocks) else np.zeros(0)
+            S_dev = dev.to_device(S_host)
+            sweeps.value = total_sweeps[0]
+            _svd_warm.ages[key] = 0
+            _svd_warm.stats['sketch_calls'] = _svd_warm.stats.get('sketch_calls', 0) + 1
+            _svd_warm.stats['sketch_sweeps'] = _svd_warm.stats.get('sketch_sweeps', 0) + total_sweeps[0]
+            _svd_warm.last_kind = 'sketch'
+            if _svd_floor_now[0] > 0. and SVD_LOWDIN_ITERATIONS > 0:
+                # the normalised Jacobi rows VH' are VH (side 'R') or the columns of U (side 'L')
+                _svd_clean_small(a.dtype, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs, v_offs, np.full(nblk, side == 'R'))
+            return U_arena, S_dev, V_arena, S_host
+        total_sweeps[0] = 0
     if len(cold) and np.sum(weight[cold]) > SVD_WARM_MAX_COLD_FRACTION * np.sum(weight):
         _svd_warm.stats['fallbacks'] += 1
         # try again after a few visits: the residual of a converging state shrinks by roughly a decade per sweep
@@ -2765,6 +2787,7 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
     _svd_warm.ages[key] = age
     _svd_warm.stats['warm_calls'] += 1
     _svd_warm.stats['warm_sweeps'] += total_sweeps[0]
+    _svd_warm.last_kind = 'warm'
     if _svd_floor_now[0] > 0. and SVD_LOWDIN_ITERATIONS > 0:
         # the normalised Jacobi rows VH' end up in U (side 'R') or VH (side 'L'); mixed calls: treat both factors
         y_vh = None if len(cold) else np.full(nblk, side == 'L')
@@ -3008,7 +3031,7 @@ def svd(a, full_matrices=False, compute_uv=True, cutoff=None, qtotal_LR=[None, N
         t0 = tick('t_store', t0)
     if ev_svd is not None:
         svd_timer.end(ev_svd, svd_work(ms, ns, a.dtype.itemsize, a.dtype.kind == 'c'),
-                      ('warm' if warm is not None else ('cold after a stale warm attempt' if tried_warm else 'cold'), sweeps.value, int(np.max(ks))))
+                      (_svd_warm.last_kind if warm is not None else ('cold after a stale warm attempt' if tried_warm else 'cold'), sweeps.value, int(np.max(ks))))
     svd_stats['calls'] += 1
     svd_stats['sweeps'] += sweeps.value
     svd_stats['max_block'] = max(svd_stats['max_block'], int(np.max(ks)))

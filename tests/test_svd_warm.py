@@ -45,9 +45,11 @@ def _check(a_dense, legL, legR, U, S, VH, tol=2e-13):
     assert np.abs(Vd[keep] @ Vd[keep].conj().T - np.eye(keep.sum())).max() < 1e-12
 
 
+@pytest.mark.parametrize("sketch", [True, False])
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("side", ['R', 'L'])
-def test_warm_start_matches_lapack(backend, side, cplx):
+def test_warm_start_matches_lapack(backend, side, cplx, sketch, monkeypatch):
+    monkeypatch.setattr(_svd_warm, 'SKETCH', sketch)       # round 5: a stale basis is used as a sketch (off: the round-4 behaviour)
     rng = np.random.RandomState(5)
     sizes_l, sizes_r = [40, 70, 9, 33], [52, 70, 17, 20]
     dense, legL, legR = _blocked(rng, sizes_l, sizes_r, cplx=cplx)
@@ -83,8 +85,12 @@ def test_warm_start_matches_lapack(backend, side, cplx):
     npc.svd_hint = ('bond', side)
     U, S, VH = npc.svd(a3)
     _check(d3, legL, legR, U, S, VH)
-    assert _svd_warm.stats['warm_calls'] == 1 and _svd_warm.stats['fallbacks'] == 1 and _svd_warm.stats['fb_stale'] > 0
-    assert _svd_warm.cooldown.get('bond', 0) > 0       # the next visits do not even try
+    assert _svd_warm.stats['warm_calls'] == 1 and _svd_warm.stats['fb_stale'] > 0
+    if sketch:      # the stale basis + 32 random rows still sketch the column space: no pivoted QR, no cold call
+        assert _svd_warm.stats['sketch_calls'] == 1 and _svd_warm.stats['fallbacks'] == 0 and _svd_warm.stats['cold_calls'] == 1
+    else:
+        assert _svd_warm.stats['fallbacks'] == 1
+        assert _svd_warm.cooldown.get('bond', 0) > 0       # the next visits do not even try
     _svd_warm.cooldown.clear()
     # the decomposition of d3 is the new basis: d3 again starts warm
     npc.svd_hint = ('bond', side)
@@ -97,7 +103,9 @@ def test_warm_start_matches_lapack(backend, side, cplx):
     npc.svd_hint = ('bond', side)
     U, S, VH = npc.svd(a4)
     _check(d4, legL, legR, U, S, VH)
-    assert _svd_warm.stats['fallbacks'] == 2
+    # (with the sketch: every block is small enough for basis + 32 random rows to be a COMPLETE sketch, so Q is square and the
+    # decomposition exact whatever the basis was)
+    assert (_svd_warm.stats['sketch_calls'] == 2 and _svd_warm.stats['fallbacks'] == 0) if sketch else _svd_warm.stats['fallbacks'] == 2
     _svd_warm.cooldown.clear()
     # (4) other leg structure under the same key: no basis
     d5, l5, r5 = _blocked(rng, [30, 21], [30, 40], cplx=cplx)
@@ -105,6 +113,50 @@ def test_warm_start_matches_lapack(backend, side, cplx):
     U, S, VH = npc.svd(npc.Array.from_ndarray(d5, [l5, r5]))
     _check(d5, l5, r5, U, S, VH)
     assert npc.svd_hint is None
+    _svd_warm.cache_clear()
+
+
+@pytest.mark.parametrize("side", ['R', 'L'])
+def test_sketch_path(backend, side, monkeypatch):
+    """Round 5: a STALE basis as a sketch of the column space (range finder + unpivoted QR + Jacobi on the small factor).  Every
+    old vector tilted by 1e-8 and a handful of new directions: the plain warm attempt fails its residual test, the sketch passes
+    it at rounding level and the result equals LAPACK's; when the rank outgrows basis + extra rows the residual test of the sketch
+    sends the call to the cold path."""
+    monkeypatch.setattr(_svd_warm, 'SKETCH', True)
+    rng = np.random.RandomState(11)
+    sizes_l, sizes_r = [150, 96, 40], [140, 120, 33]
+    dense, legL, legR = _blocked(rng, sizes_l, sizes_r, rank_frac=0.5)
+    _svd_warm.cache_clear()
+    for k in list(_svd_warm.stats):
+        _svd_warm.stats[k] = 0
+    npc.svd_hint = ('bond', side)
+    npc.svd(npc.Array.from_ndarray(dense, [legL, legR]))
+    assert _svd_warm.stats['cold_calls'] == 1
+    d2 = dense.copy()
+    for q in range(legL.block_number):
+        sl = (slice(legL.slices[q], legL.slices[q + 1]), slice(legR.slices[q], legR.slices[q + 1]))
+        m, n = dense[sl].shape
+        rotL, _ = np.linalg.qr(np.eye(m) + 1e-8 * rng.standard_normal((m, m)))
+        rotR, _ = np.linalg.qr(np.eye(n) + 1e-8 * rng.standard_normal((n, n)))
+        x = rng.standard_normal((m, 5)) @ rng.standard_normal((5, n))
+        d2[sl] = rotL @ dense[sl] @ rotR + 1e-9 * x / np.abs(x).max()
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(npc.Array.from_ndarray(d2, [legL, legR]))
+    _check(d2, legL, legR, U, S, VH)
+    st = _svd_warm.stats
+    assert st['sketch_calls'] == 1 and st['warm_calls'] == 0 and st['cold_calls'] == 1 and st['fb_stale'] > 0
+    assert st['sk_e_rel_last'] < 1e-14                     # the range finder is exact to rounding, not to the tilt
+    # the result of the sketch call is the next basis: the same matrix again starts warm
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(npc.Array.from_ndarray(d2, [legL, legR]))
+    _check(d2, legL, legR, U, S, VH)
+    assert st['warm_calls'] == 1
+    # rank growth beyond basis + extra rows: full-rank blocks under the same key -> residual test of the sketch fails -> cold
+    d3, _, _ = _blocked(np.random.RandomState(2), sizes_l, sizes_r, rank_frac=1.0, decay=3.)
+    npc.svd_hint = ('bond', side)
+    U, S, VH = npc.svd(npc.Array.from_ndarray(d3, [legL, legR]))
+    _check(d3, legL, legR, U, S, VH)
+    assert st.get('sk_residual', 0) == 1 and st['cold_calls'] == 2 and st['sketch_calls'] == 1
     _svd_warm.cache_clear()
 
 
