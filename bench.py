@@ -325,6 +325,8 @@ def run(argv=None, emit=True):
     from tenpy_amd.linalg._device import lib as dev_lib
     L, chi = args.L, args.chi
     is_tebd = args.config == 'tebd1024'
+    if os.environ.get('TPA_QR_ALG'):         # measurement knob: 2 = the two-launches-per-panel QR of rounds 2-4 (tpa_qr_set_algorithm)
+        dev_lib().tpa_qr_set_algorithm(int(os.environ['TPA_QR_ALG']))
     t_prep = time.time()
     if is_tebd:
         eng, ramp_E = build_tebd(args), []

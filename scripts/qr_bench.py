@@ -23,9 +23,11 @@ Q = torch.zeros(q_off, dtype=dt).cuda()
 R = torch.zeros(r_off, dtype=dt).cuda()
 jh = np.array(jobs, np.int64)
 st = torch.cuda.current_stream().cuda_stream
-for mode, name in ((0, 'blocked WY'), (1, 'one workgroup')):
+for mode, name in ((0, 'WY, 1 launch/panel'), (2, 'WY, 2 launches/panel'), (1, 'one workgroup')):
     lib.tpa_qr_set_algorithm(mode)
-    for rep in range(2):
+    if mode == 1 and max(m for m, _ in shapes) * (16 if cplx else 8) > 150 * 1024:
+        continue                 # (the one-workgroup kernel keeps a column in LDS)
+    for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.time()
         rc = lib.tpa_qr_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), Q.data_ptr(), R.data_ptr(), st)
@@ -35,6 +37,6 @@ for mode, name in ((0, 'blocked WY'), (1, 'one workgroup')):
     k = min(m, n)
     q = Q[:m * k].reshape(m, k)
     r = R[:k * n].reshape(k, n)
-    print("%-14s %s %s rc=%d  %.2f ms   |QR-A|=%.1e  |Q^HQ-1|=%.1e" % (name, 'c128' if cplx else 'f64', shapes, rc, dt_s * 1e3,
+    print("%-22s %s %s rc=%d  %.2f ms   |QR-A|=%.1e  |Q^HQ-1|=%.1e" % (name, 'c128' if cplx else 'f64', shapes, rc, dt_s * 1e3,
           float((q @ r - mats[0].cuda()).abs().max()), float((q.conj().T @ q - torch.eye(k, dtype=dt, device='cuda')).abs().max())), flush=True)
 lib.tpa_qr_set_algorithm(0)

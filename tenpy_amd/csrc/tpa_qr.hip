@@ -209,8 +209,11 @@ int tpa_qr_wy_internal(int dtype, const int64_t *jobs_host, int n_jobs, const vo
                        void *stream);
 int tpa_qr_use_wy = 1;   // test hook (tpa_qr_set_algorithm): 0 = always the one-workgroup kernel
 
+int tpa_qr_lookahead = 1;      // one launch per panel (real data, tpa_qr_la.inc in tpa_svd.hip); bit 1 of tpa_qr_set_algorithm = the two-kernel path of rounds 2-4
+
 extern "C" int tpa_qr_set_algorithm(int v) {
     tpa_qr_use_wy = (v & 1) ? 0 : 1;
+    tpa_qr_lookahead = (v & 2) ? 0 : 1;
     return 0;
 }
 

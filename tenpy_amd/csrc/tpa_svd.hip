@@ -24,6 +24,8 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+extern int tpa_qr_lookahead;      // tpa_qr.hip: real data, blocks of <= 2048 rows: one launch per panel (tpa_qr_la.inc)
+
 namespace {
 
 constexpr int NT = 256;  // 4 wavefronts = 4 row pairs per workgroup
@@ -1692,16 +1694,16 @@ __global__ __launch_bounds__(NTP) void qrp_panel_kernel(const QrpJob *__restrict
 // Returns (NORMS) sum_{i >= kend} C[i, j]^2 of the updated tile column j = j0 + (lane & 15), valid in threads < 16.
 constexpr int NTR = 1024, RCOLS = 16;
 
-template <int NB>
+template <int NB, int NTH = NTR>
 struct WySmem {
-    double red[NTR / 64][NB][RCOLS];
+    double red[NTH / 64][NB][RCOLS];
     double Y[NB][RCOLS], Z[NB][RCOLS], T[NB][NB];
-    double nrm[NTR / 64][RCOLS];
+    double nrm[NTH / 64][RCOLS];
 };
 
-template <int NB, bool TRANS, bool NORMS>
+template <int NB, bool TRANS, bool NORMS, int NTH = NTR>
 __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t cs, int64_t k0, int64_t M, int64_t j0, int64_t jend,
-                                                const double *__restrict__ V, int nb, int64_t kend, WySmem<NB> &sm,
+                                                const double *__restrict__ V, int nb, int64_t kend, WySmem<NB, NTH> &sm,
                                                 bool col_ok = true) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lo = lane & 15, kq = lane >> 4;
@@ -1709,7 +1711,7 @@ __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t 
     const bool jok = (j < jend) && col_ok;
     // ---- pass 1: Y(l, j) = sum_i V(l, i) C(i, j)
     d4 acc = {0, 0, 0, 0};
-    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 16 * (NTR / 64)) {
+    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 16 * (NTH / 64)) {
         double a[4], bb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1729,7 +1731,7 @@ __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t 
         const int l = threadIdx.x >> 4, c = threadIdx.x & 15;
         double t = 0;
 #pragma unroll
-        for (int q = 0; q < NTR / 64; ++q) t += sm.red[q][l][c];
+        for (int q = 0; q < NTH / 64; ++q) t += sm.red[q][l][c];
         sm.Y[l][c] = t;
     }
     __syncthreads();
@@ -1747,12 +1749,12 @@ __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t 
     // ---- pass 2: two 16-row slabs per iteration (all loads before the stores: the compiler cannot prove that the
     //      stores of one slab do not alias the loads of the next)
     double nrm = 0;
-    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 2 * 16 * (NTR / 64)) {
+    for (int64_t i0 = k0 + 16 * wave; i0 < M; i0 += 2 * 16 * (NTH / 64)) {
         d4 c[2];
         double av[2][NB / 4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int64_t ib = i0 + (int64_t)h * 16 * (NTR / 64);
+            const int64_t ib = i0 + (int64_t)h * 16 * (NTH / 64);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int64_t i = ib + kq + 4 * reg;
@@ -1771,7 +1773,7 @@ __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t 
             for (int q = 0; q < NB / 4; ++q) c[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][q], zneg[q], c[h], 0, 0, 0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int64_t ib = i0 + (int64_t)h * 16 * (NTR / 64);
+            const int64_t ib = i0 + (int64_t)h * 16 * (NTH / 64);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int64_t i = ib + kq + 4 * reg;
@@ -1790,7 +1792,7 @@ __device__ __forceinline__ double wy_apply_tile(double *Cb, int64_t rs, int64_t 
     double t = 0;
     if (threadIdx.x < RCOLS) {
 #pragma unroll
-        for (int q = 0; q < NTR / 64; ++q) t += sm.nrm[q][threadIdx.x];
+        for (int q = 0; q < NTH / 64; ++q) t += sm.nrm[q][threadIdx.x];
     }
     return t;
 }
@@ -3612,6 +3614,8 @@ __global__ __launch_bounds__(NT) void qr_copy_q_kernel(const QrpJob *__restrict_
     }
 }
 
+#include "tpa_qr_la.inc"
+
 template <bool CPLX>
 int qr_run_wy(const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base, void *r_base, hipStream_t st) {
     const int64_t esz = CPLX ? 16 : 8;
@@ -3654,7 +3658,7 @@ int qr_run_wy(const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_
                   off_cn = take(c_elems * 8), off_cperm = take(c_elems * 8), off_qj = take(n_jobs * sizeof(QrpJob)),
                   off_sj = take(n_jobs * sizeof(SvdJob)), off_state = take(n_jobs * sizeof(QrpState)),
                   off_fro = take(n_jobs * 8), off_qo = take(n_jobs * 8), off_tfac = take(tf_blocks * QNB * QNB * esz),
-                  off_tpan = take((int64_t)n_jobs * PNB * PNB * esz);
+                  off_tpan = take(2 * (int64_t)n_jobs * PNB * PNB * esz);      // (two slots: the look-ahead path ping-pongs)
     char *work = nullptr;
     TPA_HIP_CHECK(hipMallocAsync((void **)&work, (size_t)o, st));
     void *X = work + off_x, *Vall = work + off_v, *tau = work + off_tau, *Tfac = work + off_tfac, *Tpan = work + off_tpan;
@@ -3680,7 +3684,22 @@ int qr_run_wy(const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_
         else
             qrp_init_kernel<<<gcol, NT, 0, st>>>(qjobs, sjobs, (const double *)a_base, (double *)X, cn, cperm, state);
         const int tiles = (int)((nmax + RCOLS - 1) / RCOLS);
-        for (int k = 0;; k += PNB) {
+        bool tall = true;      // (wide blocks have columns beyond the last panel that belong to neither role of the fused step)
+        for (int b = 0; b < n_jobs; ++b) tall = tall && (qj[b].M >= qj[b].N);
+        const bool lookahead = !CPLX && tpa_qr_lookahead && tall && mmax <= (int64_t)QLA_RPT * NTQ;
+        if (lookahead) {
+            // one launch per panel: workgroup 0 of every block updates + factorises panel k + 1, the others apply panel k behind it
+            for (int k = -PNB; k < kmax; k += PNB) {
+                const int64_t j_first = (k < 0) ? 0 : ((int64_t)k + 2 * PNB) / RCOLS * RCOLS;
+                const int upd = (k < 0 || j_first >= nmax) ? 0 : (int)((nmax - j_first + RCOLS - 1) / RCOLS);
+                qr_la_step_kernel<<<dim3(1 + upd, n_jobs), NTQ, 0, st>>>(qjobs, k, (double *)X, (double *)Vall, (double *)tau, (double *)Tpan,
+                                                                        n_jobs, j_first);
+            }
+            // (the states: rank = min(m, n) for every block -- the two-kernel path's final panel launch does exactly that)
+            qrp_panel_kernel<256, 8><<<n_jobs, 256, 0, st>>>(qjobs, (int)((kmax + PNB - 1) / PNB * PNB), (double *)X, (double *)Vall, cn, (double *)tau,
+                                                            cperm, state, fro2, 0.0, (double *)Tpan, 0);
+        }
+        for (int k = 0; !lookahead; k += PNB) {
             if (CPLX) {
                 if (mmax <= 4 * 256)
                     qrp_panel_kernel_c<256, 4><<<n_jobs, 256, 0, st>>>(qjobs, k, (cd *)X, (cd *)Vall, cn, (cd *)tau, cperm, state, fro2, 0.0, (cd *)Tpan, 0);

@@ -537,6 +537,12 @@ def _warm_plan_b(dtype, cplx, side, A, keep, u_off_all, v_off_all):
 # The same stopping rule, the same clean-up, the same result layout as the cold path; the basis only decides how fast it goes.
 SKETCH = os.environ.get('TPA_SVD_SKETCH', '1') != '0'
 SKETCH_EXTRA = int(os.environ.get('TPA_SVD_SKETCH_EXTRA', '32'))        # random rows appended to the basis (covers a growing rank)
+# The sketch is tried only when the plain warm attempt missed by LESS than this (|E|_F / |X|_F of its worst block).  A larger miss
+# means the state is being rebuilt, not drifting -- the chi ramp, the first sweeps at a new chi: the rank outgrows basis + extra
+# rows, the sketch's own residual test fails after ~5 ms of QR, and the call goes cold anyway (measured on the driver protocol:
+# ramp sweep at chi = 1024 2.05 -> 2.33 s, first target-chi sweep 3.59 -> 3.91 s without this gate; 169 of 561 attempts of the module
+# form's run failed that way).
+SKETCH_MAX_E = float(os.environ.get('TPA_SVD_SKETCH_MAX_E', '1e-5'))
 SKETCH_RANK_TOL = float(os.environ.get('TPA_SVD_SKETCH_RANK_TOL', '1e-15'))   # rows of the small factor below this fraction of |X_b|_F are noise
 _sketch_noise = {}
 

@@ -2402,7 +2402,7 @@ def trace(a, leg1=0, leg2=1):
 # (`_svd_warm.lowdin_rows`; changes U S VH by <= eps*rho*||A||), so that every returned vector is orthonormal to machine
 # precision like LAPACK's (VERDICT r2 "What's weak") at the sweep count of the floor.  Set SVD_ABS_FLOOR = 0. for
 # the purely relative Hestenes criterion (no clean-up needed).
-SVD_ABS_FLOOR = 1.e-6
+SVD_ABS_FLOOR = float(os.environ.get('TPA_SVD_ABS_FLOOR', '1e-6'))      # (the environment variable: measurement knob)
 # Round 4 (VERDICT r3 task 7): the floor is an opt-in of the callers that can afford it -- the DMRG / TEBD drivers, which
 # truncate right afterwards and mark their call (``svd_hint`` of the engines, or ``svd_engine_floor = True`` for one call).  Every
 # other ``npc.svd`` (an unmodified TeNPy module calling it for its own purposes) runs the purely relative criterion: every returned
@@ -2743,7 +2743,7 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
                                                (U_arena, V_arena, u_offs[:-1], v_offs[:-1]),
                                                lowdin_basis=(age % 8 == 0), need_all=(SVD_WARM_MAX_COLD_FRACTION <= 0.))
     cold = np.nonzero(~done)[0]
-    if len(cold) and _svd_warm.SKETCH and np.all(found) and not np.any(done):
+    if len(cold) and _svd_warm.SKETCH and np.all(found) and not np.any(done) and _svd_warm.stats.get('e_rel_last', 1.) <= _svd_warm.SKETCH_MAX_E:
         # stale basis (the state moved since the bond's previous visit): it still is an excellent SKETCH of the column space --
         # range finder + unpivoted QR + Jacobi on the small factor instead of the pivoted QR of the cold path (round 5, _svd_warm.py)
         S_blocks = _svd_warm.svd_blocks_sketch(a.dtype, a._arena, offs, ms, ns, basis.arena, b_off, b_k, b_len, side, run_svd,

@@ -437,6 +437,48 @@ def test_qr_batch(env, cplx, wy):
             assert (r - r_old).abs().max().item() < 1e-12 * max(m, n)
 
 
+def test_qr_lookahead(env):
+    """Round 5: one launch per panel for tall real blocks (csrc/tpa_qr_la.inc: workgroup 0 updates and factorises the next panel while
+    the others apply the current one) against the two-launches-per-panel path of rounds 2-4 and against the definition."""
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(12)
+    shapes = [(50, 50), (130, 40), (300, 200), (257, 64), (1100, 600), (64, 64), (40, 33), (2048, 100), (9, 8), (35, 35)]
+    mats = [torch.randn(m, n, dtype=torch.float64, generator=g) for (m, n) in shapes]
+    mats[2][:, 5] = mats[2][:, 4]           # linearly dependent columns
+    mats[4] = mats[4] * torch.logspace(0, -14, 600, dtype=torch.float64)        # graded columns, like the sketch of a DMRG theta
+    jobs, a_off, q_off, r_off = [], 0, 0, 0
+    for (m, n) in shapes:
+        jobs.append([a_off, m, n, q_off, r_off, 0, 0, 0])
+        a_off, q_off, r_off = a_off + m * n, q_off + m * n, r_off + n * n
+    A = torch.cat([x.reshape(-1) for x in mats]).cuda()
+    jh = np.array(jobs, np.int64)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for mode in (0, 2):
+        lib.tpa_qr_set_algorithm(mode)
+        try:
+            Q = torch.zeros(q_off, dtype=torch.float64).cuda()
+            R = torch.zeros(r_off, dtype=torch.float64).cuda()
+            _lib.check(lib.tpa_qr_batch(0, jh.ctypes.data, len(jobs), A.data_ptr(), Q.data_ptr(), R.data_ptr(), st))
+            torch.cuda.synchronize()
+        finally:
+            lib.tpa_qr_set_algorithm(0)
+        res[mode] = (Q.cpu(), R.cpu())
+    for b, (m, n) in enumerate(shapes):
+        j = jobs[b]
+        for mode in (0, 2):
+            q = res[mode][0][j[3]:j[3] + m * n].reshape(m, n)
+            r = res[mode][1][j[4]:j[4] + n * n].reshape(n, n)
+            scale = mats[b].abs().max().item()
+            assert (q @ r - mats[b]).abs().max().item() < 1e-13 * max(m, n) * scale, (mode, b)
+            assert (q.T @ q - torch.eye(n, dtype=torch.float64)).abs().max().item() < 1e-13 * max(m, n), (mode, b)
+            assert torch.tril(r, -1).abs().max().item() == 0.0
+        if b != 2:          # same arithmetic per column: R agrees to rounding (beyond the rank of block 2 it is noise in both)
+            r0 = res[0][1][j[4]:j[4] + n * n].reshape(n, n)
+            r2 = res[2][1][j[4]:j[4] + n * n].reshape(n, n)
+            assert (r0 - r2).abs().max().item() < 1e-12 * max(m, n) * mats[b].abs().max().item(), b
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_eigh_batch(env, cplx):
     torch, lib, _lib = env
