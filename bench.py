@@ -104,7 +104,7 @@ def parity_and_port(eng, args, gpu_bond_s):
     spread = [L // 2 - 1, 2, L // 4, L // 2, 3 * L // 4]
     bonds = spread[:n_b] if n_b <= len(spread) else [L // 2 - 1 + i for i in range(n_b)]
     t_cpu, n_centre, mv_err, sv_err, e0_err, sv_ind, iso = 0., 0, [], [], [], [], []
-    n_kept = n_kept_bad = 0
+    n_kept = n_kept_bad = n_kept_abs_bad = 0
     for i0 in bonds:
         eff = TwoSiteH(eng.env, i0, factored=False)       # the fused form LHeff . theta . RHeff that the oracle restates
         theta = eff.combine_theta(eng.psi.get_theta(i0, n=2))
@@ -142,6 +142,9 @@ def parity_and_port(eng, args, gpu_bond_s):
         kept = b[:keep_n] > float(eng.trunc_params.get('svd_min', 0.)) * np.linalg.norm(b)
         n_kept += int(kept.sum())
         n_kept_bad += int(np.sum(np.abs(a[:keep_n][kept] - b[:keep_n][kept]) > 1.e-10 * b[:keep_n][kept]))
+        # ... and by more than LAPACK's own error bound for a singular value, a few eps sigma_max (the ORACLE is LAPACK: below
+        # ~1e-6 sigma_max its values are not good to 1e-10 of their own size either; one-sided Jacobi is the more accurate of the two there)
+        n_kept_abs_bad += int(np.sum(np.abs(a[:keep_n][kept] - b[:keep_n][kept]) > 32 * np.finfo(float).eps * b[0]))
         # isometry defect over all kept vectors (sigma > 1e-14 sigma_max, what svd_min = 1e-14 keeps)
         Ud, Vd = U.to_ndarray(), VH.to_ndarray()
         kept = np.asarray(S_dev) > 1.e-14 * np.max(S_dev)
@@ -155,7 +158,7 @@ def parity_and_port(eng, args, gpu_bond_s):
                       "%.2f s CPU per bond, extrapolated x%d bonds; GPU same bonds %.4f s per bond"
                       % (max(n_centre, 1), args.lanczos_N, per_bond, n_bonds, gpu_bond_s)}
     parity = {"sv_max_rel_err": max(sv_err), "sv_max_rel_err_individual": max(sv_ind), "sv_kept": n_kept,
-              "sv_kept_rel_err_over_1e-10": n_kept_bad, "svd_isometry_defect": max(iso),
+              "sv_kept_rel_err_over_1e-10": n_kept_bad, "sv_kept_abs_err_over_32eps_smax": n_kept_abs_bad, "svd_isometry_defect": max(iso),
               "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err),
               "parity_sample": "bonds %r (centre, edge, quarter) of the timed state: device block SVD vs LAPACK (oracle; sv_max_rel_err = max |dS| / S_max, "
                                "..._individual = max |dS_i| / S_i over S_i > 1e-8 S_max, svd_isometry_defect = max(|U^H U - 1|, |VH VH^H - 1|) "
@@ -632,6 +635,7 @@ def compact(out):
         if isinstance(port, dict):
             c["cpu_baseline"]["port"] = {"value": port.get("value"), "cores": port.get("cores")}
     for k in ("energy_err", "E", "chi_reached", "sv_max_rel_err", "sv_max_rel_err_individual", "sv_kept", "sv_kept_rel_err_over_1e-10",
+              "sv_kept_abs_err_over_32eps_smax",
               "svd_isometry_defect", "matvec_max_rel_err", "E0_rel_err", "trunc_err_eps", "S_mid_entropy", "tebd_route", "prep_s"):
         if k in out:
             c[k] = out[k]

@@ -2402,7 +2402,15 @@ def trace(a, leg1=0, leg2=1):
 # (`_svd_warm.lowdin_rows`; changes U S VH by <= eps*rho*||A||), so that every returned vector is orthonormal to machine
 # precision like LAPACK's (VERDICT r2 "What's weak") at the sweep count of the floor.  Set SVD_ABS_FLOOR = 0. for
 # the purely relative Hestenes criterion (no clean-up needed).
-SVD_ABS_FLOOR = float(os.environ.get('TPA_SVD_ABS_FLOOR', '1e-6'))      # (the environment variable: measurement knob)
+# Round 5: 1e-6 -> 1e-4.  What the floor trades is Jacobi's RELATIVE accuracy of the vectors of tiny singular values for the ABSOLUTE
+# accuracy class LAPACK's gesdd (the reference's svd_robust) has anyway: a pair below the floor stops at |cos| <= eps sqrt(L) rho |A| /
+# sigma, while gesdd's vectors carry angle errors ~ eps |A| / gap -- with gaps ~ sigma / 10 that is 10 eps |A| / sigma, i.e. the floor
+# costs nothing LAPACK delivers as long as rho <~ 0.3.  Measured on the driver protocol (chi = 2048, 3 + 4 sweeps, profiles/
+# r05_abs_floor.txt): rho = 1e-6 / 1e-4 / 1e-3 -> 2.78 / 2.66 / 2.64 s per sweep (Jacobi sweeps per warm call 4.89 / 4.35 / 4.20, per
+# sketch call 3.96 / 3.44 / 3.21, per cold call 5.77 / 5.27 / 5.12); singular values (1.7 - 2.5e-15 of sigma_max), sweep energies
+# (2 - 7e-15 against TeNPy's) and the Lanczos / matvec parity fields do not move; the isometry defect after the clean-up is 1.5e-13 at
+# 1e-4 and 4.5e-12 at 1e-3 with two Loewdin iterations (now three).  1e-4 = vectors of Schmidt weight < 1e-8.
+SVD_ABS_FLOOR = float(os.environ.get('TPA_SVD_ABS_FLOOR', '1e-4'))      # (the environment variable: measurement knob)
 # Round 4 (VERDICT r3 task 7): the floor is an opt-in of the callers that can afford it -- the DMRG / TEBD drivers, which
 # truncate right afterwards and mark their call (``svd_hint`` of the engines, or ``svd_engine_floor = True`` for one call).  Every
 # other ``npc.svd`` (an unmodified TeNPy module calling it for its own purposes) runs the purely relative criterion: every returned
@@ -2426,7 +2434,7 @@ class _PerThreadFloor(threading.local):
 
 
 _svd_floor_now = _PerThreadFloor()      # read by the helpers below
-SVD_LOWDIN_ITERATIONS = 2
+SVD_LOWDIN_ITERATIONS = 3      # (round 5: 2 -> 3 with the higher floor; first-order Loewdin squares the defect per iteration)
 # Warm start (`_svd_warm`): a caller that knows which bond it is decomposing sets ``svd_hint = (key, side)`` right before
 # ``svd`` / ``svd_theta`` (side 'R': the right singular vectors of the previous decomposition under ``key`` are a good basis,
 # 'L': the left ones); the hint is consumed by the next call.  Without a hint, or when the cached basis does not fit the block
