@@ -151,6 +151,19 @@ def parity_and_port(eng, args, gpu_bond_s):
         iso.append(float(max(np.max(np.abs(Ud[:, kept].conj().T @ Ud[:, kept] - np.eye(int(kept.sum())))),
                              np.max(np.abs(Vd[kept] @ Vd[kept].conj().T - np.eye(int(kept.sum())))))))
         e0_err.append(abs(E_dev - E_orc) / abs(E_orc))
+    # ---- what the timed sweeps themselves produced (whatever path each bond's SVD took: warm, sketch, cold): isometry of the stored
+    #      MPS tensors, sum_{vL, p} conj(A) A = 1 (form A) or sum_{p, vR} B conj(B) = 1 (form B), at the sampled bonds' sites
+    mps_iso = []
+    for i in sorted({min(max(b + d, 1), L - 2) for b in bonds for d in (0, 1)}):
+        T = eng.psi.get_B(i, None)
+        f = tuple(eng.psi.form[i])
+        if f == (1., 0.):
+            G = npc.tensordot(T.conj(), T, axes=(['vL*', 'p*'], ['vL', 'p'])).to_ndarray()
+        elif f == (0., 1.):
+            G = npc.tensordot(T, T.conj(), axes=(['p', 'vR'], ['p*', 'vR*'])).to_ndarray()
+        else:
+            continue
+        mps_iso.append(float(np.max(np.abs(G - np.eye(G.shape[0])))))
     per_bond = t_cpu / max(n_centre, 1)
     n_bonds = 2 * (L - 2)
     port = {"value": per_bond * n_bonds, "unit": "s/sweep", "cores": os.cpu_count(), "kind": "port",
@@ -159,9 +172,11 @@ def parity_and_port(eng, args, gpu_bond_s):
                       % (max(n_centre, 1), args.lanczos_N, per_bond, n_bonds, gpu_bond_s)}
     parity = {"sv_max_rel_err": max(sv_err), "sv_max_rel_err_individual": max(sv_ind), "sv_kept": n_kept,
               "sv_kept_rel_err_over_1e-10": n_kept_bad, "sv_kept_abs_err_over_32eps_smax": n_kept_abs_bad, "svd_isometry_defect": max(iso),
+              "mps_isometry_defect": max(mps_iso) if mps_iso else None,
               "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err),
               "parity_sample": "bonds %r (centre, edge, quarter) of the timed state: device block SVD vs LAPACK (oracle; sv_max_rel_err = max |dS| / S_max, "
-                               "..._individual = max |dS_i| / S_i over S_i > 1e-8 S_max, svd_isometry_defect = max(|U^H U - 1|, |VH VH^H - 1|) "
+                               "..._individual = max |dS_i| / S_i over S_i > 1e-8 S_max, mps_isometry_defect = max |T^H T - 1| of the MPS tensors the timed sweeps stored at "
+                               "those sites (whatever path their SVDs took), svd_isometry_defect = max(|U^H U - 1|, |VH VH^H - 1|) "
                                "over the vectors with S > 1e-14 S_max), factored device matvec "
                                "vs oracle LHeff.theta.RHeff, %d-step Lanczos energy vs the oracle's Lanczos" % (bonds, args.lanczos_N)}
     return port, parity
@@ -635,7 +650,7 @@ def compact(out):
         if isinstance(port, dict):
             c["cpu_baseline"]["port"] = {"value": port.get("value"), "cores": port.get("cores")}
     for k in ("energy_err", "E", "chi_reached", "sv_max_rel_err", "sv_max_rel_err_individual", "sv_kept", "sv_kept_rel_err_over_1e-10",
-              "sv_kept_abs_err_over_32eps_smax",
+              "sv_kept_abs_err_over_32eps_smax", "mps_isometry_defect",
               "svd_isometry_defect", "matvec_max_rel_err", "E0_rel_err", "trunc_err_eps", "S_mid_entropy", "tebd_route", "prep_s"):
         if k in out:
             c[k] = out[k]

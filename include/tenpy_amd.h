@@ -160,7 +160,10 @@ int tpa_convert(int from_dtype, int to_dtype, int64_t n, const void *src_dev, vo
                 void *stream);
 /* Tile shape (rows, cols of C per workgroup) of GEMM configuration `cfg` for `dtype`. */
 int tpa_gemm_tile_shape(int dtype, int cfg, int *bm, int *bn);
-/* Tuning hook: variant of the large-tile real kernel (0: 4 waves x 64x64, 1: 8 waves x 64x32). */
+/* Tuning hook: variant of the large-tile real kernel (0: 4 waves x 64x64, 1: 8 waves x 64x32); bits 1-6: BK = 32 and the wave
+ * tilings of the 64 x 64 tile measured in rounds 3-4; bit 7 (128): the double-buffered LDS loop of round 5 (two operand images, one
+ * barrier per k-tile) for the real 64 x 64 tile -- built on request, measured SLOWER (dense 4096^3 50.0 -> 46.2 TFLOP/s: the second
+ * image costs two workgroups per CU), therefore off by default (profiles/r05_gemm_double_buffer.txt). */
 int tpa_gemm_set_variant(int v);
 
 /* ---- K5: batched block SVD, one-sided (Hestenes) Jacobi -- replaces svd_flat / LAPACK gesdd
@@ -225,7 +228,11 @@ int tpa_svd_set_rank_cap(int cap);
 int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_base,
                  void *r_base, void *stream);
 /* Test hook: bit 0 = always use the one-workgroup Householder kernel (default: blocked compact-WY QR on the matrix
- * cores when min(m,n) >= 32 and m <= 8192 (real) / 2048 (complex)). */
+ * cores when min(m,n) >= 32 and m <= 8192 (real) / 2048 (complex)); bit 1 = two launches per 8-column panel (factorisation, then
+ * trailing update: rounds 2-4) also where the default is ONE launch per panel (round 5, csrc/tpa_qr_la.inc: real data, every block
+ * tall with <= 2048 rows -- workgroup 0 of a block brings panel k + 1 up to date and factorises it while the other workgroups apply
+ * panel k behind it).  Since round 5 tpa_qr_batch also orthogonalises the sketch Y = X Omega^H of the warm-started block SVD
+ * (linalg/_svd_warm.py::svd_blocks_sketch). */
 int tpa_qr_set_algorithm(int v);
 
 /* ---- K7: batched Hermitian eigendecomposition, cyclic Jacobi (np.linalg.eigh per block,

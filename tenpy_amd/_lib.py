@@ -79,7 +79,7 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise BackendError("tenpy_amd: %s not built; run `python -m tenpy_amd._build`" % path)
         _build.build()
-    elif build_if_missing and os.path.exists(_build.HIPCC) and os.path.isdir(_build.CSRC):
+    elif build_if_missing and os.path.exists(_build.HIPCC) and os.path.isdir(_build.CSRC) and not os.environ.get('TPA_NO_AUTOBUILD'):
         # no-op unless a source under csrc/ is newer than its object: a stale .so is never loaded silently.  One process
         # at a time (N ranks of a torchrun launch all come through here).
         import fcntl

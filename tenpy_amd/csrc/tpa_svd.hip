@@ -109,8 +109,18 @@ __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2
 // (quadratic convergence), so the host may skip the verification sweep (tpa_svd_set_algorithm bit 10, off by default;
 // tests/jacobi_emulation.py `predict`: one sweep of ~7 saved on chi=2048 theta blocks, identical singular values and
 // orthogonality).  Counted in n_rot[1].
+// Round 5: for a pair BELOW the floor the scale is sqrt(mx * floor^2), not floor^2.  The rotation leaves a cosine of ~cos^2, and that
+// has to meet the pair's OWN stopping rule, |gamma'| <= tol sqrt(mn) rho |A|, i.e. cos^2 <~ tol rho |A| / sqrt(mx).  With floor^2 as the
+// scale (rounds 2-4) a pair of rows with sigma ~ 1e-12 |A| was "big" only above cos = 1e-7 rho |A| / sigma >> 1: never -- the
+// iteration could end on cosines of O(0.1) among such rows once the LARGE rows were done, which the first-order clean-up does not
+// repair.  Harmless on pivoted-QR starts (those rows begin nearly orthogonal), visible on warm / sketch starts of blocks graded
+// down to rounding level: tests/test_svd_configs_gpu.py found isometry defects of 1e-10 ... 3e-3 on the MI355X; the numpy emulation
+// (tests/jacobi_emulation.py, NEW_BIG_RULE) shows 0.17 -> 1.8e-5 before the clean-up for rho = 1e-4 and 0.17 -> 1.2e-7 for rho = 1e-6.
 __device__ __forceinline__ bool svd_big_rotation(double a, double b, double g2, double floor2) {
-    return g2 > 1.0e-14 * fmin(a, b) * fmax(fmax(a, b), floor2);
+    const double mn = fmin(a, b), mx0 = fmax(a, b);
+    if (mx0 >= floor2) return g2 > 1.0e-14 * mn * mx0;            // above the floor: the relative rule, as before
+    const double p = mx0 * floor2;
+    return g2 > 1.0e-14 * mn * (p * __builtin_amdgcn_rsq(p));     // sqrt(p) from the hardware seed: a threshold, not a result
 }
 
 template <bool CPLX>

@@ -7,7 +7,23 @@ import numpy as np
 EPS = 2.220446049250313e-16
 BRJ, TRJ = 8, 16
 
+NEW_BIG_RULE = True     # False: the rule of rounds 2-4 (scaled by the floor alone)
 NULL_ROW_CUT = 1.0e-60      # svd_needs_rotation: |row|^2 below this fraction of the partner's -> zero row
+
+
+PRED_BOOST = 1.0          # experiment knobs of round 5 (the device code has neither): a prediction floor^2 = PRED_BOOST x the rotation floor^2
+PRED_CAP = float('inf')   # and a cap on the cos^2 a pair below the floor is let go with.  Emulated on chi = 2048 blocks: no sweep saved.
+
+
+def big_rotation(a, b, g2, floor2, predict=1e-7):
+    """svd_big_rotation of tpa_svd.hip, operation for operation (NEW_BIG_RULE False: the rule of rounds 2-4, scaled by the floor alone)."""
+    mn, mx0 = min(a, b), max(a, b)
+    if not NEW_BIG_RULE:
+        return g2 > predict * predict * mn * max(mx0, floor2)
+    pf2 = floor2 * PRED_BOOST
+    if mx0 >= pf2:
+        return g2 > predict * predict * mn * mx0
+    return g2 > mn * min(predict * predict * np.sqrt(mx0 * pf2), PRED_CAP * mx0)
 
 
 def needs(a, b, g2, tol, floor2):
@@ -107,7 +123,10 @@ def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False, predict=N
                             flag = True
                             if predict is not None:
                                 a_, b_ = Sm[ei, ei], Sm[ej, ej]
-                                if Sm[ei, ej] ** 2 > predict * predict * min(a_, b_) * max(a_, b_, floor2):
+                                # svd_big_rotation of tpa_svd.hip (round 5): the rotation leaves a cosine of ~cos^2, and that must
+                                # meet the pair's OWN stopping rule -- for a pair below the floor the scale is sqrt(mx * floor2), not
+                                # floor2 (with floor2 such pairs were never "big": the iteration could stop on cosines of O(0.1))
+                                if big_rotation(a_, b_, Sm[ei, ej] ** 2, floor2, predict):
                                     flag_big = True
                 if not flag:
                     continue

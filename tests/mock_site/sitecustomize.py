@@ -6,6 +6,9 @@ import os
 import sys
 
 if os.environ.get('TPA_TEST_MOCK_DEVICE') == '1':
+    # never rebuild the library from inside this hook: the compiler driver starts Python children, which would come through here
+    # again and wait for the build lock their parent holds (round 5: a header edit made every such process hang)
+    os.environ['TPA_NO_AUTOBUILD'] = '1'
     _root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path[:0] = [_root, os.path.join(_root, 'tests')]
     from _pytest.monkeypatch import MonkeyPatch

@@ -176,3 +176,25 @@ def test_smoke_runs_on_the_emulated_device(monkeypatch, capsys):
     import __graft_entry__ as g
     g.smoke()
     assert 'smoke ok' in capsys.readouterr().out
+
+
+def test_bench_force_dist_one_rank(tmp_path):
+    """`bench.py --force-dist` (what tests/test_sharded.py::test_rccl_collective_world1 runs over RCCL on the MI355X), here over gloo on
+    the emulated device: a process group of ONE rank, the row-sharded operator forced, the all-gather issued from the collective
+    callback of the native Lanczos run -- and the same energy as the plain run."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TPA_SHARD_FORCE')}
+    env.update(PYTHONPATH=os.path.join(root, 'tests', 'mock_site') + os.pathsep + env.get('PYTHONPATH', ''), TPA_TEST_MOCK_DEVICE='1',
+               TPA_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1')
+    outs = []
+    for extra in (['--force-dist'], []):
+        pr = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--L', '12', '--chi', '16', '--steps', '1', '--warmup', '1',
+                             '--no-cpu-baseline', '--no-extras'] + extra, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+        assert pr.returncode == 0, pr.stderr[-3000:]
+        outs.append(json.loads([l for l in pr.stdout.splitlines() if l.startswith('{')][-1]))
+    forced, plain = outs
+    assert forced['n_gpus'] == 1 and 'ONE rank' in forced['config']['parallelism'] and forced['lanczos_stats']['n_native_sharded'] > 0
+    assert plain['lanczos_stats']['n_native_sharded'] == 0
+    assert abs(forced['E'] - plain['E']) < 1e-12 * abs(plain['E'])

@@ -34,18 +34,25 @@ def _array(npc, legL, legR, blocks):
     return npc.Array.from_ndarray(dense, [legL, legR]), dense
 
 
-def _check(blocks, legL, legR, dense, U, S, VH):
+def _check(what, blocks, legL, legR, dense, U, S, VH):
+    """Errors of one decomposition (all relative to sigma_max = the 2-norm of the block matrix): reconstruction (max entry), singular
+    values per block against LAPACK, isometry defects of everything above 1e-14 sigma_max."""
     Ud, Vd = U.to_ndarray(), VH.to_ndarray()
-    assert np.abs((Ud * S) @ Vd - dense).max() <= 5e-14 * np.abs(dense).max()
-    off = 0
+    smax = S.max()
+    rec = np.abs((Ud * S) @ Vd - dense).max() / smax
+    off, sv = 0, 0.
     for b in blocks:
         k = min(b.shape)
         ref = np.linalg.svd(b, compute_uv=False)
-        np.testing.assert_allclose(np.sort(S[off:off + k])[::-1], ref, rtol=0, atol=1e-13 * ref.max())
+        sv = max(sv, np.abs(np.sort(S[off:off + k])[::-1] - ref).max() / smax)
         off += k
-    keep = S > 1e-14 * S.max()
-    assert np.abs(Ud[:, keep].T @ Ud[:, keep] - np.eye(keep.sum())).max() < 1e-11
-    assert np.abs(Vd[keep] @ Vd[keep].T - np.eye(keep.sum())).max() < 1e-11
+    keep = S > 1e-14 * smax
+    iso_u = np.abs(Ud[:, keep].T @ Ud[:, keep] - np.eye(keep.sum())).max()
+    iso_v = np.abs(Vd[keep] @ Vd[keep].T - np.eye(keep.sum())).max()
+    msg = "%s: reconstruction %.1e, singular values %.1e, |U^T U - 1| %.1e, |V V^T - 1| %.1e" % (what, rec, sv, iso_u, iso_v)
+    print(msg)
+    # bars: north_star asks 1e-10 for the singular values; a backward-stable SVD of a 1000 x 1000 block reconstructs to ~1e-13 sigma_max
+    assert rec <= 1e-12 and sv <= 1e-13 and iso_u < 1e-11 and iso_v < 1e-11, msg
 
 
 @pytest.mark.parametrize("side", ['R', 'L'])
@@ -70,7 +77,7 @@ def test_block_svd_cold_sketch_warm(config, side):
     # (1) first visit of the bond: no basis -> cold path
     a, dense = _array(npc, legL, legR, blocks)
     npc.svd_hint = (key, side)
-    _check(blocks, legL, legR, dense, *npc.svd(a))
+    _check('cold', blocks, legL, legR, dense, *npc.svd(a))
     assert st['cold_calls'] == 1 and st['warm_calls'] == 0 and st['sketch_calls'] == 0
     # (2) the state drifted since (every singular vector tilted by ~1e-9, a few new directions): the old basis is stale, but sketches
     #     the column space -- no pivoted QR
@@ -82,13 +89,13 @@ def test_block_svd_cold_sketch_warm(config, side):
         drifted.append(b + 1e-9 * ((k1 - k1.T) @ b + b @ (k2 - k2.T)) + 1e-10 * np.linalg.norm(b) / np.linalg.norm(x) * x)
     a, dense = _array(npc, legL, legR, drifted)
     npc.svd_hint = (key, side)
-    _check(drifted, legL, legR, dense, *npc.svd(a))
+    _check('sketch', drifted, legL, legR, dense, *npc.svd(a))
     assert st['sketch_calls'] == 1 and st['cold_calls'] == 1 and st.get('sk_residual', 0) == 0, dict(st)
     assert st['sk_e_rel_last'] < 1e-13
     # (3) the same wave function again (a converged state): plain warm start, no QR at all
     npc.svd_hint = (key, side)
-    _check(drifted, legL, legR, dense, *npc.svd(a))
+    _check('warm', drifted, legL, legR, dense, *npc.svd(a))
     assert st['warm_calls'] == 1 and st['cold_calls'] == 1 and st['sketch_calls'] == 1, dict(st)
     # (4) ... and without a hint (a generic npc.svd: purely relative stopping rule, no floor, no clean-up)
-    _check(drifted, legL, legR, dense, *npc.svd(a))
+    _check('generic (no hint, no floor)', drifted, legL, legR, dense, *npc.svd(a))
     _svd_warm.cache_clear()
