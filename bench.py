@@ -376,8 +376,6 @@ def run(argv=None, emit=True):
     npc.svd_stats['max_block'] = 0          # (a running maximum: the other configurations of the extras run in this process too)
     svd_calls0, svd_sweeps0, warm0 = npc.svd_stats['calls'], npc.svd_stats['sweeps'], dict(_sw.stats)
     import ctypes as _ct
-    _ref8 = (_ct.c_int64 * 8)()
-    dev_lib().tpa_svd_refine_stats(_ref8, 1)           # counters of the refinement end game: timed region only
     from tenpy_amd.linalg import krylov_based as _kb
     lanczos0 = dict(_kb.stats)
     if dist is not None:
@@ -532,14 +530,10 @@ def run(argv=None, emit=True):
             if os.environ.get('TPA_BENCH_PHASES'):   # diagnostic run only: the phase timers synchronise the device
                 out["phases_s"] = {k: round(v / max(args.steps, 1), 4) for k, v in eng.phase_time.items()}
             from tenpy_amd.linalg import _svd_warm
-            _ref8_end = (_ct.c_int64 * 8)()
-            dev_lib().tpa_svd_refine_stats(_ref8_end, 0)
             n_svd = max(npc.svd_stats['calls'] - svd_calls0, 1)
             out["svd_stats"] = {"calls_timed": n_svd, "jacobi_sweeps_per_call": (npc.svd_stats['sweeps'] - svd_sweeps0) / n_svd,
                                 "max_block": npc.svd_stats['max_block'], "abs_floor": npc.SVD_ABS_FLOOR,
                                 "warm": {k: (v - warm0.get(k, 0)) for k, v in _svd_warm.stats.items() if not k.startswith('e_rel')},
-                                "refine": dict(zip(("calls_refined", "steps", "newton_schulz_steps", "sweeps_before", "extra_sweeps",
-                                                    "calls_plain", "sweeps_plain", "failed"), [int(x) for x in _ref8_end])),
                                 "note": "warm = calls started from the singular vectors this bond produced on its previous visit "
                                         "(no pivoted QR; linalg/_svd_warm.py); the rest took the cold path; sweep counts include the "
                                         "low-rank residual decompositions of warm calls"}

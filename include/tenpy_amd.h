@@ -201,16 +201,12 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
  * updates of the Gram tiles and of the accumulated transform) and end with one product [W | G] <- Qtot [W | G]; bit 20
  * (1048576) = off (gram / solve / apply on the data in every round, the round-3 path; complex data: the 8-row-block rounds).
  * Bit 14 (16384): complex Gram-only rounds with the tiles the next solve does not read on a second stream (measured slower; off).
- * Round 4 -- end game by simultaneous rotations (csrc/tpa_svd_refine.inc; OFF by default, bit 21 (2097152) = on, bit 15 (32768) =
- * also for complex data): after `pre` cyclic sweeps (bits 16-19 = `pre` + 1; 0: default 3; 1 = none: warm-started calls) every
- * further sweep is replaced by a step that takes ALL pair rotations from one exact Gram matrix, makes the transform unitary by
- * Newton-Schulz (GEMMs) and applies it to [W | G] (GEMM); same pairwise stopping rule, evaluated on the exact Gram matrix for
- * all pairs; cyclic sweeps take over again whenever a step does not shrink the rotations. */
+ * Bit 23 (8388608): two launches per Gram-only round (round-4 A/B switch; bit 22 selected the round-3 solve kernel, removed in round 5).
+ * Round 5: the "big rotation" test of the predicted convergence judges a pair below the floor against its own stopping rule
+ * (scale sqrt(max(alpha, beta)) rho |A|_F instead of rho^2 |A|_F^2: with the old scale such pairs never counted and the iteration
+ * could end on cosines of O(0.1) among them).  (Bits 15 - 19 and 21 switched the round-4 end game by simultaneous rotations +
+ * Newton-Schulz steps: measured slower over a whole sweep, never on by default, removed in round 5 with its counters.) */
 int tpa_svd_set_algorithm(int pairwise);
-/* Counters of the refinement path since the last reset (host, all calls of the process): out8 = {calls that entered the
- * refinement, refinement steps, Newton-Schulz steps, cyclic sweeps before the first step, extra cyclic sweeps after a stalled
- * step, calls that never used it, their cyclic sweeps, failed calls (-> TPA_E_NOCONV, the caller's fallback chain)}. */
-int tpa_svd_refine_stats(int64_t *out8, int reset);
 /* Diagnostic ring of the most recent tpa_svd_batch calls (host): rows of out = {min(m, n) of the largest block, its max(m, n),
  * blocks, sweeps, pivoted QR used, algorithm switches, wall microseconds inside the call, return code}; returns the rows written. */
 int64_t tpa_svd_call_log(int64_t *out, int64_t max_rows, int reset);

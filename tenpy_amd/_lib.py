@@ -51,7 +51,6 @@ _SIGS = {
                                      ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp]),
     "tpa_svd_set_algorithm": (ctypes.c_int, [ctypes.c_int]),
     "tpa_svd_set_rank_cap": (ctypes.c_int, [ctypes.c_int]),
-    "tpa_svd_refine_stats": (ctypes.c_int, [_i64p, ctypes.c_int]),
     "tpa_svd_call_log": (ctypes.c_int64, [_i64p, ctypes.c_int64, ctypes.c_int]),
     "tpa_qr_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "tpa_qr_set_algorithm": (ctypes.c_int, [ctypes.c_int]),

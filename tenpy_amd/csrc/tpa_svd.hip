@@ -849,7 +849,7 @@ __global__ __launch_bounds__(NTW) void svd_round_wide_kernel(const SvdJob *__res
 
 #include "tpa_svd_b32.inc"
 #include "tpa_svd_b32c.inc"
-#include "tpa_svd_refine.inc"
+#include "tpa_svd_gram.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // Complex (Hermitian) version of the split block-Jacobi round.  Same structure; chunks are 32 complex columns
@@ -2553,24 +2553,13 @@ int tpa_svd_lookahead = 1;       // 32-row-block path: first round of the next s
 int tpa_svd_b32 = 1;             // real data: 32-row blocks, three launches per round (tpa_svd_b32.inc); bit 12 of tpa_svd_set_algorithm switches it off
 int tpa_svd_gonly = 1;           // real data, 32-row blocks: Gram-only sweeps (one exact Gram matrix per sweep, rounds on it alone, one product
                                  // [W | G] <- Qtot [W | G] at the end; tpa_svd_b32.inc); bit 20 of tpa_svd_set_algorithm switches it off
-int tpa_svd_refine = 0;          // end game by simultaneous rotations + Newton-Schulz on the MFMA (tpa_svd_refine.inc): bit 0 real data, bit 1 complex data;
-                                 // OFF by default (measured: 12.7 vs 13.9 ms on the saturated chi = 2048 theta, but 3.86 vs 3.61 s per sweep --
-                                 // the small blocks of the other bonds lose); bit 21 of tpa_svd_set_algorithm switches it on, bit 15 also for complex data
 int tpa_svd_overlap_c = 0;       // complex Gram-only rounds: tiles that the next solve does not read on a second stream (bit 14; measured slower)
-int tpa_svd_refine_pre = 3;      // Jacobi sweeps before the first refinement step (bits 16..19 of tpa_svd_set_algorithm: value + 1)
-constexpr double REF_KINF_ENTER = 6.0;    // largest row sum of |K| with which a refinement step is attempted
 constexpr int64_t REF_MIN_R = 96;   // calls whose largest block has fewer rows keep the plain Jacobi rounds (1 - 2 rounds per sweep there)
-int64_t tpa_svd_refine_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calls with refinement, refinement steps, Newton-Schulz steps, Jacobi sweeps of those calls,
-                                                                 // extra Jacobi sweeps after a stagnating step, calls without refinement, their sweeps, failures
 
 int tpa_svd_fused_rounds = 1;    // Gram-only sweeps: one launch per round (svd_b32_round_kernel); bit 23 of tpa_svd_set_algorithm: solve and update as two launches
-int tpa_svd_solve2 = 1;          // 32-row blocks: second generation of the in-LDS solve (Q in registers; bit 22 of tpa_svd_set_algorithm: the round-3 kernel)
 inline void b32_solve_launch(int n_pairs, hipStream_t st, const SvdJob *jobs, const B32Pair *b32p, const double *b32g, double *b32q, int *b32f,
                              unsigned int *cnt, const double *fro2, double rho, int full_local, const double *sfull, int r) {
-    if (tpa_svd_solve2)
-        svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, sfull, r);
-    else
-        svd_b32_solve_kernel<<<n_pairs, NTS, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, sfull, r);
+    svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, sfull, r);
 }
 
 struct Layout {
@@ -2587,9 +2576,9 @@ struct Layout {
     int n_gup_s = 0;
     std::vector<int> b32_first_pair;
     int64_t off_gup = 0;
-    RefTables ref;                 // GEMM tables of the refinement / the Gram-only sweeps (empty unless the largest block has >= REF_MIN_R rows)
+    RefTables ref;                 // GEMM tables of the Gram-only sweeps (empty unless the largest block has >= REF_MIN_R rows)
     int64_t off_rtasks = 0, off_rlinks = 0, off_rtiles = 0, off_rrt = 0;                // ... inside the uploaded table range
-    int64_t off_w2 = 0, off_rp = 0, off_rq = 0, off_rm = 0, off_rowpart = 0;           // second [W | G] image, split-K partials, Q, M, |K| row sums
+    int64_t off_w2 = 0, off_rp = 0, off_rq = 0, off_rm = 0;           // second [W | G] image, split-K partials, Qtot, S
     bool wide_ok = true;           // every job has <= FIT * NTW / 64 column chunks of [W | G]
     int64_t nb_max_pad = 0;
     int64_t max_part_chunks = 0;   // largest number of (W + G) column chunks of one part (fused round: <= 4 * FIT)
@@ -2765,8 +2754,6 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
         o = align_up(o + lay.g_elems * esz, 256);
         lay.off_rm = o;
         o = align_up(o + lay.g_elems * esz, 256);
-        lay.off_rowpart = o;
-        o = align_up(o + lay.sig_elems * lay.ref.nts * 8, 256);
     }
     lay.total = o;
     return lay;
@@ -2952,7 +2939,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         b32_solve_launch((int)lay.b32_pairs.size(), st, jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
         svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, W, G, b32q, b32f);
     };
-    // work areas and GEMM tables shared by the Gram-only sweeps and the refinement steps
+    // work areas and GEMM tables of the Gram-only sweeps
     constexpr int ES = CPLX ? 2 : 1;
     const RefTables &rt = lay.ref;
     const int64_t *rtasks = (const int64_t *)(work + lay.off_rtasks), *rlinks = (const int64_t *)(work + lay.off_rlinks);
@@ -2960,58 +2947,15 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     const RefTile *rrt = (const RefTile *)(work + lay.off_rrt);
     double *W2 = (double *)(work + lay.off_w2), *G2 = (double *)(work + lay.off_w2 + (lay.off_g - lay.off_w));
     double *P = (double *)(work + lay.off_rp), *Qm = (double *)(work + lay.off_rq), *Mm = (double *)(work + lay.off_rm);
-    const int64_t pstride = (lay.g_elems + 1) / 2 * 2 * ES, n_q = lay.g_elems * ES;
+    const int64_t pstride = (lay.g_elems + 1) / 2 * 2 * ES;
     const int n_rt = (int)rt.rtiles.size();
     auto gemm = [&](const RefTables::Span &sp, const void *A, const void *B, void *C) {
         return tpa_gemm_chain(CPLX ? TPA_C128 : TPA_F64, 1, rtasks, rlinks, rtiles + 4 * sp.tile0, sp.n_tiles, A, B, C, st);
     };
-    // End game by simultaneous rotations (tpa_svd_refine.inc): the Jacobi loops below stop after `jac_limit` sweeps and hand over.
-    const bool use_refine = use_block && lay.ref.enabled && (tpa_svd_refine & (CPLX ? 2 : 1)) && !converged;
-    int jac_limit = use_refine ? std::min(max_sweeps, std::max(tpa_svd_refine_pre, 0)) : max_sweeps;
+    const int jac_limit = max_sweeps;
     double *Wc = W, *Gc = G;            // current [W | G] image (the refinement steps ping-pong between two)
     static thread_local hipEvent_t ev_post = nullptr;
     if (ev_post == nullptr) TPA_HIP_CHECK(hipEventCreateWithFlags(&ev_post, hipEventDisableTiming));
-    auto b32_round_on = [&](int r, double *Wx, double *Gx) {
-        const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
-        svd_b32_gram_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, Wx, b32g);
-        b32_solve_launch((int)lay.b32_pairs.size(), st, jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, nullptr, r);
-        svd_b32_apply_kernel<<<(int)lay.b32_entries.size(), NTB, 0, st>>>(jobs, b32e, r, Wx, Gx, b32q, b32f);
-    };
-    // one Jacobi sweep on the image (Wx, Gx) with whatever round kernel this call uses; counters -> posted[0..1]
-    auto jacobi_sweep_on = [&](double *Wx, double *Gx) -> int {
-        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
-        for (int r = 0; r < rounds; ++r) {
-            const int full_local = (tpa_svd_cross_only && r > 0) ? 0 : 1;
-            if (use_b32) {
-                b32_round_on(r, Wx, Gx);
-            } else if (use_fused_c) {
-                ++fused_seq;
-                svd_round_fused_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)Wx, (double2 *)Gx, gpart, pcnt, fused_seq, cnt,
-                                                                                  fro2, rho, tpa_svd_local_sweeps, full_local, perr);
-            } else if (use_block && CPLX) {
-                svd_gram_part_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (const double2 *)Wx, gpart);
-                svd_solve_apply_kernel_c<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, (double2 *)Wx, (double2 *)Gx, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
-            } else if (use_wide) {
-                svd_round_wide_kernel<<<(int)lay.wpairs.size(), NTW, 0, st>>>(jobs, wpairs, r, Wx, Gx, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
-            } else if (use_fused) {
-                ++fused_seq;
-                svd_round_fused_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, Wx, Gx, gpart, pcnt, fused_seq, cnt, fro2, rho,
-                                                                                tpa_svd_local_sweeps, full_local, perr);
-            } else {
-                svd_gram_part_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, Wx, gpart);
-                svd_solve_apply_kernel<<<(int)lay.bentries.size(), NTG, 0, st>>>(jobs, bent, r, Wx, Gx, gpart, cnt, fro2, rho, tpa_svd_local_sweeps, full_local);
-            }
-        }
-        TPA_LAUNCH_CHECK();
-        const bool with_err = !use_b32 && ((use_fused && !use_wide) || use_fused_c);
-        post_words_kernel<<<1, 1, 0, st>>>(cnt, 2, with_err ? perr : nullptr, posted, 1);
-        TPA_HIP_CHECK(hipStreamSynchronize(st));
-        if (with_err && posted[2]) {
-            snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: sibling workgroups of a fused Jacobi round lost each other (spin limit)");
-            return TPA_E_NOCONV;
-        }
-        return 0;
-    };
     // ---- Gram-only sweeps (tpa_svd_b32.inc): needs the predicted-convergence rule (the stopping decision must not rest on an
     //      updated Gram matrix alone) and the GEMM tables of the refinement layout
     //      Complex data (tpa_svd_b32c.inc): the Gram-only sweep is the ONLY 32-row-block path (two launches per round).
@@ -3026,7 +2970,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             if (int rc = gemm(rt.gram, Wc, Wc, P)) rc_g = rc;
             ref_nsm_kernel<CPLX><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Mm, 0.0, -1.0, 1.0, nullptr, Qm);
         };
-        const bool fused = !CPLX && tpa_svd_fused_rounds && tpa_svd_solve2;
+        const bool fused = !CPLX && tpa_svd_fused_rounds;
         const bool overlap_c = CPLX && tpa_svd_overlap_c;
         static thread_local hipStream_t st2 = nullptr;
         static thread_local hipEvent_t ev_c[2] = {nullptr, nullptr};
@@ -3170,121 +3114,6 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         }
         ++sweep;
         converged = (h2[0] == 0) || (tpa_svd_predict_convergence && h2[1] == 0);
-    }
-    if (use_refine && !converged && sweep < max_sweeps) {
-        // ---- refinement steps: Gram (GEMM) -> K, counters, |K| bound -> host -> Newton-Schulz (GEMMs) -> [W | G] <- Q [W | G] (GEMM)
-        double *rowpart = (double *)(work + lay.off_rowpart);
-        unsigned int *rposted = (unsigned int *)pin_stage().take(64, st);
-        TPA_STAGE_CHECK(rposted);
-        TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned int), st));
-        double *Wn = (Wc == W) ? W2 : W, *Gn = (Gc == G) ? G2 : G;
-        int it = 0, ns_total = 0, extra_sweeps = 0, stalled = 0, backoff = 1;
-        double kinf_prev = 0.0;
-        const int jac_sweeps = sweep;
-        bool failed = false;
-        for (; it < REF_MAX_IT; ++it) {      // refinement steps have their own budget; cyclic sweeps count against max_sweeps
-            if (int rc = gemm(rt.gram, Wc, Wc, P)) return rc;
-            ref_build_kernel<CPLX><<<n_rt, 256, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Qm, rowpart, rt.nts, fro2, rho, cnt);
-            ref_post_kernel<<<1, 256, 0, st>>>(jobs, rows, (int)lay.rows.size(), rowpart, rt.nts, cnt, rposted);
-            TPA_HIP_CHECK(hipEventRecord(ev_post, st));
-            TPA_LAUNCH_CHECK();
-            TPA_HIP_CHECK(hipEventSynchronize(ev_post));
-            const unsigned int n_need = rposted[0], n_big = rposted[1];
-            double kinf, e_last, cmax2;
-            {
-                const unsigned long long kb = (unsigned long long)rposted[2] | ((unsigned long long)rposted[3] << 32);
-                const unsigned long long eb = (unsigned long long)rposted[4] | ((unsigned long long)rposted[5] << 32);
-                const unsigned long long cb = (unsigned long long)rposted[6] | ((unsigned long long)rposted[7] << 32);
-                memcpy(&kinf, &kb, 8);
-                memcpy(&e_last, &eb, 8);
-                memcpy(&cmax2, &cb, 8);
-            }
-            // NaN, or the last Newton-Schulz step of the previous iteration started far from unitary (the plan is a rigorous bound:
-            // this is a sanity check, not a convergence test)
-            if (!(kinf == kinf) || !(e_last < 1.0e-6) || !(cmax2 == cmax2)) {
-                failed = true;
-                break;
-            }
-            if (getenv("TPA_REF_DEBUG"))
-                fprintf(stderr, "refine it %d: need %u big %u kinf %.3e cmax %.3e e_last %.3e sweep %d\n", it, n_need, n_big, kinf, std::sqrt(cmax2), e_last, sweep);
-            if (n_need == 0) {
-                converged = true;
-                break;
-            }
-            // Simultaneous rotations only converge from near-orthogonal rows.  Measured on the rank-569 block of the chi = 2048 theta:
-            // row sums of |K| of 2.7 / 5.1 / 8.1 after 3 / 2 / 1 cyclic sweeps (then 5 / 7 / 8 steps with 26 / 39 / 60 Newton-Schulz
-            // steps: a sweep costs about as much as the 18 steps it saves), 12 straight after the pivoted QR -- and from there they
-            // GROW to 200.  So: above REF_KINF_ENTER, or when three steps in a row fail to shrink |K|, cyclic sweeps on the current
-            // image take over again -- 1, then 2, 4, ... before the next attempt.
-            if (it > 0 && kinf > 0.5 && kinf > 0.85 * kinf_prev) ++stalled;
-            else stalled = 0;
-            kinf_prev = kinf;
-            if (stalled >= 3 || kinf > REF_KINF_ENTER) {
-                bool jac_done = false;
-                for (int e = 0; e < backoff && jac_sweeps + extra_sweeps < max_sweeps && !jac_done; ++e) {
-                    if (int rc = jacobi_sweep_on(Wc, Gc)) return rc;
-                    ++sweep;
-                    ++extra_sweeps;
-                    // no predicted convergence here: the simultaneous steps leave near-degenerate rows un-paired (cosines
-                    // delta^2 / gap after a sweep that started from delta), so only a sweep without any rotation ends the iteration
-                    jac_done = (posted[0] == 0);
-                }
-                backoff = std::min(2 * backoff, 8);
-                stalled = 0;
-                kinf_prev = 0.0;
-                if (jac_done) {
-                    converged = true;
-                    break;
-                }
-                TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned int), st));
-                continue;
-            }
-            double scale;
-            const int ns = ref_ns_plan(kinf, scale);
-            for (int k = 0; k < ns; ++k) {
-                if (int rc = gemm(rt.nst, Qm, Qm, P)) return rc;
-                const double s_ = (k == 0) ? scale : 1.0;
-                ref_nsm_kernel<CPLX><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_r, pstride, Mm, 1.5 * s_, 0.5 * s_ * s_ * s_, s_ * s_,
-                                                           (k == ns - 1) ? (unsigned long long *)(cnt + 2) : nullptr, nullptr);
-                if (int rc = gemm(rt.nsq, Mm, Qm, P)) return rc;
-                ref_qsum_kernel<<<(int)((n_q / 2 + 256) / 256), 256, 0, st>>>(P, rt.nsplit_r, pstride, Qm, n_q);
-            }
-            ns_total += ns;
-            if (int rc = gemm(rt.apply, Qm, Wc, Wn)) return rc;
-            std::swap(Wc, Wn);
-            std::swap(Gc, Gn);
-            ++sweep;
-            // Simultaneous rotations leave cosines of ~ (largest cosine before) x (largest rotation) -- near-degenerate pairs keep
-            // |K| ~ 1e-2 .. 1 while the cosines are already ~1e-8 -- so a step is the last one only if every cosine it started from was
-            // at rounding level (< 1e-13: what it leaves cannot be told from noise); otherwise the next exact Gram matrix decides.
-            if (tpa_svd_predict_convergence && n_big == 0 && cmax2 < 1.0e-26) {
-                ++it;
-                converged = true;
-                break;
-            }
-        }
-        // out of refinement steps (slow linear phase: many small rotations with |K| row sums > 1): cyclic sweeps finish the job
-        while (!converged && !failed && jac_sweeps + extra_sweeps < max_sweeps) {
-            if (int rc = jacobi_sweep_on(Wc, Gc)) return rc;
-            ++sweep;
-            ++extra_sweeps;
-            converged = (posted[0] == 0);
-        }
-        TPA_LAUNCH_CHECK();
-        tpa_svd_refine_counters[0] += 1;
-        tpa_svd_refine_counters[1] += it;
-        tpa_svd_refine_counters[2] += ns_total;
-        tpa_svd_refine_counters[3] += jac_sweeps;
-        tpa_svd_refine_counters[4] += extra_sweeps;
-        if (failed) {
-            tpa_svd_refine_counters[7] += 1;
-            TPA_HIP_CHECK(hipStreamSynchronize(st));
-            snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: refinement step failed (NaN or non-unitary transform)");
-            return TPA_E_NOCONV;
-        }
-    } else if (!use_refine) {
-        tpa_svd_refine_counters[5] += 1;
-        tpa_svd_refine_counters[6] += sweep;
     }
     W = Wc;
     G = Gc;
@@ -3746,7 +3575,7 @@ int qr_run_wy(const int64_t *jobs_host, int n_jobs, const void *a_base, void *q_
         }
         if ((e = hipGetLastError()) != hipSuccess) fail(e);
     }
-    hipFreeAsync(work, st);
+    (void)hipFreeAsync(work, st);
     return rc;
 }
 
@@ -3809,7 +3638,7 @@ extern "C" int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, co
     e[2] = n_jobs;
     e[3] = sw;
     e[4] = used_qrp;
-    e[5] = tpa_svd_b32 | (tpa_svd_gonly << 1) | (tpa_svd_refine << 2);
+    e[5] = tpa_svd_b32 | (tpa_svd_gonly << 1);
     e[6] = (int64_t)(t1.tv_sec - t0.tv_sec) * 1000000 + (t1.tv_nsec - t0.tv_nsec) / 1000;
     e[7] = rc;
     ++tpa_svd_call_log_count;
@@ -4015,19 +3844,9 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_lookahead = (pairwise & 8192) ? 0 : 1;     // bit 13: no look-ahead round (the host drains the stream after every sweep)
     tpa_svd_predict_convergence = (pairwise & 1024) ? 0 : 1;   // bit 10: always run the verification sweep (see svd_big_rotation)
     if ((pairwise & 0xf0) || (pairwise & 256)) tpa_svd_local_sweeps = (pairwise >> 4) & 15;   // test hook: local sweeps in bits 4..7 (256 -> 0)
-    tpa_svd_refine = (pairwise & 2097152) ? (1 | ((pairwise & 32768) ? 2 : 0)) : 0;   // bit 21: refinement steps (off by default); bit 15: also for complex data
     tpa_svd_fused_rounds = (pairwise & 8388608) ? 0 : 1;    // bit 23: two launches per Gram-only round
     tpa_svd_overlap_c = (pairwise & 16384) ? 1 : 0;   // bit 14: complex Gram-only rounds with the non-urgent tiles on a second stream (off by default)
-    tpa_svd_solve2 = (pairwise & 4194304) ? 0 : 1;    // bit 22: the round-3 solve kernel (Q and S in LDS, nine wavefronts)
     tpa_svd_gonly = (pairwise & 1048576) ? 0 : 1;     // bit 20: no Gram-only sweeps (the round-3 rounds: gram, solve, apply on the data)
-    tpa_svd_refine_pre = ((pairwise >> 16) & 15) ? (int)((pairwise >> 16) & 15) - 1 : 3;   // bits 16..19: Jacobi sweeps before the first step, + 1
     return 0;
 }
 
-extern "C" int tpa_svd_refine_stats(int64_t *out8, int reset) {
-    for (int i = 0; i < 8; ++i) {
-        out8[i] = tpa_svd_refine_counters[i];
-        if (reset) tpa_svd_refine_counters[i] = 0;
-    }
-    return 0;
-}

@@ -2548,15 +2548,12 @@ def _svd_distributed(L, code, a, jobs, ms, ns, ks, U_arena, S_dev, V_arena, swee
 # NaN re-try of np_conserved.py:4970-4982: every entry is a `tpa_svd_set_algorithm` code that is tried when the previous
 # one returned TPA_E_NOCONV or produced NaNs: default (pivoted-QR preconditioner + fused block Jacobi), block Jacobi
 # without the preconditioner and with two-kernel rounds, then the plain one-wavefront-per-row-pair Jacobi.
-# Round 4: the default (code 0) runs Gram-only sweeps on 32-row blocks (csrc/tpa_svd_b32.inc).  SVD_REFINE (TPA_SVD_REFINE=1, off by
-# default: slower over a whole sweep) adds the end game by simultaneous rotations (bit 21, csrc/tpa_svd_refine.inc).
-SVD_REFINE_ON = 2097152
-SVD_REFINE = os.environ.get('TPA_SVD_REFINE', '0') != '0'
+# Round 4: the default (code 0) runs Gram-only sweeps on 32-row blocks (csrc/tpa_svd_b32.inc).  (The end game by simultaneous
+# rotations of round 4, TPA_SVD_REFINE, was removed in round 5: slower over a whole sweep, never on by default.)
 SVD_ALG0 = int(os.environ.get('TPA_SVD_ALG0', '0'))             # measurement knob: extra bits for the head of the chain (e.g. 1048576 = no Gram-only sweeps)
-SVD_ALGORITHM_CHAIN = ((SVD_REFINE_ON if SVD_REFINE else 0) | SVD_ALG0, 512 | 2, 1 | 512)
-# warm-started calls (`_svd_warm`): no pivoted QR (bit 9); with the refinement the steps begin at once (bits 16-19 = cyclic sweeps
-# before the first step + 1)
-SVD_ALGORITHM_CHAIN_WARM = ((512 | (1 << 16) | SVD_REFINE_ON | SVD_ALG0,) if SVD_REFINE else ()) + (512 | SVD_ALG0, 512 | 2, 1 | 512)
+SVD_ALGORITHM_CHAIN = (SVD_ALG0, 512 | 2, 1 | 512)
+# warm-started and sketch calls (`_svd_warm`): no pivoted QR (bit 9)
+SVD_ALGORITHM_CHAIN_WARM = (512 | SVD_ALG0, 512 | 2, 1 | 512)
 SVD_MAX_SWEEPS = 80
 svd_robust_stats = {'retries': 0, 'last_chain': ()}
 _svd_alg_initialised = False

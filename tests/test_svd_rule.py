@@ -160,3 +160,40 @@ def test_generic_svd_calls_run_without_the_floor(backend, monkeypatch):
     npc.svd_hint = (('test', 0), 'R')
     npc.svd(a)
     assert npc._svd_floor_now[0] == npc.SVD_ABS_FLOOR and npc.svd_hint is None
+
+
+def test_predicted_convergence_sees_pairs_below_the_floor():
+    """Round 5 (found on the MI355X by tests/test_svd_configs_gpu.py): the "no big rotation -> stop" rule of rounds 2-4 measured a rotation
+    against the FLOOR of the stopping rule, so a pair of rows below the floor was never big and the iteration could end on cosines of
+    O(0.1) among such rows once the large rows were done -- harmless after a pivoted QR, wrong on a warm / sketch start of a block graded
+    down to rounding level.  The numpy emulation of the device iteration (same predicate, operation for operation) on such a start:
+    the old rule leaves a defect the first-order clean-up cannot repair, the corrected one (`svd_big_rotation`: every pair against its
+    OWN stopping rule) a defect of ~1e-5 that three Loewdin iterations take to rounding level."""
+    import jacobi_emulation as je
+    rng = np.random.RandomState(1020)
+    m = n = 120
+    r = 60
+    u, _ = np.linalg.qr(rng.standard_normal((m, r)))
+    v, _ = np.linalg.qr(rng.standard_normal((n, r)))
+    A = (u * np.logspace(0, -14.5, r)) @ v.T
+    Bq = np.linalg.svd(A)[2][:r]                       # the basis of the previous visit ...
+    k1, k2 = rng.standard_normal((m, m)) / np.sqrt(m), rng.standard_normal((n, n)) / np.sqrt(n)
+    X = A + 1e-9 * ((k1 - k1.T) @ A + A @ (k2 - k2.T))   # ... and the state after a drift of 1e-9
+    W = Bq @ X.T                                        # what the plain warm start hands to the iteration
+    res = {}
+    for new in (False, True):
+        je.NEW_BIG_RULE = new
+        try:
+            sweeps, Wr = je.jacobi(W, rho=1e-4, predict=1e-7)
+        finally:
+            je.NEW_BIG_RULE = True
+        s = np.linalg.norm(Wr, axis=1)
+        keep = s > 1e-14 * s.max()
+        Vn = Wr[keep] / s[keep, None]
+        res[new] = (sweeps, float(np.abs(Vn @ Vn.T - np.eye(keep.sum())).max()))
+    assert res[False][1] > 1e-3, res          # the flaw: the iteration stopped on large cosines below the floor
+    assert res[True][1] < 1e-4 and res[True][0] > res[False][0], res
+    T = Vn.copy()                              # the clean-up the product runs afterwards: V <- (3 - V V^T) V / 2
+    for _ in range(3):
+        T = 1.5 * T - 0.5 * (T @ T.T) @ T
+    assert np.abs(T @ T.T - np.eye(len(T))).max() < 1e-13
