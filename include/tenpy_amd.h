@@ -91,7 +91,8 @@ int tpa_lanczos_step(int dtype, int64_t n, void *w_dev, const void *v1_dev, cons
  * logic -- tridiagonal eigh :702, `_converged` :713 -- in `cb`).  The matvec is a replayed "program" of cached launches:
  *   ops : HOST int64[n_ops][12] = {kind, cfg, p0, p1, p2, count, a_slot, b_slot, c_slot, max_elems, 0, 0}
  *         kind 0: tpa_gemm_chain(dtype, cfg, tasks = p0, links = p1, tiles = p2, n_tiles = count, A, B, C)
- *         kind 1: tpa_lincomb_batch(dtype, jobs = p0, n_jobs = count, terms = p1, max_elems, src = A, dst = C)
+ *         kind 1: tpa_lincomb_batch(dtype, jobs = p0, n_jobs = count, terms = p1, max_elems, src = A, dst = C); cfg = 1 marks the
+ *                 reduction of the split-K partial blocks of the kind-0 op before it (timed together with that GEMM)
  *         kind 2: tpa_copy_batch(dtype, jobs = p0, n_jobs = count, max_elems, src = A, dst = C)   (pack / unpack of row panels)
  *         kind 3: the caller's collective number `cfg` -- `tpa_lanczos_set_collective` -- is invoked on the host at this point of
  *                 the program; it enqueues an exchange (RCCL all-gather of the row panels of a sharded matvec) that is

@@ -28,17 +28,30 @@ eff = TwoSiteH(None, 3, tensors=(LP, RP, W0, W1))
 assert eff.factored
 p = W0.get_leg('p')
 theta = npc.Array.from_func(rnd, [bond, p, p, bond.conj()], labels=['vL', 'p0', 'p1', 'vR'])
-for _ in range(2):
-    out = eff.matvec(theta)
-torch.cuda.synchronize()
-npc.gemm_timer.reset()
-npc.gemm_timer.enabled = True
-t0 = time.time()
-for _ in range(reps):
-    out = eff.matvec(theta)
-torch.cuda.synchronize()
-dt = (time.time() - t0) / reps
-ms = npc.gemm_timer.collect()
-gt = npc.gemm_timer
-print("factored matvec chi=%d: %.3f ms per matvec, GEMM %.3f ms (%.1f TFLOP/s, %d launches), flops %.3e, min bytes %.3e" % (
-    chi, dt * 1e3, ms / reps, gt.flops / (ms * 1e-3) / 1e12, gt.n_launch // reps, eff.flops_per_matvec, eff.bytes_per_matvec), flush=True)
+knobs = sys.argv[3:] or ['0']      # TPA_GEMM_SPLIT_K values to compare ("max parts,target tiles,min K per part")
+ref = None
+for knob in knobs:
+    npc.GEMM_SPLIT_K = tuple(int(x) for x in knob.split(','))
+    npc._plan_cache.clear()
+    eff._fplans = None
+    for _ in range(2):
+        out = eff.matvec(theta)
+    torch.cuda.synchronize()
+    npc.gemm_timer.reset()
+    npc.gemm_timer.enabled = True
+    t0 = time.time()
+    for _ in range(reps):
+        out = eff.matvec(theta)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / reps
+    ms = npc.gemm_timer.collect()
+    gt = npc.gemm_timer
+    if ref is None:
+        ref = out
+    fp = eff._fplans
+    desc = ["%d tiles%s" % (pl.n_tiles, "" if pl.sk is None else " -> %d in %d parts" % (pl.sk.n_tiles, len(pl.sk.tasks_host)))
+            for pl in (fp['p1'], fp['p2'])]
+    print("factored matvec chi=%d split-K %s: %.3f ms per matvec, GEMM %.3f ms (%.1f TFLOP/s, %d launches), flops %.3e, min bytes %.3e; "
+          "step 1 %s, step 2 %s; |out - out(first knob)| / |out| = %.1e" % (
+              chi, knob, dt * 1e3, ms / reps, gt.flops / (ms * 1e-3) / 1e12, gt.n_launch // reps, eff.flops_per_matvec,
+              eff.bytes_per_matvec, desc[0], desc[1], npc.norm(out - ref) / npc.norm(ref)), flush=True)

@@ -376,6 +376,20 @@ def factored_matvec_possible(LP, RP, W0, W1):
             w0 in (['wL', 'wR', 'p0', 'p0*'], ['wL', 'wR', 'p', 'p*']) and w1 in (['wL', 'wR', 'p1', 'p1*'], ['wL', 'wR', 'p', 'p*']))
 
 
+def _gemm_ops(plan, a_slot, b_slot, c_slot, bufs, scratch_name):
+    """Rows of a `tpa_lanczos_run` program for one planned contraction: the grouped GEMM, or -- split-K plans, `npc._split_k` --
+    the GEMM of the partial blocks into a scratch arena (appended to ``bufs``) followed by their reduction into ``c_slot``
+    (kind 1 with cfg = 1: timed together with the GEMM it completes)."""
+    sk = plan.sk
+    if sk is None:
+        return [[0, plan.cfg, plan.tasks_dev.data_ptr(), plan.links_dev.data_ptr(), plan.tiles_dev.data_ptr(), plan.n_tiles,
+                 a_slot, b_slot, c_slot, 0, 0, 0]]
+    bufs.append(dev.scratch(scratch_name, sk.total, plan.dtype))
+    part = len(bufs) - 1
+    return [[0, plan.cfg, sk.tasks_dev.data_ptr(), sk.links_dev.data_ptr(), sk.tiles_dev.data_ptr(), sk.n_tiles, a_slot, b_slot, part, 0, 0, 0],
+            [1, 1, sk.jobs_dev.data_ptr(), sk.terms_dev.data_ptr(), 0, sk.n_jobs, part, 0, c_slot, sk.max_elems, 0, 0]]
+
+
 class TwoSiteH:
     length = 2
     acts_on = ['(vL.p0)', '(p1.vR)']
@@ -597,11 +611,10 @@ class TwoSiteH:
             if ok:
                 bufs = [self._LPf._arena, self._RPf._arena, dev.scratch('lanczos_t1', p1.res_total, p1.dtype),
                         dev.scratch('lanczos_t3', a01.total, a01.dtype)]
-                ops = np.zeros((3, 12), dtype=np.int64)
-                ops[0, :9] = [0, p1.cfg, p1.tasks_dev.data_ptr(), p1.links_dev.data_ptr(), p1.tiles_dev.data_ptr(), p1.n_tiles, 0, -1, 2]
-                ops[1, :10] = [1, 0, a01.jobs_dev.data_ptr(), a01.terms_dev.data_ptr(), 0, a01.n_jobs, 2, 0, 3, a01.max_elems]
-                ops[2, :9] = [0, p2.cfg, p2.tasks_dev.data_ptr(), p2.links_dev.data_ptr(), p2.tiles_dev.data_ptr(), p2.n_tiles, 3, 1, -2]
-                res = (ops, bufs, (p1, p2))
+                ops = _gemm_ops(p1, 0, -1, 2, bufs, 'lanczos_sk1')
+                ops.append([1, 0, a01.jobs_dev.data_ptr(), a01.terms_dev.data_ptr(), 0, a01.n_jobs, 2, 0, 3, a01.max_elems, 0, 0])
+                ops += _gemm_ops(p2, 3, 1, -2, bufs, 'lanczos_sk2')
+                res = (np.array(ops, dtype=np.int64), bufs, (p1, p2))
                 last = p2
         else:
             if self._plans is None or not self._plan_matches(theta):
@@ -619,10 +632,8 @@ class TwoSiteH:
             p1, p2 = self._plans[0], self._plans[1]
             if p1.dtype == p2.dtype == theta.dtype == self.LHeff.dtype == self.RHeff.dtype and not p1.empty and not p2.empty:
                 bufs = [self.LHeff._arena, self.RHeff._arena, dev.scratch('lanczos_t1', p1.res_total, p1.dtype)]
-                ops = np.zeros((2, 12), dtype=np.int64)
-                ops[0, :9] = [0, p1.cfg, p1.tasks_dev.data_ptr(), p1.links_dev.data_ptr(), p1.tiles_dev.data_ptr(), p1.n_tiles, 0, -1, 2]
-                ops[1, :9] = [0, p2.cfg, p2.tasks_dev.data_ptr(), p2.links_dev.data_ptr(), p2.tiles_dev.data_ptr(), p2.n_tiles, 2, 1, -2]
-                res = (ops, bufs, (p1, p2))
+                ops = _gemm_ops(p1, 0, -1, 2, bufs, 'lanczos_sk1') + _gemm_ops(p2, 2, 1, -2, bufs, 'lanczos_sk2')
+                res = (np.array(ops, dtype=np.int64), bufs, (p1, p2))
                 last = p2
         self.__dict__['_program_out'] = None
         if res is not None and not (last.res_total == theta._arena.numel() and np.array_equal(last.res_qdata, theta._qdata)

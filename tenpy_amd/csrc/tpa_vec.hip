@@ -453,6 +453,8 @@ extern "C" int tpa_lanczos_run(int dtype, int64_t n, const int64_t *ops, int n_o
             } else if (op[0] == 1) {
                 TPA_ARG_CHECK(a != nullptr && c != nullptr);
                 if (int rc = tpa_lincomb_batch(dtype, (const int64_t *)op[2], (int)op[5], (const int64_t *)op[3], op[9], a, c, stream)) return rc;
+                // cfg = 1: the reduction of the split-K partial blocks of the GEMM just launched -- part of that GEMM's time
+                if (time_gemms && op[1] == 1 && n_tev >= 2) TPA_HIP_CHECK(hipEventRecord(H.tev[n_tev - 1], st));
             } else if (op[0] == 2) {        // batched strided copy (pack / unpack of the row panels of a sharded matvec)
                 TPA_ARG_CHECK(a != nullptr && c != nullptr);
                 if (int rc = tpa_copy_batch(dtype, (const int64_t *)op[2], (int)op[5], op[9], a, c, stream)) return rc;

@@ -1917,6 +1917,7 @@ class TensordotPlan:
 
     def __init__(self):
         self.empty = True
+        self.sk = None
 
     def apply(self, a, b, out_arena=None, launch=True):
         """``launch=False``: only the result's bookkeeping and allocation (callers that replay the plan themselves,
@@ -1944,9 +1945,18 @@ class TensordotPlan:
         if b.dtype != self.dtype:
             b_arena = b.astype(self.dtype)._arena
         ev = gemm_timer.begin()
-        dev.check(dev.lib().tpa_gemm_chain(dev.code(self.dtype), self.cfg, self.tasks_dev.data_ptr(), self.links_dev.data_ptr(),
-                                           self.tiles_dev.data_ptr(), self.n_tiles, a_arena.data_ptr(),
-                                           b_arena.data_ptr(), out_arena.data_ptr(), dev.stream()), "gemm_chain")
+        sk = self.sk
+        if sk is None:
+            dev.check(dev.lib().tpa_gemm_chain(dev.code(self.dtype), self.cfg, self.tasks_dev.data_ptr(), self.links_dev.data_ptr(),
+                                               self.tiles_dev.data_ptr(), self.n_tiles, a_arena.data_ptr(),
+                                               b_arena.data_ptr(), out_arena.data_ptr(), dev.stream()), "gemm_chain")
+        else:       # split-K: partial blocks into a scratch arena, then one deterministic reduction pass (see `_split_k`)
+            part = dev.scratch('gemm_split_k', sk.total, self.dtype)
+            dev.check(dev.lib().tpa_gemm_chain(dev.code(self.dtype), self.cfg, sk.tasks_dev.data_ptr(), sk.links_dev.data_ptr(),
+                                               sk.tiles_dev.data_ptr(), sk.n_tiles, a_arena.data_ptr(),
+                                               b_arena.data_ptr(), part.data_ptr(), dev.stream()), "gemm_chain")
+            dev.check(dev.lib().tpa_lincomb_batch(dev.code(self.dtype), sk.jobs_dev.data_ptr(), sk.n_jobs, sk.terms_dev.data_ptr(),
+                                                  sk.max_elems, part.data_ptr(), out_arena.data_ptr(), dev.stream()), "lincomb_batch")
         gemm_timer.end(ev, self)
         return res
 
@@ -2246,7 +2256,101 @@ def _build_plan(a, b, ca, cb, fa, fb):
     plan.bytes_min = int(esz * (np.sum(M[ua] * K[ua]) + np.sum(K_of_b(b_shapes, cb, ub) * N[ub]) + plan.res_total))
     plan.n_gemm = len(gi)
     plan.gemm_shapes = np.stack([M[ga], K[ga], N[gb]], axis=1)
+    plan.sk = _split_k(plan, tasks, links, tm, tn)
     return plan
+
+
+# Split-K for launches with few tiles and long chains (round 5).  A launch of T tiles keeps at most T workgroups busy: the 69 tiles of
+# matvec step 2 at chi = 512 use a quarter of the 256 CUs, the 831 tiles at chi = 2048 sit on the CUs as 3 or 4 workgroups each (81 %
+# balance).  With the knob on, the chain of every C block is cut into up to S parts of whole k-tiles; part p of block t is its own task
+# writing a PARTIAL block into a scratch arena, and one `tpa_lincomb_batch` launch adds the parts up into C in a fixed order
+# (deterministic: no atomics).  No kernel change -- the cut links are ordinary links with shifted offsets.
+# Measured on MI355X (profiles/r05_gemm_split_k.txt): GEMM fraction of the f64 MFMA peak 0.452 -> 0.461 (Heisenberg chi = 2048, step 2 of
+# the matvec: 930 tiles -> 3572), 0.279 -> 0.324 (Hubbard chi = 1024), 0.105 -> 0.132 (XXZ chi = 512); sweeps 1.2 % / 2.2 % / ~2 % shorter.
+# Launches that already have more than ~4 workgroups per CU lose (chi = 1024 step 1, 1336 tiles: 0.130 -> 0.145 ms per matvec when split).
+GEMM_SPLIT_K = tuple(int(x) for x in os.environ.get('TPA_GEMM_SPLIT_K', '4,4096,128,1024').split(','))     # (max parts, target tiles, min K per part, max tiles of a launch that is split); '0' = off
+GEMM_K_TILE = 16
+
+
+class _SplitK:
+    __slots__ = ('tasks_dev', 'links_dev', 'tiles_dev', 'n_tiles', 'total', 'jobs_dev', 'terms_dev', 'n_jobs', 'max_elems',
+                 'tasks_host', 'links_host', 'jobs_host', 'terms_host', 'parts')
+
+
+def _split_k(plan, tasks, links, tm, tn, knob=None):
+    knob = tuple(knob or GEMM_SPLIT_K)
+    s_max, target, min_k, max_tiles = knob + (4096, 128, 1024)[len(knob) - 1:]
+    if s_max < 2 or plan.n_tiles * 2 > target or plan.n_tiles > max_tiles or len(tasks) > 65535:
+        return None
+    s_plan = min(s_max, target // plan.n_tiles)
+    nt = len(tasks)
+    first, counts = tasks[:, 4], tasks[:, 5]
+    assert np.array_equal(first, np.cumsum(counts) - counts) and first[-1] + counts[-1] == len(links)      # chains stored back to back
+    K = links[:, 2]
+    g_end = np.cumsum(K)                    # the contracted indices of all chains laid end to end: link i covers [g_start, g_end)
+    g_start = g_end - K
+    t_start, t_end = g_start[first], g_end[first + counts - 1]
+    ktot = t_end - t_start
+    s_t = np.clip(ktot // max(min_k, 1), 1, s_plan)
+    if np.all(s_t == 1):
+        return None
+    # nominal cuts ktot j / s, snapped to a whole k-tile of the link they fall into (or to that link's end)
+    n_cut = s_t - 1
+    ct = np.repeat(np.arange(nt), n_cut)
+    cj = np.arange(int(np.sum(n_cut))) - np.repeat(np.cumsum(n_cut) - n_cut, n_cut) + 1
+    pos = t_start[ct] + ktot[ct] * cj // s_t[ct]
+    li = np.searchsorted(g_start, pos, side='right') - 1
+    pos = g_start[li] + np.minimum((pos - g_start[li] + GEMM_K_TILE // 2) // GEMM_K_TILE * GEMM_K_TILE, K[li])
+    # boundaries of the parts, task by task: start, cuts, end; parts of length zero (cuts snapped onto each other) are dropped
+    bt = np.concatenate([np.arange(nt), ct, np.arange(nt)])
+    bp = np.concatenate([t_start, pos, t_end])
+    order = np.lexsort((bp, bt))
+    bt, bp = bt[order], bp[order]
+    keep = (bt[:-1] == bt[1:]) & (bp[1:] > bp[:-1])
+    p_task, p0, p1 = bt[:-1][keep], bp[:-1][keep], bp[1:][keep]
+    n_new = len(p_task)
+    if n_new == nt:
+        return None
+    l0 = np.searchsorted(g_start, p0, side='right') - 1
+    l1 = np.searchsorted(g_start, p1, side='left')
+    nl = l1 - l0
+    lb = np.cumsum(nl) - nl
+    idx = np.repeat(l0, nl) + np.arange(int(np.sum(nl))) - np.repeat(lb, nl)
+    new_links = links[idx].copy()
+    c0 = np.maximum(np.repeat(p0, nl), g_start[idx]) - g_start[idx]
+    c1 = np.minimum(np.repeat(p1, nl), g_end[idx]) - g_start[idx]
+    new_links[:, 0] += c0 * new_links[:, 4]
+    new_links[:, 1] += c0 * new_links[:, 5]
+    new_links[:, 2] = c1 - c0
+    m, n = tasks[p_task, 1], tasks[p_task, 2]
+    offs = np.cumsum(m * n) - m * n
+    new_tasks = np.zeros((n_new, 8), dtype=np.int64)
+    new_tasks[:, 0], new_tasks[:, 1], new_tasks[:, 2], new_tasks[:, 3], new_tasks[:, 4], new_tasks[:, 5] = offs, m, n, n, lb, nl
+    terms = np.zeros((n_new, 4), dtype=np.int64)
+    terms[:, 0], terms[:, 1], terms[:, 2] = offs, n, np.array(1.0).view(np.int64)
+    parts = np.bincount(p_task, minlength=nt)
+    jobs = np.zeros((nt, 8), dtype=np.int64)
+    jobs[:, :4] = tasks[:, :4]
+    jobs[:, 4], jobs[:, 5] = np.cumsum(parts) - parts, parts
+    works = p1 - p0
+    off = int(np.sum(m * n))
+    sk = _SplitK()
+    sk.parts = parts
+    ntile = np.repeat(tm * tn, sk.parts)
+    t_task = np.repeat(np.arange(n_new), ntile)
+    local = np.arange(int(np.sum(ntile))) - np.repeat(np.cumsum(ntile) - ntile, ntile)
+    tn_new, tm_new = np.repeat(tn, sk.parts), np.repeat(tm, sk.parts)
+    t_row, t_col = local // np.repeat(tn_new, ntile), local % np.repeat(tn_new, ntile)
+    order = _xcd_tile_order(t_task, t_row, t_col, np.repeat(works, ntile), np.repeat(tm_new, ntile),
+                            np.repeat(tn_new, ntile))
+    tiles = np.zeros((len(t_task), 4), dtype=np.int32)
+    tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task[order], t_row[order], t_col[order]
+    sk.tasks_host, sk.links_host, sk.jobs_host, sk.terms_host = new_tasks, new_links, jobs, terms
+    sk.tasks_dev, sk.links_dev, sk.tiles_dev = dev.to_device(sk.tasks_host), dev.to_device(sk.links_host), dev.to_device(tiles)
+    sk.jobs_dev, sk.terms_dev = dev.to_device(sk.jobs_host), dev.to_device(sk.terms_host)
+    sk.n_tiles, sk.total, sk.n_jobs = len(tiles), off, len(jobs)
+    sk.max_elems = int(np.max(tasks[:, 1] * tasks[:, 2]))
+    return sk
 
 
 N_XCD = 8
