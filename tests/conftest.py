@@ -8,6 +8,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+CPU_WORKERS = int(os.environ.get('TPA_TEST_WORKERS', '4'))
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """Without a GPU (the build container) the suite is host logic on the numpy emulation of the device: independent, CPU-bound
+    tests, 8.5 min one after the other.  If pytest-xdist is there and the caller did not choose, run them on ``CPU_WORKERS`` worker
+    processes (``TPA_TEST_WORKERS=0`` or ``-n 0`` / ``-p no:xdist``: serial).  With a GPU nothing changes: one process, one device."""
+    opt = config.option
+    if CPU_WORKERS < 2 or not hasattr(opt, 'numprocesses') or opt.numprocesses is not None or getattr(opt, 'collectonly', False):
+        return None
+    if getattr(opt, 'usepdb', False) or os.path.exists('/dev/kfd') or os.environ.get('PYTEST_XDIST_WORKER'):
+        return None
+    opt.numprocesses = CPU_WORKERS
+    if getattr(opt, 'dist', 'no') == 'no':
+        opt.dist = 'load'
+    if not getattr(opt, 'tx', None):
+        opt.tx = ['popen'] * CPU_WORKERS
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running")

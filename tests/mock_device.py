@@ -91,6 +91,18 @@ def _host(ptr, shape, dtype=np.int64):
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
+def _strided(base, off, shape, strides, writeable=False):
+    """2-d view base[off + i * strides[0] + j * strides[1]] of a flat array, bounds-checked like the index arrays it replaces
+    (element strides, all non-negative in the tables of the kernels)."""
+    off, shape, strides = int(off), tuple(int(x) for x in shape), tuple(int(x) for x in strides)
+    assert off >= 0 and min(strides) >= 0 and min(shape) >= 1
+    last = off + sum((n - 1) * st for n, st in zip(shape, strides))
+    if last >= len(base):
+        raise IndexError("mock_device: index %d is out of bounds for the arena view of size %d" % (last, len(base)))
+    isz = base.itemsize
+    return np.lib.stride_tricks.as_strided(base[off:], shape=shape, strides=tuple(st * isz for st in strides), writeable=writeable)
+
+
 class MockLib:
     def __init__(self):
         self.real = _lib.load()
@@ -118,19 +130,18 @@ class MockLib:
                 a_off, b_off, k, a_rs, a_ks, b_ks, b_ns, flags = links_all[8 * l:8 * l + 8]
                 if k <= 0:
                     continue
-                ai = a_off + np.arange(r0, r1)[:, None] * a_rs + np.arange(k)[None, :] * a_ks
-                bi = b_off + np.arange(k)[:, None] * b_ks + np.arange(c0, c1)[None, :] * b_ns
-                Am, Bm = A[ai], B[bi]
+                Am = _strided(A, a_off + r0 * a_rs, (r1 - r0, k), (a_rs, a_ks))
+                Bm = _strided(B, b_off + c0 * b_ns, (k, c1 - c0), (b_ks, b_ns))
                 if flags & 1:
                     Am = Am.conj()
                 if flags & 2:
                     Bm = Bm.conj()
                 out += Am @ Bm
-            ci = c_off + np.arange(r0, r1)[:, None] * ldc + np.arange(c0, c1)[None, :]
+            Cm = _strided(C, c_off + r0 * ldc + c0, out.shape, (ldc, 1), writeable=True)
             if acc:
-                C[ci] += out
+                Cm += out
             else:
-                C[ci] = out
+                Cm[...] = out
         return 0
 
     # ---- K2-K4 -----------------------------------------------------------------------------------

@@ -133,9 +133,13 @@ def test_cache_storages_hold_device_arrays(tmp_path, where):
                              capture_output=True, text=True, timeout=1200)
         assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
         return json.loads([l for l in res.stdout.splitlines() if l.startswith('RESULT ')][0][7:])
-    ram = run('Storage', False, 'ram')
-    for storage, threads in (('PickleStorage', False), ('PickleStorage', True), ('Hdf5Storage', False)):
-        got = run(storage, threads, storage + str(int(threads)))
+    from concurrent.futures import ThreadPoolExecutor
+    cases = (('PickleStorage', False), ('PickleStorage', True), ('Hdf5Storage', False))
+    with ThreadPoolExecutor(4) as pool:         # four independent processes: run them side by side
+        f_ram = pool.submit(run, 'Storage', False, 'ram')
+        futs = [pool.submit(run, storage, threads, storage + str(int(threads))) for storage, threads in cases]
+        ram, results = f_ram.result(), [f.result() for f in futs]
+    for (storage, threads), got in zip(cases, results):
         assert got['n_stored'] > 0, "nothing was handed to the storage"
         np.testing.assert_allclose(got['E'], ram['E'], rtol=1e-13, atol=0)
         np.testing.assert_allclose(got['S'], ram['S'], rtol=0, atol=1e-13)

@@ -54,11 +54,11 @@ FAST = [
     ['test_charges.py'],
     ['test_np_conserved.py', '-k', 'not test_expm'],
     ['test_krylov_based.py', 'test_sparse.py', 'test_svd_robust.py'],
-    ['test_truncation.py', '-k', 'truncate or (decompose and 45-True-parity-True)'],
+    ['test_truncation.py', '-k', 'truncate or (decompose and 45-True-parity-True)', '-n', '3'],
     # callers: two-site DMRG, single-site DMRG with the subspace-expansion mixer (in-place scaling of a transposed H_eff half:
     # needs the copy-on-write arenas), finite TEBD, MPS.from_full of 5 sites (rank-12 combine_legs), a purification
-    ['test_dmrg.py', '-k', 'finite-True-False-2 or finite-True-True-1'],
-    ['test_tebd.py', '-k', 'finite-standard'],
+    ['test_dmrg.py', '-k', 'finite-True-False-2 or finite-True-True-1', '-n', '2'],
+    ['test_tebd.py', '-k', 'finite-standard', '-n', '3'],
     ['test_purification.py', '-k', 'from_density_matrix and Sz'],
 ]
 
@@ -83,7 +83,7 @@ def test_reference_tebd_with_fused_callers(where):
     """The reference's ``test_tebd.py`` (finite cases: standard and QR-based engines, real and imaginary time) with
     ``install(fused=True)``: ``TEBDEngine.evolve_step`` is the batched form of ``module_form.batched_tebd_evolve_step``."""
     _needs(where)
-    out = run_reference_tests(['test_tebd.py', '-k', 'finite'], extra_env={'TPA_REFSUITE_FUSED': '1'})
+    out = run_reference_tests(['test_tebd.py', '-k', 'finite', '-n', '4'], extra_env={'TPA_REFSUITE_FUSED': '1'})
     assert ' passed' in out and ' failed' not in out
 
 
