@@ -82,22 +82,30 @@ def scratch(name, n, dtype):
     allocator for a different size every call splits its cached blocks and ends in a fresh hipMalloc per call (measured: the
     same ``tpa_svd_batch`` took 20.7 instead of 16.4 ms when 300 MB of temporaries had been allocated and freed before it).
     The contents are only valid until the next request under the same name; all users are ordered on one stream."""
-    dt = np.dtype(dtype)
-    n = int(n)
-    need = max(n, 1) * dt.itemsize
     ident = _thread_ident()
     if ident != _main_thread[0]:
         name = (name, ident)          # a second host thread (DMRGThreadPlusHC) gets pools of its own
+    n = int(n)
     ent = _pool.get(name)
+    if ent is not None:               # the same (size, type) again -- every bond of a sweep asks ~24 times: the view made last time
+        got = ent[2].get((n, dtype))
+        if got is not None:
+            return got
+    dt = np.dtype(dtype)
+    need = max(n, 1) * dt.itemsize
     if ent is None or ent[0].numel() * 8 < need:
         buf = empty(((int(need * 1.5) + 7) // 8 + 32) // 2 * 2, np.float64)      # `empty`: the (test-patchable) allocator; even: complex views
-        ent = _pool[name] = (buf, {})
-    buf, views = ent
+        ent = _pool[name] = (buf, {}, {})
+    buf, views, sized = ent
     v = views.get(dt.char)
     if v is None:
         import torch as real_torch
         v = views[dt.char] = buf.view({'float64': real_torch.float64, 'complex128': real_torch.complex128, 'uint8': real_torch.uint8}[dt.name])
-    return v[:max(n, 1)] if n > 0 else v[:0]
+    out = v[:max(n, 1)] if n > 0 else v[:0]
+    if len(sized) >= 64:
+        sized.clear()
+    sized[(n, dtype)] = out
+    return out
 
 
 PIN_RING_BYTES = 64 << 20
