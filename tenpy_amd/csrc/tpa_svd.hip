@@ -1336,6 +1336,42 @@ __global__ __launch_bounds__(NT) void svd_norms_kernel(const SvdJob *__restrict_
     if (lane == 0) sig[J.sig_off + jr.y] = sqrt(a);
 }
 
+// The order of the singular values on the device (round 5): perm[sig_off + rank(j)] = j with
+//     rank(j) = #{i : s_i > s_j} + #{i < j : s_i == s_j},
+// the permutation of a stable sort by descending sigma (what the host did with std::stable_sort between two copies: D2H of sigma, a
+// synchronisation, the sort, H2D of the permutation; profiles/r05_idle_gap_analysis.txt "svd_norms -> svd_finish").  One wavefront per row
+// counts; O(R^2 / 64) compares per wavefront, R <= a few thousand.  A sigma that is not finite sorts last (so that perm is a permutation
+// whatever the data) and raises *bad.  Measured: the same permutation (every parity field of the bench line unchanged to the last digit),
+// 8.54 instead of 8.54 - 8.62 ms per npc.svd at chi = 2048, 2.70 instead of 2.71 at chi = 512 -- one synchronisation and two copies fewer per
+// call, worth less than 1 % (the host sorted while the device had nothing else to do anyway, and the final synchronisation stays).
+__global__ __launch_bounds__(NT) void svd_rank_kernel(const SvdJob *__restrict__ jobs, const int2 *__restrict__ rows,
+                                                      const double *__restrict__ sig, int64_t *__restrict__ perm, unsigned int *bad) {
+    const int gw = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int2 jr = rows[gw];
+    if (jr.x < 0) return;
+    const SvdJob J = jobs[jr.x];
+    const double *s = sig + J.sig_off;
+    const int64_t j = jr.y;
+    const double sj = s[j];
+    const bool fin = isfinite(sj);
+    const double kj = fin ? sj : -1.0;
+    double before = 0;
+    for (int64_t i = lane; i < J.R; i += 64) {
+        const double si = s[i];
+        const double ki = isfinite(si) ? si : -1.0;
+        if (ki > kj || (ki == kj && i < j)) before += 1.0;
+    }
+    before = wave_sum(before);
+    if (lane == 0) {
+        perm[J.sig_off + (int64_t)before] = j;
+        if (!fin) {
+            *bad = 1u;
+            __threadfence_system();
+        }
+    }
+}
+
 // rows[gw] = (job, sorted position jj); perm[sig_off + jj] = source row
 template <bool CPLX>
 __global__ __launch_bounds__(NT) void svd_finish_kernel(const SvdJob *__restrict__ jobs,
@@ -3120,30 +3156,15 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     if (sweeps_done) *sweeps_done = sweep;
     svd_norms_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, W, sig);
     TPA_LAUNCH_CHECK();
-    double *hs = (double *)pin_stage().take((size_t)lay.sig_elems * 8 + 8, st);
-    int64_t *hp = (int64_t *)pin_stage().take((size_t)lay.sig_elems * 8 + 8, st);
-    TPA_STAGE_CHECK(hs);
-    TPA_STAGE_CHECK(hp);
-    TPA_HIP_CHECK(hipMemcpyAsync(hs, sig, lay.sig_elems * 8, hipMemcpyDeviceToHost, st));
-    TPA_HIP_CHECK(hipStreamSynchronize(st));
-    bool bad = false;
-    for (int b = 0; b < n_jobs; ++b) {
-        const SvdJob &J = lay.jobs[b];
-        int64_t *p = hp + J.sig_off;
-        const double *s = hs + J.sig_off;
-        std::iota(p, p + J.R, (int64_t)0);
-        std::stable_sort(p, p + J.R, [s](int64_t x, int64_t y) { return s[x] > s[y]; });
-        for (int64_t i = 0; i < J.R; ++i)
-            if (!std::isfinite(s[i])) bad = true;
-    }
-    if (bad) {
-        snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: NaN/Inf in singular values");
-        return TPA_E_NAN;
-    }
-    TPA_HIP_CHECK(hipMemcpyAsync(perm, hp, lay.sig_elems * 8, hipMemcpyHostToDevice, st));
+    posted[4] = 0u;     // (mapped host word: set by svd_rank_kernel if a singular value is not finite)
+    svd_rank_kernel<<<g_rows, NT, 0, st>>>(jobs, rows, sig, perm, posted + 4);      // descending order, stable: no host round trip
     svd_finish_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, perm, W, G, sig, (double *)u_base, s_dev, (double *)vh_base);
     TPA_LAUNCH_CHECK();
     TPA_HIP_CHECK(hipStreamSynchronize(st));  // callers read the results (and the staging arena is reused by the next call)
+    if (posted[4]) {
+        snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: NaN/Inf in singular values");
+        return TPA_E_NAN;
+    }
     if (!converged) {
         snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: no convergence in %d sweeps", max_sweeps);
         return TPA_E_NOCONV;
