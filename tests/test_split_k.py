@@ -133,3 +133,67 @@ def test_native_lanczos_with_split_plans(backend, monkeypatch, factored):
     assert abs(E1 - E0) <= 1e-12 * max(1., abs(E0))
     assert abs(npc.inner(v0, v1, axes='range', do_conj=True) - 1.) < 1e-12
     assert npc.norm(hv0 - hv1) <= 1e-13 * npc.norm(hv0)
+
+
+def test_default_knob_on_a_chi2048_structure(backend):
+    """The tables of the default knob on the block structure of the chi = 2048 Heisenberg matvec (synthetic Sz sectors, no arithmetic): step 1
+    (thousands of tiles) is left alone, step 2 (hundreds of tiles, chains over the MPO index and the bond sectors) is cut into <= 4 parts per block,
+    every part covers >= 128 contracted indices, cuts inside a link fall on whole k-tiles, and the parts tile the chains exactly."""
+    if backend != 'mock':
+        pytest.skip("table check only: the emulated device is enough")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts'))
+    from gemm_bench import sectors
+    from tenpy_amd.models.spin_chains import xxz_chain_mpo
+    assert npc.GEMM_SPLIT_K[0] >= 2, "the default knob is on"
+    chi = 2048
+    H = xxz_chain_mpo(8, 1., 1., 0.)
+    W0, W1 = H.get_W(3), H.get_W(4)
+    q, n = sectors(chi)
+    bond = LegCharge.from_qind(W0.chinfo, np.concatenate([[0], np.cumsum(n)]), q.reshape(-1, 1), qconj=+1)
+    zeros = lambda sh: np.zeros(sh)
+    LP = npc.Array.from_func(zeros, [bond, W0.get_leg('wL').conj(), bond.conj()], labels=['vR*', 'wR', 'vR'])
+    RP = npc.Array.from_func(zeros, [bond, W1.get_leg('wR').conj(), bond.conj()], labels=['vL', 'wL', 'vL*'])
+    p = W0.get_leg('p')
+    theta = npc.Array.from_func(zeros, [bond, p, p, bond.conj()], labels=['vL', 'p0', 'p1', 'vR'])
+    eff = mps_common.TwoSiteH(None, 3, tensors=(LP, RP, W0, W1))
+    assert eff.factored
+    prog = eff.matvec_program(theta)
+    assert prog is not None
+    p1, p2 = prog[2]
+    assert p1.n_tiles > 1024 and p1.sk is None
+    sk = p2.sk
+    assert 64 < p2.n_tiles <= 1024 and sk is not None
+    assert sk.parts.max() <= 4 and sk.parts.min() >= 1 and sk.n_tiles > 2 * p2.n_tiles
+    tasks, links = p2.tasks_host, p2.links_host
+    # coverage: per original link, the pieces cut from it are disjoint, in order, and add up to its k
+    key = lambda l: (int(l[3]), int(l[4]), int(l[5]), int(l[6]), int(l[7]))
+    it = 0
+    for t in range(len(tasks)):
+        lb, lc = int(tasks[t, 4]), int(tasks[t, 5])
+        orig = links[lb:lb + lc]
+        pos = 0                  # walks through the original chain
+        done = 0                 # contracted indices of orig[pos] covered so far
+        for _ in range(int(sk.parts[t])):
+            nt = sk.tasks_host[it]
+            it += 1
+            part_k = 0
+            for l in sk.links_host[int(nt[4]):int(nt[4] + nt[5])]:
+                o = orig[pos]
+                assert key(l) == key(o)
+                assert int(l[0]) == int(o[0]) + done * int(o[4]) and int(l[1]) == int(o[1]) + done * int(o[5])
+                if done:
+                    assert done % npc.GEMM_K_TILE == 0, "a cut inside a link falls on a whole k-tile"
+                done += int(l[2])
+                part_k += int(l[2])
+                assert done <= int(o[2])
+                if done == int(o[2]):
+                    pos, done = pos + 1, 0
+            assert part_k >= 100 or sk.parts[t] == 1, "no crumbs: parts are cut at ~ K / parts >= 128, snapped by at most half a k-tile"
+        assert pos == lc and done == 0
+    assert it == len(sk.tasks_host)
+    # the launch program carries the reduction as a kind-1 op with cfg = 1 right after the split GEMM
+    ops = np.asarray(prog[0])
+    k = [i for i in range(len(ops)) if ops[i, 0] == 1 and ops[i, 1] == 1]
+    assert len(k) == 1 and ops[k[0] - 1, 0] == 0 and ops[k[0] - 1, 5] == sk.n_tiles and ops[k[0], 8] == -2
