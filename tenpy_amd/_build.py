@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT_DIR = os.path.join(HERE, "_lib")
+OUT_DIR = os.environ.get("TPA_BUILD_OUT") or os.path.join(HERE, "_lib")      # (TPA_BUILD_OUT + TPA_BUILD_FLAGS: a build variant beside the default, loaded with TPA_LIB_PATH)
 LIB_PATH = os.path.join(OUT_DIR, "libtenpy_amd.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -74,6 +74,11 @@ def load(build_if_missing=True):
         return _lib
     import torch  # noqa: F401  (loads libamdhip64.so.7 first; device memory + streams come from torch)
     path = _build.LIB_PATH
+    alt = os.environ.get('TPA_LIB_PATH')          # dev aid: an explicitly named build variant (e.g. compiled with -DTPA_B32_TIMING)
+    if alt:
+        if not os.path.exists(alt):
+            raise BackendError("tenpy_amd: TPA_LIB_PATH=%s does not exist" % alt)
+        path, build_if_missing = alt, False
     if not os.path.exists(path):
         if not build_if_missing:
             raise BackendError("tenpy_amd: %s not built; run `python -m tenpy_amd._build`" % path)

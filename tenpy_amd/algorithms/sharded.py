@@ -72,6 +72,9 @@ def restrict_plan_rows(plan, res_leg0, lo, hi):
     ``[lo, hi)``.  Works on the host tables: ``c_off += r0*ldc``, ``m = r1-r0``, ``a_off += r0*a_rs``."""
     sub = npc.TensordotPlan()
     sub.__dict__.update(plan.__dict__)
+    # the split-K tables of the FULL plan cover all rows: a sub-plan that kept them would run the whole GEMM (and its reduction) on
+    # every rank through `TensordotPlan.apply`, which prefers `sk` (ADVICE r5).  The row panels are launches of their own size.
+    sub.sk = None
     if plan.empty:
         return sub
     tasks, links = plan.tasks_host, plan.links_host

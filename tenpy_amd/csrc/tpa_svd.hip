@@ -3052,12 +3052,13 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 return;
             }
             // one launch per round: solve(r) on S_r formed from S_(r-1) and the transforms of round r - 1, + the tiles of update(r - 1)
+            static const int b32_prio = getenv("TPA_B32_PRIO") ? atoi(getenv("TPA_B32_PRIO")) : 0;      // experiment: s_setprio of the angle wavefront
             if (r == 0)
-                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, full_local, sbuf[0], 0);
+                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, full_local | (b32_prio << 8), sbuf[0], 0);
             else
                 svd_b32_round_kernel<<<n_pairs + n_gup, NTS3, 0, st>>>(jobs, b32p, n_pairs, gup, r, sbuf[(r - 1) & 1], sbuf[r & 1], Qm,
                                                                        qb2[(r - 1) & 1], qb2[r & 1], fb2[(r - 1) & 1], fb2[r & 1], cnt, fro2,
-                                                                       rho, full_local);
+                                                                       rho, full_local | (b32_prio << 8));
             if (r == rounds_g - 1)    // the transforms of the last round still have to reach Qtot (its S tiles are never read)
                 svd_b32_gupdate_kernel<<<n_gup - lay.n_gup_s, NTB, 0, st>>>(gup + lay.n_gup_s, r, sbuf[r & 1], Qm, qb2[r & 1], fb2[r & 1]);
         };

@@ -358,6 +358,34 @@ def _tick(name):
 
 
 
+DUMP_W = os.environ.get('TPA_SVD_DUMP_W')               # dev aid: directory for the Jacobi inputs of the largest block of warm / sketch calls
+DUMP_MAX = int(os.environ.get('TPA_SVD_DUMP_MAX', '6'))
+DUMP_MIN_ROWS = int(os.environ.get('TPA_SVD_DUMP_MIN_ROWS', '400'))
+DUMP_SKIP = int(os.environ.get('TPA_SVD_DUMP_SKIP', '0'))        # qualifying calls to let pass first (reach the steady state)
+DUMP_STRIDE = int(os.environ.get('TPA_SVD_DUMP_STRIDE', '1'))    # then every n-th qualifying call (different bonds)
+_dumped = [0]
+_dump_seen = [0]
+
+
+def _dump_jacobi_input(kind, dtype, arena, jjobs):
+    """Write the largest block the Jacobi iteration is about to see (rows x length, as handed over) to ``DUMP_W`` -- the input of
+    the offline emulation of the iteration, scripts/warm_trace_emulate.py.  Calls whose largest block has < DUMP_MIN_ROWS rows are skipped."""
+    if _dumped[0] >= DUMP_MAX or np.dtype(dtype).kind == 'c':
+        return
+    j = np.asarray(jjobs)
+    big = int(np.argmax(j[:, 1]))
+    off, r, ln = (int(x) for x in j[big, :3])
+    if r < DUMP_MIN_ROWS:
+        return
+    _dump_seen[0] += 1
+    if _dump_seen[0] <= DUMP_SKIP or (_dump_seen[0] - DUMP_SKIP - 1) % DUMP_STRIDE:
+        return
+    os.makedirs(DUMP_W, exist_ok=True)
+    W = dev.to_host(arena[off:off + r * ln]).reshape(r, ln)
+    np.save(os.path.join(DUMP_W, 'W%02d_%s_%dx%d.npy' % (_dumped[0], kind, r, ln)), W)
+    _dumped[0] += 1
+
+
 def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, side, run_svd, out, lowdin_basis=True, need_all=False):
     """Warm-started SVD of the blocks ``A_b`` (``ms[b] x ns[b]`` row-major at ``offs[b]``, packed back to back) with row
     bases ``Bq_b`` (``b_k[b] x b_len[b]`` row-major at ``b_off[b]`` in ``b_arena``; ``b_k[b] = 0``: no basis for block b).
@@ -435,6 +463,8 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
     JU = dev.scratch('warm_JU', B['nJU'], dtype)
     JV = dev.scratch('warm_JV', B['nJV'], dtype)
     JS = dev.scratch('warm_JS', B['nJS'], np.float64)
+    if DUMP_W:
+        _dump_jacobi_input('warm', dtype, W, B['jjobs'])
     S_J = run_svd(B['jjobs'], W, JU, JS, JV, False)
     if PROFILE:
         _tick('t_warm_jacobi')
@@ -708,6 +738,8 @@ def svd_blocks_sketch(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, 
     JV = dev.scratch('warm_JV', pl['nC'], dtype)
     if PROFILE:
         _tick('t_sketch_scratch')
+    if DUMP_W:
+        _dump_jacobi_input('sketch', dtype, C, pl['jjobs'])
     S_J = run_svd(pl['jjobs'], C, JU, JS, JV, False)
     if PROFILE:
         _tick('t_sketch_jacobi')
