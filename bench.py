@@ -533,6 +533,7 @@ def run(argv=None, emit=True):
             n_svd = max(npc.svd_stats['calls'] - svd_calls0, 1)
             out["svd_stats"] = {"calls_timed": n_svd, "jacobi_sweeps_per_call": (npc.svd_stats['sweeps'] - svd_sweeps0) / n_svd,
                                 "max_block": npc.svd_stats['max_block'], "abs_floor": npc.SVD_ABS_FLOOR,
+                                "floor_on_min": bool(npc.SVD_FLOOR_ON_MIN), "jacobi_rounds": _dyn_rounds(),
                                 "warm": {k: (v - warm0.get(k, 0)) for k, v in _svd_warm.stats.items() if not k.startswith('e_rel')},
                                 "note": "warm = calls started from the singular vectors this bond produced on its previous visit "
                                         "(no pivoted QR; linalg/_svd_warm.py); the rest took the cold path; sweep counts include the "
@@ -659,7 +660,7 @@ def compact(out):
                           "warm_calls": w.get("warm_calls"), "sketch_calls": w.get("sketch_calls"), "cold_calls": w.get("cold_calls"),
                           "sk_residual": w.get("sk_residual"), "fb_stale": w.get("fb_stale"),
                           "sweeps_per_call": {k: round(w.get(k + "_sweeps", 0) / max(w.get(k + "_calls", 0), 1), 2) for k in ("warm", "sketch", "cold")},
-                          "abs_floor": ss.get("abs_floor")}
+                          "abs_floor": ss.get("abs_floor"), "floor_on_min": ss.get("floor_on_min"), "jacobi_rounds": ss.get("jacobi_rounds")}
     ls = out.get("lanczos_stats")
     if isinstance(ls, dict):
         c["lanczos_stats"] = {k: v for k, v in ls.items() if k != "note"}
@@ -898,6 +899,18 @@ def _free_port():
     with socket.socket() as so:
         so.bind(('127.0.0.1', 0))
         return so.getsockname()[1]
+
+
+def _dyn_rounds():
+    """Rounds the activity-driven schedule of the Gram-only sweeps launched against the round-robin count (whole process)."""
+    try:
+        import ctypes
+        from tenpy_amd import _lib
+        o = (ctypes.c_int64 * 3)()
+        _lib.load().tpa_svd_dyn_stats(o, 0)
+        return {"launched": int(o[0]), "round_robin": int(o[1]), "sweeps": int(o[2])}
+    except Exception:      # the emulated device has no such counters
+        return None
 
 
 def main():

@@ -145,6 +145,12 @@ int tpa_lincomb_batch(int dtype, const int64_t *jobs_dev, int n_jobs, const int6
 int tpa_scale_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems,
                          void *x_base, const void *s_dev, int s_is_complex, void *stream);
 int tpa_fill_zero(void *dst_dev, int64_t n_bytes, void *stream);
+/* G_b <- strict lower triangle of G_b, diagonal (G_ii - 1) / 2, zeros above, for square blocks G_b (n x n row-major at g_off).
+ * With G = T T^H the Gram matrix of row vectors sorted by descending singular value, T <- T - G T orthonormalises every vector
+ * against the vectors before it (one ordered Gram-Schmidt step on the matrix cores, defect d -> O(d^2)): the post-processing of
+ * the singular vectors below the absolute floor of the block SVD, where the reference gets LAPACK's orthonormal vectors
+ * (np_conserved.py:4970 svd_flat).  jobs: int64[n][2] = {g_off, n}. */
+int tpa_tri_lower_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems, void *g_base, void *stream);
 /* dst[b][i, j, l] = src[b][i, idx[idx_off + j], l] for blocks viewed as (pre, len, post): the np.compress
  * of iproject (np_conserved.py:1982).  jobs: int64[n][8] = {dst_off, src_off, pre, len_src, len_dst, post,
  * idx_off, 0}; idx_dev: int64 indices. */
@@ -181,6 +187,12 @@ int tpa_gemm_set_variant(int v);
  *   pivoting (X P = Q [R;0], X = A or A^T); the Jacobi iteration then runs on the r x min(m,n) factor only
  *   (r = numerical rank: residual column norms <= 1e-15 ||A||_F).  Singular values below that threshold are
  *   returned as exact zeros with zero singular vectors (LAPACK returns rounding noise there).
+ * tol: absolute floor rho of the stopping rule, |tol| <= 1 (0: the purely relative Hestenes criterion, every pair converged to a
+ *   cosine of eps sqrt(L)).  tol > 0: pairs whose LARGER row is below rho |A|_F stop at |x.y| <= eps sqrt(L) |y| rho |A|_F (rounds
+ *   1 - 5; exact after a SYMMETRIC re-orthonormalisation of the small vectors).  tol < 0 (round 6, what the engines pass): the floor
+ *   |tol| acts on the SMALLER row, |x.y| <= eps sqrt(L) |x| max(|y|, rho |A|_F) with |x| >= |y| -- the same absolute accuracy of
+ *   U S VH and of S provided the caller orthonormalises the normalised rows in DESCENDING order of S (every vector against the
+ *   ones before it: tpa_tri_lower_batch), far fewer rotations on spectra graded down to rounding level.
  * Returns TPA_E_NOCONV if max_sweeps is exhausted, TPA_E_NAN if the input holds NaN/Inf.
  */
 int64_t tpa_svd_worksize(int dtype, const int64_t *jobs_host, int n_jobs);
@@ -208,6 +220,11 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
  * could end on cosines of O(0.1) among them).  (Bits 15 - 19 and 21 switched the round-4 end game by simultaneous rotations +
  * Newton-Schulz steps: measured slower over a whole sweep, never on by default, removed in round 5 with its counters.) */
 int tpa_svd_set_algorithm(int pairwise);
+/* Round 6 -- activity-driven rounds of the Gram-only sweeps (real data; bit 24 (16777216) of tpa_svd_set_algorithm = off): at the start
+ * of a sweep a kernel tests, on the exact Gram matrix, which pairs of 32-row blocks contain a row pair that needs a rotation; the host
+ * packs only those block pairs into perfect matchings (the rounds of that sweep) and ends the iteration after a sweep that started
+ * without "big" pairs.  tpa_svd_dyn_stats: out = {rounds launched, rounds the round-robin schedule would have run, sweeps}. */
+int tpa_svd_dyn_stats(int64_t *out, int reset);
 /* Diagnostic ring of the most recent tpa_svd_batch calls (host): rows of out = {min(m, n) of the largest block, its max(m, n),
  * blocks, sweeps, pivoted QR used, algorithm switches, wall microseconds inside the call, return code}; returns the rows written. */
 int64_t tpa_svd_call_log(int64_t *out, int64_t max_rows, int reset);

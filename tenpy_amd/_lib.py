@@ -41,6 +41,8 @@ _SIGS = {
     "tpa_krylov_combine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpa_copy_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp]),
     "tpa_lincomb_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_int64, _vp, _vp, _vp]),
+    "tpa_svd_dyn_stats": (ctypes.c_int, [_i64p, ctypes.c_int]),
+    "tpa_tri_lower_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp]),
     "tpa_scale_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, ctypes.c_int, _vp]),
     "tpa_gather_axis_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "tpa_axis_sqnorm_batch": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),

@@ -243,6 +243,47 @@ extern "C" int tpa_scale_axis_batch(int dtype, const int64_t *jobs_dev, int n_jo
     return 0;
 }
 
+// Ordered (Gram-Schmidt like) orthonormalisation step on the Gram matrix G = T T^H of row vectors sorted by DESCENDING weight:
+// G <- strict lower triangle of G, diagonal (G_ii - 1) / 2, zero above.  Then T <- T - G T makes every vector orthogonal to the
+// vectors BEFORE it (to second order in the defect) and moves no vector towards a later one: the clean-up of the small singular
+// vectors of the block SVD (tenpy_amd/linalg/_svd_warm.py::ordered_rows).  jobs: int64[n][2] = {g_off, n}.
+struct TriJob {
+    int64_t g_off, n;
+};
+
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void tri_lower_kernel(const TriJob *__restrict__ jobs, double *__restrict__ g) {
+    const TriJob J = jobs[blockIdx.y];
+    const int64_t total = J.n * J.n;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < total; e += (int64_t)gridDim.x * NT) {
+        const int64_t i = e / J.n, j = e - i * J.n;
+        if (!CPLX) {
+            double v = g[J.g_off + e];
+            v = (i > j) ? v : (i == j) ? 0.5 * (v - 1.0) : 0.0;
+            g[J.g_off + e] = v;
+        } else {
+            double2 v = reinterpret_cast<double2 *>(g)[J.g_off + e];
+            v = (i > j) ? v : (i == j) ? double2{0.5 * (v.x - 1.0), 0.0} : double2{0.0, 0.0};
+            reinterpret_cast<double2 *>(g)[J.g_off + e] = v;
+        }
+    }
+}
+
+extern "C" int tpa_tri_lower_batch(int dtype, const int64_t *jobs_dev, int n_jobs, int64_t max_job_elems, void *g_base,
+                                   void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n_jobs <= 0) return 0;
+    TPA_ARG_CHECK(n_jobs <= 65535);
+    dim3 grid(grid_x(max_job_elems), n_jobs);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TPA_F64)
+        tri_lower_kernel<false><<<grid, NT, 0, st>>>((const TriJob *)jobs_dev, (double *)g_base);
+    else
+        tri_lower_kernel<true><<<grid, NT, 0, st>>>((const TriJob *)jobs_dev, (double *)g_base);
+    TPA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int tpa_gather_axis_batch(int dtype, const int64_t *jobs_dev, int n_jobs,
                                      int64_t max_job_elems, const int64_t *idx_dev,
                                      const void *src_base, void *dst_base, void *stream) {

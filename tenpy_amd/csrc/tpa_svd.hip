@@ -93,6 +93,16 @@ __global__ __launch_bounds__(64) void svd_fro_sum_kernel(const SvdJob *__restric
 // an absolute floor: couplings that can change a singular value by less than ~tol*rho*||A||_F are left
 // alone.  Without the floor the iteration keeps rotating rounding noise among rows whose norm is below
 // ~eps*||A||_F/tol (strongly graded spectra, e.g. DMRG wave functions) and needs 5x more sweeps.
+// Round 6: THE FLOOR ACTS ON THE SMALLER ROW (tpa_floor_on_min = 1, the default for callers that pass a negative rho, see
+// tpa_svd_batch):  |gamma| <= tol * sqrt(max(alpha,beta)) * max( sqrt(min(alpha,beta)), rho * ||A||_F ),
+// i.e. a pair stops at a cosine of tol * rho ||A|| / sigma_MIN instead of tol * rho ||A|| / sigma_MAX.  What that leaves behind is a
+// component of the SMALLER row along the larger one of size <= tol rho ||A||: the absolute accuracy class again -- provided the
+// post-processing that makes the normalised rows orthonormal moves only the smaller vector of a pair (ordered Gram-Schmidt clean-up,
+// linalg/_svd_warm.py::ordered_rows) and not both (symmetric Loewdin, rounds 3 - 5: error sigma_max * cosine / 2, which is what forced
+// the cosine down to tol rho ||A|| / sigma_max).  On the Jacobi inputs of the chi = 2048 sweeps two thirds of the block pairs never
+// become active under this rule (profiles/r06_stopping_rule_emulation.txt).
+__device__ int tpa_floor_on_min = 0;
+
 __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2, double tol, double floor2) {
     if (!(a > 0.0) || !(b > 0.0)) return false;
     const double mn = fmin(a, b), mx0 = fmax(a, b);
@@ -101,6 +111,7 @@ __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2
     // zero columns, bond matrices of the subspace expansion) shrinks by ~eps per sweep until |row|^2 is denormal;
     // there tol^2*mn*mx underflows to 0, zeta^2 overflows (rotation angle 0) and the pair is "rotated" forever.
     if (mn < 1.0e-60 * mx0) return false;
+    if (tpa_floor_on_min) return g2 > tol * tol * mx0 * fmax(mn, floor2);
     const double mx = fmax(mx0, floor2);
     return g2 > tol * tol * mn * mx;
 }
@@ -118,6 +129,12 @@ __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2
 // (tests/jacobi_emulation.py, NEW_BIG_RULE) shows 0.17 -> 1.8e-5 before the clean-up for rho = 1e-4 and 0.17 -> 1.2e-7 for rho = 1e-6.
 __device__ __forceinline__ bool svd_big_rotation(double a, double b, double g2, double floor2) {
     const double mn = fmin(a, b), mx0 = fmax(a, b);
+    if (tpa_floor_on_min) {
+        // the rotation leaves a cosine of ~cos^2, to be met by the pair's own rule: cos^2 <= tol rho |A| / sqrt(mn) below the floor
+        if (mn >= floor2) return g2 > 1.0e-14 * mn * mx0;
+        const double p = mn * floor2;
+        return g2 > 1.0e-14 * mx0 * (p * __builtin_amdgcn_rsq(p));
+    }
     if (mx0 >= floor2) return g2 > 1.0e-14 * mn * mx0;            // above the floor: the relative rule, as before
     const double p = mx0 * floor2;
     return g2 > 1.0e-14 * mn * (p * __builtin_amdgcn_rsq(p));     // sqrt(p) from the hardware seed: a threshold, not a result
@@ -2598,6 +2615,94 @@ inline void b32_solve_launch(int n_pairs, hipStream_t st, const SvdJob *jobs, co
     svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, b32q, b32f, cnt, fro2, rho, full_local, sfull, r);
 }
 
+// ---- round 6: the rounds of a Gram-only sweep as TABLES built from the activity of the block pairs ------------------------------------
+int tpa_svd_dyn = 1;             // 0 (TPA_SVD_DYN=0 / bit 24 of tpa_svd_set_algorithm): the full round-robin schedule in every sweep (rounds 3 - 5)
+int64_t tpa_svd_dyn_rounds = 0, tpa_svd_dyn_rounds_static = 0, tpa_svd_dyn_sweeps = 0;      // statistics (tpa_svd_dyn_stats)
+
+inline void b32_host_pair_of(int R, int pair, int round, int &bi, int &bj) {      // = b32_pair_of_R on the device
+    const int NB = (R + BB - 1) / BB, NBp = (NB + 1) / 2 * 2, mod = NBp - 1;
+    const int r = (mod > 0) ? (round % mod) : 0;
+    if (pair == 0) {
+        bi = NBp - 1;
+        bj = r;
+    } else {
+        bi = (r + pair) % mod;
+        bj = (r - pair + mod) % mod;
+    }
+    if (bi > bj) std::swap(bi, bj);
+}
+
+typedef std::vector<std::pair<int, int>> B32Matching;      // NBp / 2 pairs (bi < bj): a perfect matching of the padded blocks of one job
+
+// The rounds 1, 2, ... of one job for this sweep (round 0 is always the static first round: it rotates ALL row pairs inside its block
+// pairs).  `act`: NBp x NBp words of b32_activity_kernel (upper triangle).  Every round is a perfect matching that contains as many of
+// the still unscheduled active block pairs as a greedy pass finds (vertices by remaining degree); the other blocks are paired among
+// themselves (their solves find nothing to rotate and leave at once).  Nearly complete activity: the round-robin schedule itself.
+inline void b32_job_rounds(int R, const int *act, int max_rounds, std::vector<B32Matching> &out) {
+    const int NB = (R + BB - 1) / BB, NBp = (NB + 1) / 2 * 2, np = NBp / 2;
+    out.clear();
+    if (NBp < 4) return;         // one pair: round 0 is everything
+    std::vector<char> A((size_t)NBp * NBp, 0);
+    int n_edges = 0;
+    for (int i = 0; i < NB; ++i)
+        for (int j = i + 1; j < NB; ++j)
+            if (act[i * NBp + j]) {
+                A[i * NBp + j] = A[j * NBp + i] = 1;
+                ++n_edges;
+            }
+    for (int p = 0; p < np; ++p) {      // round 0 covers its own pairs
+        int bi, bj;
+        b32_host_pair_of(R, p, 0, bi, bj);
+        if (bj < NB && A[bi * NBp + bj]) {
+            A[bi * NBp + bj] = A[bj * NBp + bi] = 0;
+            --n_edges;
+        }
+    }
+    if (n_edges == 0) return;
+    if (10 * n_edges > 6 * (NB * (NB - 1) / 2)) {      // dense: the round-robin rounds 1 .. NBp - 2 (a greedy colouring would need more)
+        for (int r = 1; r < NBp - 1 && (int)out.size() < max_rounds; ++r) {
+            B32Matching m(np);
+            for (int p = 0; p < np; ++p) b32_host_pair_of(R, p, r, m[p].first, m[p].second);
+            out.push_back(m);
+        }
+        return;
+    }
+    std::vector<int> deg(NBp), order(NBp);
+    std::vector<char> used(NBp);
+    while (n_edges > 0 && (int)out.size() < max_rounds) {
+        for (int v = 0; v < NBp; ++v) {
+            deg[v] = 0;
+            for (int w = 0; w < NBp; ++w) deg[v] += A[v * NBp + w];
+            order[v] = v;
+            used[v] = 0;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return deg[x] > deg[y]; });
+        B32Matching m;
+        for (int v : order) {
+            if (used[v] || deg[v] == 0) continue;
+            int best = -1;
+            for (int w = 0; w < NBp; ++w)
+                if (!used[w] && w != v && A[v * NBp + w] && (best < 0 || deg[w] > deg[best])) best = w;
+            if (best < 0) continue;
+            m.push_back({std::min(v, best), std::max(v, best)});
+            used[v] = used[best] = 1;
+            A[v * NBp + best] = A[best * NBp + v] = 0;
+            --n_edges;
+        }
+        int prev = -1;
+        for (int v = 0; v < NBp; ++v) {      // the blocks without a partner this round: paired in index order
+            if (used[v]) continue;
+            if (prev < 0)
+                prev = v;
+            else {
+                m.push_back({prev, v});
+                prev = -1;
+            }
+        }
+        out.push_back(m);
+    }
+}
+
 struct Layout {
     std::vector<SvdJob> jobs;
     std::vector<int2> rows;   // (job,row) per wavefront, padded to multiple of 4 with (-1,-1)
@@ -2612,6 +2717,9 @@ struct Layout {
     int n_gup_s = 0;
     std::vector<int> b32_first_pair;
     int64_t off_gup = 0;
+    std::vector<B32Act> b32_act;         // round 6: block pairs (bi <= bj) whose activity the exact Gram matrix of a sweep start decides
+    std::vector<int> b32_act_off;        // per job: offset of its NBp x NBp activity words
+    int64_t n_act = 0, off_act_ents = 0, off_act = 0, off_sched = 0;
     RefTables ref;                 // GEMM tables of the Gram-only sweeps (empty unless the largest block has >= REF_MIN_R rows)
     int64_t off_rtasks = 0, off_rlinks = 0, off_rtiles = 0, off_rrt = 0;                // ... inside the uploaded table range
     int64_t off_w2 = 0, off_rp = 0, off_rq = 0, off_rm = 0;           // second [W | G] image, split-K partials, Qtot, S
@@ -2760,6 +2868,18 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
             }
             lay.off_gup = o;
             o = align_up(o + (int64_t)lay.b32_gup.size() * sizeof(B32GUp), 256);
+            if (dtype != TPA_C128) {      // activity entries of the dynamic schedule (real data)
+                for (int b = 0; b < (int)lay.jobs.size(); ++b) {
+                    const SvdJob &J = lay.jobs[b];
+                    const int NB32 = (int)((J.R + BB - 1) / BB), NBp = (NB32 + 1) / 2 * 2;
+                    lay.b32_act_off.push_back((int)lay.n_act);
+                    for (int bi = 0; bi < NB32; ++bi)
+                        for (int bj = bi; bj < NB32; ++bj) lay.b32_act.push_back(B32Act{b, bi, bj, (int)lay.n_act + bi * NBp + bj});
+                    lay.n_act += (int64_t)NBp * NBp;
+                }
+                lay.off_act_ents = o;
+                o = align_up(o + (int64_t)lay.b32_act.size() * sizeof(B32Act), 256);
+            }
         }
     }
     lay.off_tab_end = o;
@@ -2781,6 +2901,12 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     }
     lay.off_b32q = o;            // two images of 64 x 64 transforms per pair
     o = align_up(o + ((dtype == TPA_C128) ? 4 : 2) * (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
+    if (lay.ref.enabled && !lay.b32_act.empty()) {
+        lay.off_act = o;
+        o = align_up(o + lay.n_act * 4, 256);
+        lay.off_sched = o;               // (nb32_max_pad + 2) rounds of one B32Sched per pair
+        o = align_up(o + (lay.nb32_max_pad + 2) * (int64_t)lay.b32_pairs.size() * sizeof(B32Sched), 256);
+    }
     if (lay.ref.enabled) {
         lay.off_w2 = o;                                   // [W2 | G2] with the spacing of [W | G]
         o = align_up(o + (lay.off_g - lay.off_w) + lay.g_elems * esz, 256);
@@ -2917,6 +3043,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         stage_put(stg, t0, lay.off_wpairs, lay.wpairs);
         stage_put(stg, t0, lay.off_b32e, lay.b32_entries);
         stage_put(stg, t0, lay.off_b32p, lay.b32_pairs);
+        if (!lay.b32_act.empty()) stage_put(stg, t0, lay.off_act_ents, lay.b32_act);
         if (lay.ref.enabled) {
             stage_put(stg, t0, lay.off_rtasks, lay.ref.tasks);
             stage_put(stg, t0, lay.off_rlinks, lay.ref.links);
@@ -3071,6 +3198,119 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             std::swap(Wc, Wn);
             std::swap(Gc, Gn);
         };
+        // ---- round 6: DYNAMIC schedule (real data, one launch per round).  The exact Gram matrix of a sweep start says which block
+        //      pairs need rotations at all (b32_activity_kernel); only those are scheduled (b32_job_rounds), and a sweep that starts
+        //      without "big" pairs is the last one.  With the floor of the stopping rule on the smaller row two thirds of the block
+        //      pairs of a chi = 2048 theta are never active (profiles/r06_stopping_rule_emulation.txt).
+        const bool use_dyn = fused && tpa_svd_dyn && tpa_svd_lookahead && !lay.b32_act.empty() && lay.off_sched != 0;
+        if (use_dyn) {
+            B32Sched *sched_dev = (B32Sched *)(work + lay.off_sched);
+            int *act_dev = (int *)(work + lay.off_act);
+            const B32Act *act_ents = (const B32Act *)(work + lay.off_act_ents);
+            const int n_act_ents = (int)lay.b32_act.size(), n_jobs_l = (int)lay.jobs.size();
+            const int max_rounds = (int)lay.nb32_max_pad + 2;
+            int *act_host = (int *)pin_stage().take((size_t)lay.n_act * 4, st);
+            TPA_STAGE_CHECK(act_host);
+            B32Sched *sched_stage = (B32Sched *)pin_stage().take((size_t)max_rounds * n_pairs * sizeof(B32Sched), st);
+            TPA_STAGE_CHECK(sched_stage);
+            std::vector<std::vector<B32Matching>> job_rounds(n_jobs_l);      // rounds >= 1 of every job for the sweep at hand
+            std::vector<int> pos;                                            // block -> 2 * global pair + half in the previous round
+            // entries of round r (r >= 1: from job_rounds, padded by repeating the last matching; r = 0: the static first round)
+            auto matching_of = [&](int b, int r, B32Matching &m) {
+                const int R = (int)lay.jobs[b].R, NB = (R + BB - 1) / BB, np = ((NB + 1) / 2 * 2) / 2;
+                if (r == 0 || job_rounds[b].empty()) {
+                    m.resize(np);
+                    for (int p = 0; p < np; ++p) b32_host_pair_of(R, p, 0, m[p].first, m[p].second);
+                } else
+                    m = job_rounds[b][std::min<int>(r - 1, (int)job_rounds[b].size() - 1)];
+            };
+            auto fill_round = [&](int r) {
+                B32Matching m, mp;
+                for (int b = 0; b < n_jobs_l; ++b) {
+                    const int first = lay.b32_first_pair[b];
+                    matching_of(b, r, m);
+                    if (r > 0) {
+                        matching_of(b, r - 1, mp);
+                        pos.assign(2 * mp.size() + 2, -1);
+                        for (int p = 0; p < (int)mp.size(); ++p) {
+                            pos[mp[p].first] = 2 * (first + p);
+                            pos[mp[p].second] = 2 * (first + p) + 1;
+                        }
+                    }
+                    for (int p = 0; p < (int)m.size(); ++p) {
+                        B32Sched &E = sched_stage[(size_t)r * n_pairs + first + p];
+                        E.bi = m[p].first;
+                        E.bj = m[p].second;
+                        if (r > 0) {
+                            E.srcA = pos[E.bi];
+                            E.srcB = pos[E.bj];
+                            const std::pair<int, int> &sa = mp[(E.srcA >> 1) - first], &sb = mp[(E.srcB >> 1) - first];
+                            E.ax = sa.first;
+                            E.ay = sa.second;
+                            E.bx = sb.first;
+                            E.by = sb.second;
+                        } else
+                            E.srcA = E.srcB = E.ax = E.ay = E.bx = E.by = -1;
+                    }
+                }
+            };
+            fill_round(0);
+            TPA_HIP_CHECK(hipMemsetAsync(act_dev, 0, (size_t)lay.n_act * 4, st));      // (only the upper triangles of real blocks are ever written)
+            TPA_HIP_CHECK(hipMemcpyAsync(sched_dev, sched_stage, (size_t)n_pairs * sizeof(B32Sched), hipMemcpyHostToDevice, st));
+            auto sweep_head = [&]() {      // exact Gram matrix, activity of the block pairs, first round: enqueued before the host knows the activity
+                g_begin();
+                b32_activity_kernel<<<n_act_ents, 256, 0, st>>>(jobs, act_ents, Mm, fro2, rho, act_dev);
+                if (hipMemcpyAsync(act_host, act_dev, (size_t)lay.n_act * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipEventRecord(ev_post, st) != hipSuccess)
+                    rc_g = 999;
+                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, 1, sbuf[0], 0, sched_dev);
+            };
+            TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
+            sweep_head();
+            while (sweep < jac_limit) {
+                if (rc_g) return rc_g;
+                TPA_LAUNCH_CHECK();
+                TPA_HIP_CHECK(hipEventSynchronize(ev_post));
+                bool any = false, big = false;
+                for (int64_t i = 0; i < lay.n_act; ++i) {
+                    any |= act_host[i] != 0;
+                    big |= (act_host[i] & 2) != 0;
+                }
+                if (!any) {              // nothing to rotate on exact data (the first round already enqueued finds nothing either)
+                    converged = true;
+                    break;
+                }
+                int n_r = 1;
+                for (int b = 0; b < n_jobs_l; ++b) {
+                    b32_job_rounds((int)lay.jobs[b].R, act_host + lay.b32_act_off[b], max_rounds - 1, job_rounds[b]);
+                    n_r = std::max(n_r, 1 + (int)job_rounds[b].size());
+                }
+                for (int r = 1; r < n_r; ++r) fill_round(r);
+                if (n_r > 1)
+                    TPA_HIP_CHECK(hipMemcpyAsync(sched_dev + n_pairs, sched_stage + n_pairs, (size_t)(n_r - 1) * n_pairs * sizeof(B32Sched),
+                                                 hipMemcpyHostToDevice, st));
+                for (int r = 1; r < n_r; ++r)
+                    svd_b32_round_kernel<<<n_pairs + n_gup, NTS3, 0, st>>>(jobs, b32p, n_pairs, gup, r, sbuf[(r - 1) & 1], sbuf[r & 1], Qm,
+                                                                           qb2[(r - 1) & 1], qb2[r & 1], fb2[(r - 1) & 1], fb2[r & 1], cnt, fro2,
+                                                                           rho, 0, sched_dev + (size_t)r * n_pairs, sched_dev + (size_t)(r - 1) * n_pairs);
+                {   // the transforms of the last round still have to reach Qtot
+                    const int rl = n_r - 1;
+                    svd_b32_gupdate_kernel<<<n_gup - lay.n_gup_s, NTB, 0, st>>>(gup + lay.n_gup_s, rl, sbuf[rl & 1], Qm, qb2[rl & 1], fb2[rl & 1],
+                                                                                sched_dev + (size_t)rl * n_pairs);
+                }
+                g_end();
+                ++sweep;
+                tpa_svd_dyn_rounds += n_r;
+                tpa_svd_dyn_rounds_static += rounds_g;
+                ++tpa_svd_dyn_sweeps;
+                if (!big) {              // the sweep started without big pairs: every rotation it made converges its pair (predicted convergence)
+                    converged = true;
+                    break;
+                }
+                if (sweep < jac_limit) sweep_head();
+            }
+            if (rc_g) return rc_g;
+        } else {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
         g_begin();
         g_round(0);
@@ -3094,6 +3334,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             }
         }
         if (rest_pending) TPA_HIP_CHECK(hipStreamWaitEvent(st, ev_c[1], 0));      // (look-ahead round of a sweep that was not needed)
+        }
     } else
     if (use_b32 && tpa_svd_lookahead && !converged && jac_limit > 0) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
@@ -3671,10 +3912,20 @@ static int tpa_svd_batch_impl(int dtype, const int64_t *jobs_host, int n_jobs, c
                               void *u_base, double *s_dev, void *vh_base, void *work_dev,
                               int64_t work_bytes, int max_sweeps, double tol, int *sweeps_done,
                               void *stream, int *used_qrp) {
-    TPA_ARG_CHECK(tol >= 0.0 && tol <= 1.0);
+    TPA_ARG_CHECK(tol >= -1.0 && tol <= 1.0);
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
     for (int b = 0; b < n_jobs; ++b) TPA_ARG_CHECK(jobs_host[8 * b + 1] > 0 && jobs_host[8 * b + 2] > 0);
+    {   // tol < 0: floor |tol| on the SMALLER row of a pair (svd_needs_rotation; the caller post-processes with the ordered clean-up)
+        const int mode = (tol < 0.0) ? 1 : 0;
+        static thread_local int mode_on_device = 0;      // (one device per process)
+        if (mode != mode_on_device) {
+            TPA_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(tpa_floor_on_min), &mode, sizeof(int), 0, hipMemcpyHostToDevice, (hipStream_t)stream));
+            TPA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));      // (`mode` lives on this stack frame)
+            mode_on_device = mode;
+        }
+        tol = fabs(tol);
+    }
     pin_stage().reset();      // the previous call on this thread ended with a stream synchronisation
     Layout lay = make_layout(dtype, jobs_host, n_jobs);
     TPA_ARG_CHECK(work_bytes >= lay.total);
@@ -3869,6 +4120,19 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_fused_rounds = (pairwise & 8388608) ? 0 : 1;    // bit 23: two launches per Gram-only round
     tpa_svd_overlap_c = (pairwise & 16384) ? 1 : 0;   // bit 14: complex Gram-only rounds with the non-urgent tiles on a second stream (off by default)
     tpa_svd_gonly = (pairwise & 1048576) ? 0 : 1;     // bit 20: no Gram-only sweeps (the round-3 rounds: gram, solve, apply on the data)
+    tpa_svd_dyn = (pairwise & 16777216) ? 0 : 1;      // bit 24: the full round-robin schedule in every sweep instead of the activity-driven one (round 6)
+    return 0;
+}
+
+/* Rounds launched by the activity-driven schedule of the Gram-only sweeps against the round-robin count: out = {rounds launched,
+ * rounds of the static schedule for the same sweeps, sweeps}; reset != 0 clears the counters. */
+extern "C" int tpa_svd_dyn_stats(int64_t *out, int reset) {
+    if (out) {
+        out[0] = tpa_svd_dyn_rounds;
+        out[1] = tpa_svd_dyn_rounds_static;
+        out[2] = tpa_svd_dyn_sweeps;
+    }
+    if (reset) tpa_svd_dyn_rounds = tpa_svd_dyn_rounds_static = tpa_svd_dyn_sweeps = 0;
     return 0;
 }
 

@@ -206,6 +206,69 @@ def lowdin_rows(dtype, arena, off, nvec, length, vs, cs, iterations=1):
     run_copy(dtype, pl['scatter'], T, arena)
 
 
+ORDERED_PANEL = 128       # row panel of the triangular products of `ordered_rows`
+
+
+def ordered_rows(dtype, arena, off, nvec, length, vs, cs, iterations=1):
+    """In place ORDERED orthonormalisation of sets of vectors ``V_t[i][j] = arena[off_t + i vs_t + j cs_t]`` (``i < nvec_t``, ``j <
+    length_t``) that are sorted by descending weight (singular value): per iteration ``G = T T^H``, ``N`` = strict lower triangle of
+    ``G`` with ``(G_ii - 1) / 2`` on the diagonal (``tpa_tri_lower_batch``), ``T <- T - N T`` -- every vector is made orthogonal to the
+    vectors BEFORE it and normalised, no vector moves towards a later one; a defect ``d = |V V^H - 1|`` becomes ``O(d^2)``.
+
+    Why ordered, not symmetric (round 6).  The one-sided Jacobi iteration delivers ``A = U' D V0`` exactly, with ``U'`` a product of
+    plane rotations, ``D`` the row norms and ``V0`` unit rows whose Gram matrix is ``1 + C``.  Replacing ``V0`` by an orthonormal
+    ``V`` changes the product by ``D (V0 - V)``: the symmetric (Loewdin) choice moves BOTH vectors of a pair by ``C_ij / 2``, error
+    ``max(d_i, d_j) |C_ij| / 2`` -- it forces the iteration to converge every pair to ``|C_ij| <= eps |A| / d_max``; the ordered choice
+    moves only the vector of the SMALLER singular value, error ``min(d_i, d_j) |C_ij|``, so a pair may stop at
+    ``|C_ij| <= eps |A| / d_min`` (the stopping rule of csrc/tpa_svd.hip::svd_needs_rotation with the floor on the smaller row).
+    Measured on Jacobi inputs dumped from the chi = 2048 sweeps (profiles/r06_stopping_rule_emulation.txt): a third of the block pairs
+    active, reconstruction error 1 - 3e-16 |A| (symmetric clean-up at the old rule: 3e-15)."""
+    dtype = np.dtype(dtype)
+    off, nvec, length, vs, cs = (np.ascontiguousarray(x, dtype=np.int64) for x in (off, nvec, length, vs, cs))
+    key = _key('ordered', dtype.str, off, nvec, length, vs, cs)
+    pl = _plan_get(key)
+    if pl is None:
+        keep = nvec > 1
+        o, nv, ln, v, c = off[keep], nvec[keep], length[keep], vs[keep], cs[keep]
+        if len(o) == 0:
+            pl = _plan_put(key, False)
+        else:
+            cplx = dtype.kind == 'c'
+            g_off = np.concatenate([[0], np.cumsum(nv * nv)])
+            t_off = np.concatenate([[0], np.cumsum(nv * ln)])
+            z = np.zeros(len(o), dtype=np.int64)
+            one = z + 1
+            # Only the LOWER triangle of G is used: row panel [r0, r1) of block t needs G[r0:r1, 0:r1] = T[r0:r1] T[0:r1]^H and
+            # contributes N[r0:r1, 0:r1] T[0:r1] -- half the flops of the square products (the upper part of G is never read: the
+            # triangle kernel overwrites it with zeros).
+            gram_spec, mult_spec = [], []
+            for t in range(len(o)):
+                for r0 in range(0, int(nv[t]), ORDERED_PANEL):
+                    r1 = min(r0 + ORDERED_PANEL, int(nv[t]))
+                    gram_spec.append([g_off[t] + r0 * nv[t], r1 - r0, r1, nv[t], t_off[t] + r0 * ln[t], ln[t], 1, t_off[t], 1, ln[t], ln[t],
+                                      2 if cplx else 0])
+                    mult_spec.append([t_off[t] + r0 * ln[t], r1 - r0, ln[t], ln[t], g_off[t] + r0 * nv[t], nv[t], 1, t_off[t], ln[t], 1, r1, 0])
+            pl = _plan_put(key, dict(
+                nT=int(t_off[-1]), nG=int(g_off[-1]), n=len(o), max_g=int(np.max(nv * nv)),
+                gather=copy_table(copy_jobs_2d(t_off[:-1], ln, one, o, v, c, nv, ln)),
+                gram=gemm_table(dtype, np.array(gram_spec, dtype=np.int64)),
+                tri=dev.to_device(np.ascontiguousarray(np.stack([g_off[:-1], nv], axis=1))),
+                mult=gemm_table(dtype, np.array(mult_spec, dtype=np.int64)),
+                scatter=copy_table(copy_jobs_2d(o, v, c, t_off[:-1], ln, one, nv, ln))))
+    if pl is False:
+        return
+    T = dev.scratch('lowdin_T', pl['nT'], dtype)
+    run_copy(dtype, pl['gather'], arena, T)
+    for _ in range(iterations):
+        G = dev.scratch('lowdin_G', pl['nG'], dtype)
+        run_gemm(dtype, pl['gram'], T, T, G)
+        dev.check(dev.lib().tpa_tri_lower_batch(dev.code(dtype), pl['tri'].data_ptr(), pl['n'], pl['max_g'], G.data_ptr(), dev.stream()), "tri_lower")
+        T2 = dev.scratch('lowdin_T2', pl['nT'], dtype)
+        run_gemm(dtype, pl['mult'], G, T, T2)
+        _axpy(dtype, -1.0, T2, T)
+    run_copy(dtype, pl['scatter'], T, arena)
+
+
 class Basis:
     """Orthonormal row bases of the charge sectors of one leg: block b holds ``k[b] x length[b]`` row-major at ``off[b]``."""
     __slots__ = ('arena', 'off', 'k', 'length', 'sectors', 'dtype', 'age')

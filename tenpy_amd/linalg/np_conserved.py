@@ -2522,6 +2522,19 @@ def trace(a, leg1=0, leg2=1):
 #     Singular values (1.7 - 2.7e-15 of sigma_max), sweep energies (3 - 8e-15 against TeNPy's), matvec / Lanczos parity, the isometry of
 #     the sampled decompositions (1.5e-13) and of the MPS tensors the sweeps stored (7e-15) are the same in every row of the new rule.
 SVD_ABS_FLOOR = float(os.environ.get('TPA_SVD_ABS_FLOOR', '1e-2'))      # (the environment variable: measurement knob)
+# Round 6: the floor acts on the SMALLER row of a pair (include/tenpy_amd.h, tpa_svd_batch `tol` < 0) and the clean-up of the vectors
+# below it is ORDERED (every vector against the ones of larger singular value, `_svd_warm.ordered_rows`) instead of symmetric: a pair
+# of rows of very different size may then stop at a cosine of eps rho |A| / sigma_min instead of eps rho |A| / sigma_max, because the
+# clean-up no longer pushes half of the remaining cosine into the LARGE vector.  Same accuracy class (reconstruction 1 - 3e-16 |A|,
+# singular values 2 - 4e-16 sigma_max on the Jacobi inputs of the chi = 2048 sweeps, profiles/r06_stopping_rule_emulation.txt), a third
+# of the block pairs active.  TPA_SVD_FLOOR_ON_MIN=0 restores the rule of rounds 1 - 5 (the ordered clean-up is valid for both).
+SVD_FLOOR_ON_MIN = os.environ.get('TPA_SVD_FLOOR_ON_MIN', '1') != '0'
+
+
+def _svd_tol_arg():
+    """The `tol` argument of tpa_svd_batch / tpa_eigh_batch for the call in progress (sign = which row the floor acts on)."""
+    f = _svd_floor_now[0]
+    return -f if (SVD_FLOOR_ON_MIN and f > 0.) else f
 # Round 4 (ADVICE r2, VERDICT r3 task 7): the floor is an opt-in of the callers that can afford it -- the DMRG / TEBD drivers, which
 # truncate right afterwards and mark their call (``svd_hint`` of the engines, or ``svd_engine_floor = True`` for one call).  Every
 # other ``npc.svd`` (an unmodified TeNPy module calling it for its own purposes) runs the purely relative criterion: every returned
@@ -2545,7 +2558,10 @@ class _PerThreadFloor(threading.local):
 
 
 _svd_floor_now = _PerThreadFloor()      # read by the helpers below
-SVD_LOWDIN_ITERATIONS = int(os.environ.get('TPA_SVD_LOWDIN_ITERATIONS', '4'))      # (round 5: 2 -> 4 with the higher floor: the tiniest kept rows stop at cosines ~7e-3, and first-order Loewdin squares the defect per iteration)
+# Round 6: with the floor on the smaller row the cosines left among the tiniest rows are larger and MANY (2-norm of the cosine matrix
+# 0.6 - 0.8 on the Jacobi inputs of the chi = 2048 sweeps against 0.25 under the old rule): the ordered clean-up needs 6 instead of 4 - 5
+# iterations to reach 1e-15 (emulation on dumped inputs: 1e-1, 2e-2, 1e-3, 8e-6, 4e-10, 9e-16).
+SVD_LOWDIN_ITERATIONS = int(os.environ.get('TPA_SVD_LOWDIN_ITERATIONS', '6' if os.environ.get('TPA_SVD_FLOOR_ON_MIN', '1') != '0' else '4'))      # (round 5: 2 -> 4 with the higher floor: the tiniest kept rows stop at cosines ~7e-3, and first-order Loewdin squares the defect per iteration)
 # Warm start (`_svd_warm`): a caller that knows which bond it is decomposing sets ``svd_hint = (key, side)`` right before
 # ``svd`` / ``svd_theta`` (side 'R': the right singular vectors of the previous decomposition under ``key`` are a good basis,
 # 'L': the left ones); the hint is consumed by the next call.  Without a hint, or when the cached basis does not fit the block
@@ -2688,7 +2704,7 @@ def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, swe
         tried.append(alg)
         try:
             rc = L.tpa_svd_batch(code, jobs.ctypes.data, nblk, a_arena.data_ptr(), U_arena.data_ptr(), S_dev.data_ptr(),
-                                 V_arena.data_ptr(), work.data_ptr(), int(wb), SVD_MAX_SWEEPS, _svd_floor_now[0],
+                                 V_arena.data_ptr(), work.data_ptr(), int(wb), SVD_MAX_SWEEPS, _svd_tol_arg(),
                                  dev.byref(sweeps), dev.stream())
         finally:
             if hop or alg != SVD_ALGORITHM_CHAIN[0]:
@@ -2755,15 +2771,17 @@ def _svd_clean_small(dtype, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
     ``y_is_vh[b]`` says which factor holds the normalised Jacobi rows (only that one can be off); None: both are treated."""
     k0 = _svd_sig_counts(S_host, ks, s_offs, _svd_floor_now[0])
     k1 = _svd_sig_counts(S_host, ks, s_offs, 1.e-15)
-    n_small = k1 - k0
-    if not np.any(n_small > 1):
+    if not np.any(k1 - k0 > 0):
         return
-    n_small = np.where(n_small > 1, n_small, 0)
+    # Round 6: ORDERED clean-up over ALL significant vectors [0, k1) -- with the floor on the smaller row a vector below the floor may
+    # keep a cosine of eps rho |A| / sigma_small with a vector ABOVE it, which only the ordered step removes without touching the large one
+    # (the vectors above the floor are mutually converged to eps sqrt(L): the step leaves them alone to rounding).
+    n_all = np.where(k1 - k0 > 0, k1, 0)
     one = np.ones(len(ks), dtype=np.int64)
-    nv = n_small if y_is_vh is None else np.where(y_is_vh, n_small, 0)
-    nu = n_small if y_is_vh is None else np.where(y_is_vh, 0, n_small)
-    _svd_warm.lowdin_rows(dtype, V_arena, v_offs[:-1] + k0 * ns, nv, ns, ns, one, iterations=SVD_LOWDIN_ITERATIONS)
-    _svd_warm.lowdin_rows(dtype, U_arena, u_offs[:-1] + k0, nu, ms, one, ks, iterations=SVD_LOWDIN_ITERATIONS)
+    nv = n_all if y_is_vh is None else np.where(y_is_vh, n_all, 0)
+    nu = n_all if y_is_vh is None else np.where(y_is_vh, 0, n_all)
+    _svd_warm.ordered_rows(dtype, V_arena, v_offs[:-1], nv, ns, ns, one, iterations=SVD_LOWDIN_ITERATIONS)
+    _svd_warm.ordered_rows(dtype, U_arena, u_offs[:-1], nu, ms, one, ks, iterations=SVD_LOWDIN_ITERATIONS)
 
 
 def _leg_sector_keys(leg, qinds):

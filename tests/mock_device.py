@@ -305,6 +305,17 @@ class MockLib:
             dst[j[0] + r * j[3] + c] = acc
         return 0
 
+    def tpa_tri_lower_batch(self, code, jobs_p, n_jobs, max_elems, g_p, stream):
+        dt = _npdt(code)
+        jobs = REG.view(jobs_p, np.int64)[:2 * n_jobs].reshape(n_jobs, 2)
+        g = REG.view(g_p, dt)
+        for g_off, n in jobs:
+            blk = g[g_off:g_off + n * n].reshape(n, n)
+            d = 0.5 * (np.real(np.diag(blk)) - 1.0)
+            blk[:] = np.tril(blk, -1)
+            blk[np.arange(n), np.arange(n)] = d
+        return 0
+
     def tpa_scale_axis_batch(self, code, jobs_p, n_jobs, max_elems, x_p, s_p, s_cplx, stream):
         dt = _npdt(code)
         jobs = REG.view(jobs_p, np.int64)[:6 * n_jobs].reshape(n_jobs, 6)

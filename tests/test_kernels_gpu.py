@@ -304,7 +304,9 @@ def test_svd_gram_only_sweeps(env, cplx):
         finally:
             lib.tpa_svd_set_algorithm(0)
         assert rc == 0 and rc_off == 0
-        assert sweeps <= sweeps_off + 1, (sweeps, sweeps_off)
+        # (round 6: with the activity-driven schedule a sweep visits only the block pairs that were active on the exact Gram matrix of
+        #  its start -- a pair that other rotations activate in between waits for the next sweep, which costs a few rounds, not 17)
+        assert sweeps <= sweeps_off + 2, (sweeps, sweeps_off)
         for x, (u, s, vh), (u2, s2, vh2) in zip(mats, res, res_off):
             m, n = x.shape
             ref = torch.linalg.svdvals(x)

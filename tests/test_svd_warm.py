@@ -183,6 +183,37 @@ def test_lowdin_rows(backend):
         assert np.abs(out.conj().T @ out - np.eye(24)).max() < 1e-14
 
 
+def test_ordered_rows(backend):
+    """Round 6: the ORDERED clean-up (``tpa_tri_lower_batch``) -- every vector is orthonormalised against the vectors BEFORE it, so the
+    leading vectors move by the SQUARE of the defect only, however large their cosines with later vectors are (the symmetric step
+    moves both vectors of a pair by half the cosine); the result equals Gram-Schmidt in that order = Q of a QR factorisation."""
+    from tenpy_amd.linalg import _device as dev
+    rng = np.random.RandomState(4)
+    for cplx in (False, True):
+        dt = np.complex128 if cplx else np.float64
+        q, _ = np.linalg.qr(rng.standard_normal((60, 24)) + (1j * rng.standard_normal((60, 24)) if cplx else 0))
+        V0 = q.T.copy()
+        # later vectors tilted towards earlier ones by up to 3e-2 (what the stopping rule with the floor on the smaller row leaves
+        # between a tiny row and a large one), unit norm again
+        mix = np.tril(rng.standard_normal((24, 24)), -1) * 3e-2 / np.sqrt(24)
+        V = V0 + mix @ V0
+        V /= np.linalg.norm(V, axis=1)[:, None]
+        want = np.linalg.qr(V.conj().T)[0].conj().T            # Gram-Schmidt of the rows in order (up to phases)
+        want *= (np.sum(want * V.conj(), axis=1) / np.abs(np.sum(want * V.conj(), axis=1)))[:, None].conj() if cplx else np.sign(np.sum(want * V, axis=1))[:, None]
+        arena = dev.to_device(np.concatenate([np.zeros(5, dt), V.reshape(-1).astype(dt)]))
+        _svd_warm.ordered_rows(dt, arena, [5], [24], [60], [60], [1], iterations=4)
+        out = dev.to_host(arena)[5:].reshape(24, 60)
+        assert np.abs(out @ out.conj().T - np.eye(24)).max() < 1e-14
+        assert np.abs(out - want).max() < 1e-13
+        assert np.abs(out[0] - V[0]).max() < 1e-15            # the first vector is not touched at all
+        # the same vectors stored as columns
+        arena = dev.to_device(np.ascontiguousarray(V.T).reshape(-1).astype(dt))
+        _svd_warm.ordered_rows(dt, arena, [0], [24], [60], [1], [24], iterations=4)
+        out = dev.to_host(arena).reshape(60, 24)
+        assert np.abs(out.conj().T @ out - np.eye(24)).max() < 1e-14
+        assert np.abs(out.T - want).max() < 1e-13
+
+
 def test_warm_cache_is_bounded_by_bytes_and_tied_to_its_owner(backend, monkeypatch):
     """the cache of warm-start bases is capped by device BYTES (LRU), keyed by a token that is never reused, and the
     bases of an engine disappear with the engine."""
