@@ -111,6 +111,10 @@ class TwoSiteDMRGEngine:
             eff_H = ShardedTwoSiteH(env, i0, combine=True, move_right=move_right)
         else:
             eff_H = TwoSiteH(env, i0, combine=True, move_right=move_right)
+            # the contraction plans of this bond's previous visit (same block structure once chi has saturated: checked by their keys)
+            cache = self.__dict__.setdefault('_heff_plans', {})
+            if eff_H.factored and cache.get(i0) is not None:
+                eff_H._fplans = cache[i0]
         theta = eff_H.combine_theta(psi.get_theta(i0, n=2))
         self._tick('heff')
         if self.shard_matvec and self.options.get('krylov_row_panels', False):
@@ -118,6 +122,8 @@ class TwoSiteDMRGEngine:
             E0, theta, N = lanczos_row_panels(eff_H, theta, self.lanczos_params)
         else:
             E0, theta, N = LanczosGroundState(eff_H, theta, self.lanczos_params).run()
+        if not self.shard_matvec and isinstance(getattr(eff_H, '_fplans', None), dict) and 'lkey' in eff_H._fplans:
+            self._heff_plans[i0] = eff_H._fplans
         theta = eff_H.prepare_svd(theta)                      # fused matrix [(vL.p0), (p1.vR)]
         self._tick('lanczos')
         previous = npc.SVD_DIST_GROUP

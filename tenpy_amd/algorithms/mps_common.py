@@ -588,6 +588,8 @@ class TwoSiteH:
         res = None
         if self.factored:
             fp = self._fplans
+            if fp is not None and 'lkey' in fp and (fp['lkey'] != self._LPf._struct_key() or fp['rkey'] != self._RPf._struct_key()):
+                fp = None           # (plans handed over from the previous visit of this bond, `plan_cache`: the environments changed shape)
             if fp is None or fp['key'] != theta._struct_key() or fp['dtype'] != theta.dtype:
                 p1, l_use, t_use = npc.plan_tensordot(self._LPf, theta, axes=['vR', 'vL'])
                 if l_use is not self._LPf or t_use is not theta or p1.empty:
@@ -601,7 +603,8 @@ class TwoSiteH:
                 p2, t3_use, r_use = npc.plan_tensordot(T3, self._RPf, axes=(['wR', 'vR'], ['wL', 'vL']))
                 if t3_use is not T3 or r_use is not self._RPf or p2.empty:
                     return None
-                self._fplans = fp = dict(key=theta._struct_key(), dtype=theta.dtype, p1=p1, a01=a01, p2=p2)
+                self._fplans = fp = dict(key=theta._struct_key(), dtype=theta.dtype, p1=p1, a01=a01, p2=p2,
+                                         lkey=self._LPf._struct_key(), rkey=self._RPf._struct_key())
                 self.flops_per_matvec = p1.flops + p2.flops
                 self.bytes_per_matvec = p1.bytes_min + p2.bytes_min + a01.bytes
                 self.gemm_shapes = (p1.gemm_shapes, p2.gemm_shapes)

@@ -2616,6 +2616,7 @@ inline void b32_solve_launch(int n_pairs, hipStream_t st, const SvdJob *jobs, co
 }
 
 // ---- round 6: the rounds of a Gram-only sweep as TABLES built from the activity of the block pairs ------------------------------------
+int tpa_svd_dyn_round0 = 1;      // the first round of a sweep adapts to the activity of its pairs (bit 25 of tpa_svd_set_algorithm: off)
 int tpa_svd_dyn = 1;             // 0 (TPA_SVD_DYN=0 / bit 24 of tpa_svd_set_algorithm): the full round-robin schedule in every sweep (rounds 3 - 5)
 int64_t tpa_svd_dyn_rounds = 0, tpa_svd_dyn_rounds_static = 0, tpa_svd_dyn_sweeps = 0;      // statistics (tpa_svd_dyn_stats)
 
@@ -3249,8 +3250,11 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                             E.ay = sa.second;
                             E.bx = sb.first;
                             E.by = sb.second;
-                        } else
-                            E.srcA = E.srcB = E.ax = E.ay = E.bx = E.by = -1;
+                        } else {
+                            E.srcA = E.srcB = E.bx = E.by = -1;
+                            E.ax = lay.b32_act_off[b];          // round 0: where the job's activity words are (svd_b32_solve2_kernel)
+                            E.ay = 2 * (int)m.size();           // NBp
+                        }
                     }
                 }
             };
@@ -3263,7 +3267,8 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 if (hipMemcpyAsync(act_host, act_dev, (size_t)lay.n_act * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipEventRecord(ev_post, st) != hipSuccess)
                     rc_g = 999;
-                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, 1, sbuf[0], 0, sched_dev);
+                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, 1, sbuf[0], 0, sched_dev,
+                                                                tpa_svd_dyn_round0 ? act_dev : nullptr);
             };
             TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
             sweep_head();
@@ -4120,6 +4125,7 @@ extern "C" int tpa_svd_set_algorithm(int pairwise) {
     tpa_svd_fused_rounds = (pairwise & 8388608) ? 0 : 1;    // bit 23: two launches per Gram-only round
     tpa_svd_overlap_c = (pairwise & 16384) ? 1 : 0;   // bit 14: complex Gram-only rounds with the non-urgent tiles on a second stream (off by default)
     tpa_svd_gonly = (pairwise & 1048576) ? 0 : 1;     // bit 20: no Gram-only sweeps (the round-3 rounds: gram, solve, apply on the data)
+    tpa_svd_dyn_round0 = (pairwise & 33554432) ? 0 : 1;   // bit 25: the first round of every sweep rotates all 2016 local pairs of every block pair
     tpa_svd_dyn = (pairwise & 16777216) ? 0 : 1;      // bit 24: the full round-robin schedule in every sweep instead of the activity-driven one (round 6)
     return 0;
 }

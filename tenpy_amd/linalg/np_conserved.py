@@ -2676,6 +2676,7 @@ SVD_ALGORITHM_CHAIN = (SVD_ALG0, 512 | 2, 1 | 512)
 SVD_ALGORITHM_CHAIN_WARM = (512 | SVD_ALG0, 512 | 2, 1 | 512)
 SVD_MAX_SWEEPS = 80
 svd_robust_stats = {'retries': 0, 'last_chain': ()}
+_svd_worksize_cache = {}
 _svd_alg_initialised = False
 
 
@@ -2687,7 +2688,12 @@ def _svd_batch_robust(L, code, jobs, nblk, a_arena, U_arena, S_dev, V_arena, swe
         if SVD_ALGORITHM_CHAIN[0] != 0:
             L.tpa_svd_set_algorithm(SVD_ALGORITHM_CHAIN[0])
     chain = SVD_ALGORITHM_CHAIN if chain is None else chain
-    wb = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
+    wkey = (code, jobs.tobytes())
+    wb = _svd_worksize_cache.get(wkey)
+    if wb is None:              # (the layout of the work area: ~30 us of host time per call for what depends on the block sizes only)
+        if len(_svd_worksize_cache) > 4096:
+            _svd_worksize_cache.clear()
+        wb = _svd_worksize_cache[wkey] = L.tpa_svd_worksize(code, jobs.ctypes.data, nblk)
     work = dev.scratch('svd_work', int(wb), np.uint8)
     if _svd_warm.PROFILE:
         _svd_warm._tick('t_svd_worksize_scratch')
@@ -2776,7 +2782,10 @@ def _svd_clean_small(dtype, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
     # Round 6: ORDERED clean-up over ALL significant vectors [0, k1) -- with the floor on the smaller row a vector below the floor may
     # keep a cosine of eps rho |A| / sigma_small with a vector ABOVE it, which only the ordered step removes without touching the large one
     # (the vectors above the floor are mutually converged to eps sqrt(L): the step leaves them alone to rounding).
-    n_all = np.where(k1 - k0 > 0, k1, 0)
+    # (rounded up to whole 32-row groups, at most the block's rank: the count of significant values moves by a few between two
+    #  visits of a bond, and every new count would be a new plan -- tables built and uploaded with the device idle, 170 us per call in
+    #  profiles/r06_bench_trace_excerpt.txt; vectors beyond the count are unit rows of rounding noise or exact zeros, harmless here)
+    n_all = np.where(k1 - k0 > 0, np.minimum((k1 + 31) // 32 * 32, ks), 0)
     one = np.ones(len(ks), dtype=np.int64)
     nv = n_all if y_is_vh is None else np.where(y_is_vh, n_all, 0)
     nu = n_all if y_is_vh is None else np.where(y_is_vh, 0, n_all)

@@ -142,3 +142,170 @@ def jacobi(A, rho=1e-6, max_sweeps=80, cross_only=True, verbose=False, predict=N
         if cnt == 0 or (predict is not None and big == 0):
             return sweep + 1, W
     return -1, W
+
+
+# ======================================================================================================================
+# Round 6: emulation of the DEFAULT device path -- Gram-only sweeps on 32-row blocks (csrc/tpa_svd_b32.inc), both stopping rules
+# (floor on the larger row: rounds 1 - 5; on the smaller row: round 6, csrc/tpa_svd.hip::svd_needs_rotation), the activity-driven
+# schedule, and the ordered clean-up of linalg/_svd_warm.py::ordered_rows.  Vectorised numpy; used by tests/test_svd_highprec.py.
+# ======================================================================================================================
+BB32, TB32 = 32, 64
+
+
+def needs32(a, b, g2, tol, floor2, on_min):
+    mn, mx0 = np.minimum(a, b), np.maximum(a, b)
+    ok = (a > 0) & (b > 0) & ~(mn < NULL_ROW_CUT * mx0)
+    if on_min:
+        return ok & (g2 > tol * tol * mx0 * np.maximum(mn, floor2))
+    return ok & (g2 > tol * tol * mn * np.maximum(mx0, floor2))
+
+
+def big32(a, b, g2, floor2, on_min):
+    mn, mx0 = np.minimum(a, b), np.maximum(a, b)
+    if on_min:
+        return np.where(mn >= floor2, g2 > 1e-14 * mn * mx0, g2 > 1e-14 * mx0 * np.sqrt(mn * floor2))
+    return np.where(mx0 >= floor2, g2 > 1e-14 * mn * mx0, g2 > 1e-14 * mn * np.sqrt(mx0 * floor2))
+
+
+def _pair_of32(R, pair, rnd):
+    NB = (R + BB32 - 1) // BB32
+    NBp = (NB + 1) // 2 * 2
+    mod = NBp - 1
+    r = rnd % mod if mod > 0 else 0
+    bi, bj = (NBp - 1, r) if pair == 0 else ((r + pair) % mod, (r - pair + mod) % mod)
+    return (bi, bj) if bi < bj else (bj, bi)
+
+
+def _local_pairs32(rr, full_local):
+    a = np.arange(BB32)
+    if not full_local:
+        return a, BB32 + ((a + rr) & (BB32 - 1))
+    x = np.where(a == 0, TB32 - 1, (rr + a) % (TB32 - 1))
+    y = np.where(a == 0, rr, (rr - a + (TB32 - 1)) % (TB32 - 1))
+    return np.minimum(x, y), np.maximum(x, y)
+
+
+def _solve_pair32(Sm, full_local, tol, floor2, on_min):
+    if full_local:
+        iu = np.triu_indices(TB32, 1)
+    else:
+        iu = np.nonzero((np.arange(TB32) < BB32)[:, None] & (np.arange(TB32) >= BB32)[None, :])
+    d = np.diag(Sm)
+    if not needs32(d[iu[0]], d[iu[1]], Sm[iu] ** 2, tol, floor2, on_min).any():
+        return None
+    Q = np.eye(TB32)
+    Sm = Sm.copy()
+    for rr in range(TB32 - 1 if full_local else BB32):
+        p, q = _local_pairs32(rr, full_local)
+        al, be, ga = Sm[p, p], Sm[q, q], Sm[p, q]
+        nr = needs32(al, be, ga * ga, tol, floor2, on_min)
+        if not nr.any():
+            continue
+        with np.errstate(all='ignore'):
+            zeta = (be - al) / (2.0 * ga)
+            t = np.copysign(1.0, zeta) / (np.abs(zeta) + np.sqrt(zeta * zeta + 1.0))
+            c = 1.0 / np.sqrt(t * t + 1.0)
+            s = c * t
+        c, s = np.where(nr, c, 1.0), np.where(nr, s, 0.0)
+        J = np.eye(TB32)
+        J[p, p], J[q, q], J[p, q], J[q, p] = c, c, -s, s
+        Sm = J @ Sm @ J.T
+        Q = J @ Q
+    return Q
+
+
+def jacobi_b32(W0, rho=1e-2, on_min=True, max_sweeps=40):
+    """One-sided block Jacobi on the ROWS of ``W0`` as the device runs it by default: per sweep one exact Gram matrix, the activity of
+    the block pairs on it, the first round of the round-robin schedule (all local pairs) + perfect matchings of the remaining active
+    block pairs, one product with the accumulated transform; the sweep that starts without big pairs is the last.
+    Returns ``(sweeps, rounds, W, G)``: ``W = G W0`` with ``G`` orthogonal (accumulated rotations)."""
+    W = W0.copy()
+    R, L = W.shape
+    fro2 = float((W * W).sum())
+    tol, floor2 = EPS * np.sqrt(L), rho * rho * fro2
+    NB = (R + BB32 - 1) // BB32
+    NBp = (NB + 1) // 2 * 2
+    Gtot = np.eye(R)
+    rounds = 0
+    for sweep in range(max_sweeps):
+        S = W @ W.T
+        d = np.diag(S)
+        nd = needs32(d[:, None], d[None, :], S * S, tol, floor2, on_min)
+        np.fill_diagonal(nd, False)
+        if not nd.any():
+            return sweep, rounds, W, Gtot
+        any_big = bool((nd & big32(d[:, None], d[None, :], S * S, floor2, on_min)).any())
+        pad = NBp * BB32 - R
+        act = np.pad(nd, ((0, pad), (0, pad))).reshape(NBp, BB32, NBp, BB32).any(axis=(1, 3))
+        sched = [[_pair_of32(R, p, 0) for p in range(NBp // 2)]]
+        A = act.copy()
+        np.fill_diagonal(A, False)
+        for (i, j) in sched[0]:
+            A[i, j] = A[j, i] = False
+        while A.any():
+            deg = A.sum(1)
+            free = np.ones(NBp, bool)
+            m = []
+            for v in np.argsort(-deg, kind='stable'):
+                if not free[v] or deg[v] == 0:
+                    continue
+                cand = np.nonzero(A[v] & free)[0]
+                cand = cand[cand != v]
+                if len(cand) == 0:
+                    continue
+                w = cand[np.argmax(deg[cand])]
+                m.append((min(v, w), max(v, w)))
+                free[v] = free[w] = False
+                A[v, w] = A[w, v] = False
+            rest = np.nonzero(free)[0]
+            m += [(rest[k], rest[k + 1]) for k in range(0, len(rest) - 1, 2)]
+            sched.append(m)
+        Qtot = np.eye(R)
+        for r, m in enumerate(sched):
+            for (bi, bj) in m:
+                idx = np.concatenate([np.arange(bi * BB32, bi * BB32 + BB32), np.arange(bj * BB32, bj * BB32 + BB32)])
+                ok = idx < R
+                gi = np.where(ok, idx, 0)
+                Q = _solve_pair32(S[np.ix_(gi, gi)] * np.outer(ok, ok), r == 0, tol, floor2, on_min)
+                if Q is None:
+                    continue
+                rows, Qs = gi[ok], Q[np.ix_(ok, ok)]
+                S[rows, :] = Qs @ S[rows, :]
+                S[:, rows] = S[:, rows] @ Qs.T
+                Qtot[rows, :] = Qs @ Qtot[rows, :]
+        W = Qtot @ W
+        Gtot = Qtot @ Gtot
+        rounds += len(sched)
+        if not any_big:
+            return sweep + 1, rounds, W, Gtot
+    return -1, rounds, W, Gtot
+
+
+def ordered_cleanup(V0, iterations=6):
+    """``ordered_rows`` of linalg/_svd_warm.py on unit rows sorted by descending weight."""
+    T = V0.copy()
+    for _ in range(iterations):
+        G = T @ T.T
+        N = np.tril(G, -1) + np.diag((np.diag(G) - 1.0) / 2.0)
+        T = T - N @ T
+    return T
+
+
+def svd_rows_emulated(W0, rho=1e-2, on_min=True, iterations=6):
+    """``W0 = Gt^T diag(s) V`` through the emulated iteration + the ordered clean-up: returns ``(s, V, Gt, sweeps, rounds)`` with the
+    rows sorted by descending ``s``; ``Gt`` orthogonal to rounding, ``V`` orthonormal after the clean-up."""
+    sweeps, rounds, W, G = jacobi_b32(W0, rho, on_min)
+    s = np.linalg.norm(W, axis=1)
+    order = np.argsort(-s, kind='stable')
+    s, W, G = s[order], W[order], G[order]
+    nz = s > 1e-15 * np.linalg.norm(s)
+    V = np.zeros_like(W)
+    V[nz] = ordered_cleanup(W[nz] / s[nz, None], iterations) if on_min else _lowdin(W[nz] / s[nz, None], iterations)
+    return s, V, G, sweeps, rounds
+
+
+def _lowdin(V0, iterations):
+    T = V0.copy()
+    for _ in range(iterations):
+        T = 1.5 * T - 0.5 * (T @ T.T) @ T
+    return T
