@@ -483,8 +483,11 @@ def run(argv=None, emit=True):
             tref_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_cpu_reference_tebd.json')
             qr_ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_cpu_reference_tebd_qr.json')
             like_for_like = not args.qr
+            eig_ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r06_cpu_reference_tebd_qr_eig.json')
             if args.qr and not args.eig_svd and os.path.exists(qr_ref):      # the reference's own QRBasedTEBDEngine, run offline (round 4)
                 tref_file, like_for_like = qr_ref, True
+            elif args.qr and args.eig_svd and os.path.exists(eig_ref):       # ... with use_eig_based_svd=True (truncation.py:473; round 6)
+                tref_file, like_for_like = eig_ref, True
             n_done = args.warmup + args.steps
             if os.path.exists(tref_file) and world == 1:
                 with open(tref_file) as f:

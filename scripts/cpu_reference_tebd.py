@@ -55,11 +55,12 @@ print("state built in %.1f s, chi = %s" % (t_state, max(psi.chi)), flush=True)
 QR = os.environ.get('TPA_CPU_REF_ENGINE', 'svd') == 'qr'       # the like-for-like reference of `bench.py --config tebd1024 --qr`
 if DEVICE:
     OUT = os.environ.get('TPA_CPU_REF_OUT') or os.path.join(ROOT, 'gpurun_out', 'r04_module_form_tebd%s.json' % ('_qr' if QR else ''))
+EIG = bool(os.environ.get('TPA_CPU_REF_EIG_SVD'))          # round 6: the like-for-like reference of `bench.py --config tebd1024 --qr --eig-svd`
 if QR:
     if not DEVICE:
-        OUT = os.environ.get('TPA_CPU_REF_OUT') or os.path.join(ROOT, 'profiles', 'r04_cpu_reference_tebd_qr.json')
+        OUT = os.environ.get('TPA_CPU_REF_OUT') or os.path.join(ROOT, 'profiles', 'r06_cpu_reference_tebd_qr_eig.json' if EIG else 'r04_cpu_reference_tebd_qr.json')
     eng = tebd.QRBasedTEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 1, 'compute_err': True, 'cbe_expand': 0.1,
-                                          'use_eig_based_svd': False, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
+                                          'use_eig_based_svd': EIG, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
 else:
     eng = tebd.TEBDEngine(psi, M, {'order': 2, 'dt': 0.05, 'N_steps': 1, 'trunc_params': {'chi_max': chi, 'svd_min': 1e-12}})
 steps = []
@@ -83,7 +84,7 @@ for k in range(n_steps):
                   "schmidt_top8": [float(x) for x in np.sort(S)[::-1][:8]]})
     print(steps[-1], flush=True)
     import scipy
-    out = {"engine": "QRBasedTEBDEngine (tebd.py:622; cbe_expand 0.1, compute_err True, use_eig_based_svd False)" if QR else "TEBDEngine",
+    out = {"engine": ("QRBasedTEBDEngine (tebd.py:622; cbe_expand 0.1, compute_err True, use_eig_based_svd %s)" % EIG) if QR else "TEBDEngine",
            "what": "TeNPy %s TEBD engine (order 2, dt 0.05, one step per run(), svd_min 1e-12) on the synthetic state of bench.py --config tebd1024: "
                    "TFIChain L=%d J=1 g=1.5 conserve=parity, random right-canonical MPS chi=%d complex128 seed 1 (scripts/tebd_state.py)"
                    % (tenpy.__version__, L, chi),

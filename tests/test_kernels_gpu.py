@@ -463,6 +463,46 @@ def test_eigh_batch(env, cplx):
         assert (v.conj().T @ v - torch.eye(n, dtype=dt)).abs().max().item() < 1e-12
 
 
+def test_eigh_batch_mixer_blocks(env):
+    """``tpa_eigh_batch`` at the sizes the density-matrix mixer diagonalises at chi = 2048 (``mix_rho``, reference
+    mps_common.py:1972-2079, through ``eigh`` np_conserved.py:3899 / ``_eig_worker`` :5041): graded positive semi-definite blocks of
+    570 and 1086 rows (rho = theta theta^dagger of a wave function with 14 decades of Schmidt values), real data, against LAPACK."""
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(29)
+    ns = [570, 1086]
+    mats = []
+    for n in ns:
+        q, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, generator=g))
+        lam = torch.logspace(0, -14, n, dtype=torch.float64)
+        x = (q * lam) @ q.T
+        mats.append(0.5 * (x + x.T))
+    jobs, a_off, w_off = [], 0, 0
+    for n in ns:
+        jobs.append([a_off, n, w_off, a_off, 0, 0, 0, 0])
+        a_off += n * n
+        w_off += n
+    A = torch.cat([x.reshape(-1) for x in mats]).cuda()
+    W = torch.zeros(w_off, dtype=torch.float64).cuda()
+    V = torch.zeros(a_off, dtype=torch.float64).cuda()
+    jh = np.array(jobs, np.int64)
+    wb = lib.tpa_eigh_worksize(0, jh.ctypes.data, len(jobs))
+    work = torch.empty(wb, dtype=torch.uint8).cuda()
+    sw = ctypes.c_int()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tpa_eigh_batch(0, jh.ctypes.data, len(jobs), A.data_ptr(), W.data_ptr(), V.data_ptr(),
+                                  work.data_ptr(), wb, 60, 0.0, ctypes.byref(sw), st), "eigh")
+    torch.cuda.synchronize()
+    for b, n in enumerate(ns):
+        j = jobs[b]
+        w = W[j[2]:j[2] + n].cpu()
+        v = V[j[3]:j[3] + n * n].reshape(n, n).cpu()
+        ref = torch.linalg.eigvalsh(mats[b])
+        # eigenvalues: absolute accuracy eps ||A|| like LAPACK's (both orders), residual and orthonormality of ALL vectors
+        assert (torch.sort(w).values - ref).abs().max().item() < 1e-13 * n
+        assert (mats[b] @ v - v * w).abs().max().item() < 1e-12 * n
+        assert (v.T @ v - torch.eye(n, dtype=torch.float64)).abs().max().item() < 1e-11
+
+
 def test_copy_scale_gather(env):
     torch, lib, _lib = env
     rng = np.random.default_rng(0)
