@@ -121,19 +121,7 @@ class TwoSiteDMRGEngine:
             from .sharded import lanczos_row_panels          # north_star: Krylov vectors as row panels, scalars by all-reduce
             E0, theta, N = lanczos_row_panels(eff_H, theta, self.lanczos_params)
         else:
-            lp = self.lanczos_params
-            n_vec = int(theta._arena.numel())
-            if eff_H.N < self.options.get('max_N_for_ED', 400) and n_vec < max(lp.get('N_max', 20), lp.get('N_min', 2)):
-                # The reference's engine diagonalises tiny effective Hamiltonians exactly (`full_diag_effH` for eff_H.N < max_N_for_ED =
-                # 400, algorithms/dmrg.py:733-739).  The Krylov space of a vector with n entries is exhausted after n steps -- the exact
-                # answer in the sector -- and every further step of a forced N_min only rotates rounding noise (beta ~ 3e-14, just
-                # above the reference's cutoff of 100 eps: "poorly conditioned H matrix" on the edge bonds of every sweep, 10 of 3920
-                # runs of the round-5 bench).  scripts/lanczos_warning_parity.py: TeNPy's engine 0 warnings (it never runs Lanczos
-                # there), TeNPy's LanczosGroundState forced onto those bonds: the same warnings as the loop here.
-                lp = dict(lp)
-                lp['N_max'] = max(2, min(lp.get('N_max', 20), n_vec))        # (the class asks for at least two steps, like the reference's)
-                lp['N_min'] = max(1, min(lp.get('N_min', 2), lp['N_max']))
-            E0, theta, N = LanczosGroundState(eff_H, theta, lp).run()
+            E0, theta, N = LanczosGroundState(eff_H, theta, self.lanczos_params).run()
         if not self.shard_matvec and isinstance(getattr(eff_H, '_fplans', None), dict) and 'lkey' in eff_H._fplans:
             self._heff_plans[i0] = eff_H._fplans
         theta = eff_H.prepare_svd(theta)                      # fused matrix [(vL.p0), (p1.vR)]

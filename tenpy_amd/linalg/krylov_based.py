@@ -102,7 +102,13 @@ class LanczosGroundState:
         w = self.psi0
         n, dtype = w._arena.numel(), w.dtype
         code, L = dev.code(dtype), dev.lib()
-        N_max = self.N_max
+        # The launch program exists only when the block structure of the vector is CLOSED under the operator (`native_input`): the
+        # Krylov space then lives in n dimensions and is exhausted after n steps -- the exact answer in that space.  A forced N_min
+        # beyond n would only rotate rounding noise (edge bonds of a chain: n = 3 ... 6; beta stays far above any cutoff when the
+        # start vector was nearly converged, because its tiny first residual is normalised).  The reference's engine never gets there:
+        # it diagonalises effective Hamiltonians below N = 400 exactly (algorithms/dmrg.py:733-739, `full_diag_effH`).
+        N_max = max(2, min(self.N_max, n))
+        N_min_run = min(self.N_min, N_max)
         krylov = dev.scratch('lanczos_krylov', (N_max + 1) * n, dtype)
         scal = dev.scratch('lanczos_scalars', 2 * (N_max + 2) + 4, np.float64)
         _, scr = dev.reduction_buffers()
@@ -117,10 +123,10 @@ class LanczosGroundState:
                 # :673, `_converged` reads Es[j] and Es[j - 1]) and by the final result: below N_min - 2 it is skipped -- the same
                 # (E0, psi0, N), ~30 us less host time per step (at chi <= 512 the device waits for this callback)
                 # (also at the last step the loop can take: the reference allows N_min > N_max and returns the N_max result)
-                if j + 2 >= self.N_min or j + 1 >= N_max or abs(b) < self._cutoff:
+                if j + 2 >= N_min_run or j + 1 >= N_max or abs(b) < self._cutoff:
                     self._calc_result_krylov(j)
                 h[j, j + 1] = h[j + 1, j] = b
-                return int(abs(b) < self._cutoff or (j + 1 >= self.N_min and self._converged(j)))
+                return int(abs(b) < self._cutoff or (j + 1 >= N_min_run and self._converged(j)))
             except BaseException as e:       # an exception must not unwind through the C frame
                 err.append(e)
                 return 1
