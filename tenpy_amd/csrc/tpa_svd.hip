@@ -101,10 +101,14 @@ __global__ __launch_bounds__(64) void svd_fro_sum_kernel(const SvdJob *__restric
 // linalg/_svd_warm.py::ordered_rows) and not both (symmetric Loewdin, rounds 3 - 5: error sigma_max * cosine / 2, which is what forced
 // the cosine down to tol rho ||A|| / sigma_max).  On the Jacobi inputs of the chi = 2048 sweeps two thirds of the block pairs never
 // become active under this rule (profiles/r06_stopping_rule_emulation.txt).
-__device__ int tpa_floor_on_min = 0;
+// The mode travels in the SIGN of the floor: floor2 < 0 <=> floor |floor2| on the smaller row.  (A first version kept it in a __device__
+// variable: one global load + s_waitcnt vmcnt(0) inside the angle chain of every elementary round.)
+__device__ __forceinline__ double svd_floor2(double rho, double fro2) { return copysign(rho * rho * fro2, rho); }
 
-__device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2, double tol, double floor2) {
+__device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2, double tol, double floor2s) {
     if (!(a > 0.0) || !(b > 0.0)) return false;
+    const bool tpa_floor_on_min = floor2s < 0.0;
+    const double floor2 = fabs(floor2s);
     const double mn = fmin(a, b), mx0 = fmax(a, b);
     // A row 1e-30 times shorter than its partner (<= 1e-30 ||A||_F) is a zero row for every purpose.  Without this cut a
     // row that lies EXACTLY in the span of the others (exactly rank-deficient block with no room for rounding noise:
@@ -114,6 +118,13 @@ __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2
     if (tpa_floor_on_min) return g2 > tol * tol * mx0 * fmax(mn, floor2);
     const double mx = fmax(mx0, floor2);
     return g2 > tol * tol * mn * mx;
+}
+
+// The same test without control flow (the angle wavefront of the 32-row-block solve evaluates it inside its dependency chain).
+__device__ __forceinline__ bool svd_needs_rotation_bf(double a, double b, double g2, double tol2, double floor2s) {
+    const double mn = fmin(a, b), mx0 = fmax(a, b), floor2 = fabs(floor2s);
+    const double thr = (floor2s < 0.0) ? mx0 * fmax(mn, floor2) : mn * fmax(mx0, floor2);
+    return (mn > 0.0) & !(mn < 1.0e-60 * mx0) & (g2 > tol2 * thr);
 }
 
 // "Big" rotation: scaled cosine above 1e-7.  A sweep without any big rotation leaves all cosines at ~1e-14 or below
@@ -127,8 +138,10 @@ __device__ __forceinline__ bool svd_needs_rotation(double a, double b, double g2
 // repair.  Harmless on pivoted-QR starts (those rows begin nearly orthogonal), visible on warm / sketch starts of blocks graded
 // down to rounding level: tests/test_svd_configs_gpu.py found isometry defects of 1e-10 ... 3e-3 on the MI355X; the numpy emulation
 // (tests/jacobi_emulation.py, NEW_BIG_RULE) shows 0.17 -> 1.8e-5 before the clean-up for rho = 1e-4 and 0.17 -> 1.2e-7 for rho = 1e-6.
-__device__ __forceinline__ bool svd_big_rotation(double a, double b, double g2, double floor2) {
+__device__ __forceinline__ bool svd_big_rotation(double a, double b, double g2, double floor2s) {
     const double mn = fmin(a, b), mx0 = fmax(a, b);
+    const bool tpa_floor_on_min = floor2s < 0.0;
+    const double floor2 = fabs(floor2s);
     if (tpa_floor_on_min) {
         // the rotation leaves a cosine of ~cos^2, to be met by the pair's own rule: cos^2 <= tol rho |A| / sqrt(mn) below the floor
         if (mn >= floor2) return g2 > 1.0e-14 * mn * mx0;
@@ -196,8 +209,8 @@ __global__ __launch_bounds__(NT) void svd_round_kernel(const SvdJob *__restrict_
     if (CPLX) gi = wave_sum(gi);
     const double g2 = gr * gr + gi * gi;
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    if (!svd_needs_rotation(a, b, g2, tol, rho * rho * fro2[jp.x])) return;  // already orthogonal (or NaN)
-    const bool big_rot = svd_big_rotation(a, b, g2, rho * rho * fro2[jp.x]);
+    if (!svd_needs_rotation(a, b, g2, tol, svd_floor2(rho, fro2[jp.x]))) return;  // already orthogonal (or NaN)
+    const bool big_rot = svd_big_rotation(a, b, g2, svd_floor2(rho, fro2[jp.x]));
     const double gabs = sqrt(g2);
     const double zeta = (b - a) / (2.0 * gabs);
     const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel(const SvdJob *__re
     if (tid == 0) any_flag = 0;
     __syncthreads();
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[E.job];
+    const double floor2 = svd_floor2(rho, fro2[E.job]);
     {
         const int ei = tid >> 4, ej = tid & 15;
         const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(NTG, 4) void svd_round_fused_kernel(const SvdJob *_
     }
     __syncthreads();
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[E.job];
+    const double floor2 = svd_floor2(rho, fro2[E.job]);
     {
         const int ei = tid >> 4, ej = tid & 15;
         const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
@@ -802,7 +815,7 @@ __global__ __launch_bounds__(NTW) void svd_round_wide_kernel(const SvdJob *__res
     if (tid == 0) any_flag = 0;
     __syncthreads();
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[E.x];
+    const double floor2 = svd_floor2(rho, fro2[E.x]);
     if (tid < TRJ * TRJ) {
         const int i = tid >> 4, j = tid & 15;
         double sacc = 0;
@@ -1082,7 +1095,7 @@ __global__ __launch_bounds__(NTG) void svd_solve_apply_kernel_c(const SvdJob *__
     if (tid == 0) any_flag = 0;
     __syncthreads();
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[E.job];
+    const double floor2 = svd_floor2(rho, fro2[E.job]);
     {
         const int ei = tid >> 4, ej = tid & 15;
         const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
@@ -1273,7 +1286,7 @@ __global__ __launch_bounds__(NTG, 4) void svd_round_fused_kernel_c(const SvdJob 
     }
     __syncthreads();
     const double tol = 2.220446049250313e-16 * sqrt((double)L);
-    const double floor2 = rho * rho * fro2[E.job];
+    const double floor2 = svd_floor2(rho, fro2[E.job]);
     {
         const int ei = tid >> 4, ej = tid & 15;
         const bool relevant = full_local ? (ei < ej) : (ei < BRJ && ej >= BRJ);
@@ -3180,13 +3193,12 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 return;
             }
             // one launch per round: solve(r) on S_r formed from S_(r-1) and the transforms of round r - 1, + the tiles of update(r - 1)
-            static const int b32_prio = getenv("TPA_B32_PRIO") ? atoi(getenv("TPA_B32_PRIO")) : 0;      // experiment: s_setprio of the angle wavefront
             if (r == 0)
-                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, full_local | (b32_prio << 8), sbuf[0], 0);
+                svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, full_local, sbuf[0], 0);
             else
                 svd_b32_round_kernel<<<n_pairs + n_gup, NTS3, 0, st>>>(jobs, b32p, n_pairs, gup, r, sbuf[(r - 1) & 1], sbuf[r & 1], Qm,
                                                                        qb2[(r - 1) & 1], qb2[r & 1], fb2[(r - 1) & 1], fb2[r & 1], cnt, fro2,
-                                                                       rho, full_local | (b32_prio << 8));
+                                                                       rho, full_local);
             if (r == rounds_g - 1)    // the transforms of the last round still have to reach Qtot (its S tiles are never read)
                 svd_b32_gupdate_kernel<<<n_gup - lay.n_gup_s, NTB, 0, st>>>(gup + lay.n_gup_s, r, sbuf[r & 1], Qm, qb2[r & 1], fb2[r & 1]);
         };
@@ -3921,16 +3933,8 @@ static int tpa_svd_batch_impl(int dtype, const int64_t *jobs_host, int n_jobs, c
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
     for (int b = 0; b < n_jobs; ++b) TPA_ARG_CHECK(jobs_host[8 * b + 1] > 0 && jobs_host[8 * b + 2] > 0);
-    {   // tol < 0: floor |tol| on the SMALLER row of a pair (svd_needs_rotation; the caller post-processes with the ordered clean-up)
-        const int mode = (tol < 0.0) ? 1 : 0;
-        static thread_local int mode_on_device = 0;      // (one device per process)
-        if (mode != mode_on_device) {
-            TPA_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(tpa_floor_on_min), &mode, sizeof(int), 0, hipMemcpyHostToDevice, (hipStream_t)stream));
-            TPA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));      // (`mode` lives on this stack frame)
-            mode_on_device = mode;
-        }
-        tol = fabs(tol);
-    }
+    // tol < 0: floor |tol| on the SMALLER row of a pair (svd_needs_rotation; the caller post-processes with the ordered clean-up): the
+    // sign goes down to the kernels with the value (svd_floor2)
     pin_stage().reset();      // the previous call on this thread ended with a stream synchronisation
     Layout lay = make_layout(dtype, jobs_host, n_jobs);
     TPA_ARG_CHECK(work_bytes >= lay.total);
