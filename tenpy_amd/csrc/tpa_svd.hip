@@ -2629,6 +2629,11 @@ inline void b32_solve_launch(int n_pairs, hipStream_t st, const SvdJob *jobs, co
 }
 
 // ---- round 6: the rounds of a Gram-only sweep as TABLES built from the activity of the block pairs ------------------------------------
+// eigh = shift + SVD: after the shift every singular value sits within |A| of mu -- a (nearly) degenerate cluster, where the iteration does
+// NOT converge quadratically and a sweep without big rotations still leaves cosines of ~1e-8 (tests/test_kernels_gpu.py::
+// test_eigh_batch_mixer_blocks: 7.6e-9 at 570 / 1086 rows).  tpa_eigh_batch therefore switches the predicted-convergence exit off for its
+// call: the iteration ends only when the exact Gram matrix of a sweep start shows no pair left to rotate.
+static thread_local int tpa_svd_strict = 0;
 int tpa_svd_dyn_round0 = 1;      // the first round of a sweep adapts to the activity of its pairs (bit 25 of tpa_svd_set_algorithm: off)
 int tpa_svd_dyn = 1;             // 0 (TPA_SVD_DYN=0 / bit 24 of tpa_svd_set_algorithm): the full round-robin schedule in every sweep (rounds 3 - 5)
 int64_t tpa_svd_dyn_rounds = 0, tpa_svd_dyn_rounds_static = 0, tpa_svd_dyn_sweeps = 0;      // statistics (tpa_svd_dyn_stats)
@@ -3320,7 +3325,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 tpa_svd_dyn_rounds += n_r;
                 tpa_svd_dyn_rounds_static += rounds_g;
                 ++tpa_svd_dyn_sweeps;
-                if (!big) {              // the sweep started without big pairs: every rotation it made converges its pair (predicted convergence)
+                if (!big && !tpa_svd_strict) {      // the sweep started without big pairs: every rotation it made converges its pair (predicted convergence)
                     converged = true;
                     break;
                 }
@@ -3344,7 +3349,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             TPA_LAUNCH_CHECK();
             TPA_HIP_CHECK(hipEventSynchronize(ev_post));
             ++sweep;
-            converged = (posted[0] == 0) || posted[1] == 0;
+            converged = (posted[0] == 0) || (posted[1] == 0 && !tpa_svd_strict);
             if (!tpa_svd_lookahead && !converged && sweep < jac_limit) {
                 g_begin();
                 g_round(0);
@@ -3364,7 +3369,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             TPA_LAUNCH_CHECK();
             TPA_HIP_CHECK(hipEventSynchronize(ev_post));
             ++sweep;
-            converged = (posted[0] == 0) || (tpa_svd_predict_convergence && posted[1] == 0);
+            converged = (posted[0] == 0) || (tpa_svd_predict_convergence && !tpa_svd_strict && posted[1] == 0);
         }
     }
     while (!converged && sweep < jac_limit) {
@@ -3408,7 +3413,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             return TPA_E_NOCONV;
         }
         ++sweep;
-        converged = (h2[0] == 0) || (tpa_svd_predict_convergence && h2[1] == 0);
+        converged = (h2[0] == 0) || (tpa_svd_predict_convergence && !tpa_svd_strict && h2[1] == 0);
     }
     W = Wc;
     G = Gc;
@@ -4094,15 +4099,19 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
     if (dtype == TPA_F64) {
         eigh_shift_kernel<false><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, (double *)(work + lay.off_ap), mu);
         TPA_LAUNCH_CHECK();
+        tpa_svd_strict = 1;
         rc = svd_run<false>(slay, n_jobs, work + lay.off_ap, work + lay.off_u, (double *)(work + lay.off_s),
                             work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st, 0.0);
+        tpa_svd_strict = 0;
         if (rc != 0) return rc;
         eigh_finish_kernel<false><<<n_jobs, NT, 0, st>>>(jobs, (const double *)(work + lay.off_u), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base);
     } else {
         eigh_shift_kernel<true><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, (double *)(work + lay.off_ap), mu);
         TPA_LAUNCH_CHECK();
+        tpa_svd_strict = 1;
         rc = svd_run<true>(slay, n_jobs, work + lay.off_ap, work + lay.off_u, (double *)(work + lay.off_s),
                            work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st, 0.0);
+        tpa_svd_strict = 0;
         if (rc != 0) return rc;
         eigh_finish_kernel<true><<<n_jobs, NT, 0, st>>>(jobs, (const double *)(work + lay.off_u), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base);
     }
