@@ -104,6 +104,7 @@ def parity_and_port(eng, args, gpu_bond_s):
     spread = [L // 2 - 1, 2, L // 4, L // 2, 3 * L // 4]
     bonds = spread[:n_b] if n_b <= len(spread) else [L // 2 - 1 + i for i in range(n_b)]
     t_cpu, n_centre, mv_err, sv_err, e0_err, sv_ind, iso = 0., 0, [], [], [], [], []
+    hp = None
     n_kept = n_kept_bad = n_kept_abs_bad = 0
     for i0 in bonds:
         eff = TwoSiteH(eng.env, i0, factored=False)       # the fused form LHeff . theta . RHeff that the oracle restates
@@ -151,6 +152,8 @@ def parity_and_port(eng, args, gpu_bond_s):
         iso.append(float(max(np.max(np.abs(Ud[:, kept].conj().T @ Ud[:, kept] - np.eye(int(kept.sum())))),
                              np.max(np.abs(Vd[kept] @ Vd[kept].conj().T - np.eye(int(kept.sum())))))))
         e0_err.append(abs(E_dev - E_orc) / abs(E_orc))
+        if i0 == bonds[0] and hp is None:
+            hp = _sv_vs_highprec(fac.prepare_svd(th_fac), np.asarray(S_dev))
     # ---- what the timed sweeps themselves produced (whatever path each bond's SVD took: warm, sketch, cold): isometry of the stored
     #      MPS tensors, sum_{vL, p} conj(A) A = 1 (form A) or sum_{p, vR} B conj(B) = 1 (form B), at the sampled bonds' sites
     mps_iso = []
@@ -173,13 +176,42 @@ def parity_and_port(eng, args, gpu_bond_s):
     parity = {"sv_max_rel_err": max(sv_err), "sv_max_rel_err_individual": max(sv_ind), "sv_kept": n_kept,
               "sv_kept_rel_err_over_1e-10": n_kept_bad, "sv_kept_abs_err_over_32eps_smax": n_kept_abs_bad, "svd_isometry_defect": max(iso),
               "mps_isometry_defect": max(mps_iso) if mps_iso else None,
-              "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err),
+              "matvec_max_rel_err": max(mv_err), "E0_rel_err": max(e0_err), "sv_vs_highprec": hp,
               "parity_sample": "bonds %r (centre, edge, quarter) of the timed state: device block SVD vs LAPACK (oracle; sv_max_rel_err = max |dS| / S_max, "
                                "..._individual = max |dS_i| / S_i over S_i > 1e-8 S_max, mps_isometry_defect = max |T^H T - 1| of the MPS tensors the timed sweeps stored at "
                                "those sites (whatever path their SVDs took), svd_isometry_defect = max(|U^H U - 1|, |VH VH^H - 1|) "
                                "over the vectors with S > 1e-14 S_max), factored device matvec "
                                "vs oracle LHeff.theta.RHeff, %d-step Lanczos energy vs the oracle's Lanczos" % (bonds, args.lanczos_N)}
     return port, parity
+
+
+def _sv_vs_highprec(theta, S_dev, rows=(100, 330)):
+    """the device singular values of ONE mid-size charge block of the centre-bond wave function against singular values
+    in EXTENDED precision (tests/svd_reference.py: np.longdouble, checked against mpmath in tests/test_svd_highprec.py), next to
+    LAPACK's on the same block -- LAPACK cannot arbitrate values below ~1e-6 sigma_max, its own relative error there is 1e-10 ... 1e-3.
+    Returns the worst relative error over the decades >= 1e-12 sigma_max for both, and per decade."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        import svd_reference as sr
+        blocks = theta._data
+        shapes = [b.shape for b in blocks]
+        ks = [min(sh) for sh in shapes]
+        cand = [b for b in range(len(blocks)) if rows[0] <= ks[b] <= rows[1]]
+        if not cand:
+            return None
+        b = max(cand, key=lambda x: ks[x])
+        off = int(sum(ks[:b]))
+        A = np.asarray(blocks[b], dtype=np.float64)
+        ref = sr.sv_reference(A)
+        e_dev = sr.rel_err_by_decade(S_dev[off:off + ks[b]], ref)
+        e_lap = sr.rel_err_by_decade(np.linalg.svd(A, compute_uv=False), ref)
+        dec = [d for d in e_dev if d <= 12 and d in e_lap]
+        return {"block": list(shapes[b]), "sv_max_rel_err_vs_highprec": max(e_dev[d] for d in dec), "lapack_max_rel_err_vs_highprec": max(e_lap[d] for d in dec),
+                "worst_ratio_to_lapack": max(e_dev[d] / max(e_lap[d], 1e-300) for d in dec),
+                "by_decade": {str(d): [float("%.2g" % e_dev[d]), float("%.2g" % e_lap[d])] for d in sorted(e_dev) if d in e_lap},
+                "note": "max relative error per decade of sigma / sigma_max, [device, LAPACK], against np.longdouble singular values; decades 0..12 in the maxima"}
+    except Exception as e:      # a checker: never kills the line
+        return {"error": repr(e)}
 
 
 def reference_same_run(n_bonds=2, timeout=600):
@@ -371,6 +403,9 @@ def run(argv=None, emit=True):
         tm.keep = bool(os.environ.get('TPA_BENCH_SVD_RECORDS')) and tm is npc.svd_timer
         tm.reset()
         tm.enabled = True
+    # the grouped-GEMM rate is measured on every 8th launch (Lanczos run): an event record between two kernels is a barrier packet of
+    # ~5.6 us, and four of them per matvec were 1.7 % of the sweep (KernelTimer.sample); the SVD / eigh timers bracket whole calls
+    npc.gemm_timer.stride = int(os.environ.get('TPA_BENCH_GEMM_TIMER_STRIDE', '8'))
     n0 = 0 if is_tebd else len(eng.update_stats['E_total'])
     from tenpy_amd.linalg import _svd_warm as _sw
     npc.svd_stats['max_block'] = 0          # (a running maximum: the other configurations of the extras run in this process too)
@@ -416,13 +451,14 @@ def run(argv=None, emit=True):
                  "hbm_achieved_GBs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS, "kernel": kernel, "launches": tm.n_launch,
                  "avg_launch_ms": tm.ms / max(tm.n_launch, 1), "algorithmic_flops_per_launch": tm.flops / max(tm.n_launch, 1),
                  "algorithmic_bytes_per_launch": tm.bytes_min / max(tm.n_launch, 1),
-                 "time_share_of_timed_region": sec / max(elapsed, 1e-12)}
+                 # (a sampling timer -- the GEMM one, KernelTimer.sample -- has seen every `stride`-th launch only)
+                 "time_share_of_timed_region": sec * max(int(getattr(tm, 'stride', 1)), 1) / max(elapsed, 1e-12)}
             r.update(extra)
             return r
         pmc_note = {"traffic_note": "no PMC summary for this workload (profiles/r04_svd_call_pmc.json is the chi=2048 Heisenberg call)"}
-        pmc_file = os.path.join(ROOT, 'profiles', 'r05_svd_call_pmc.json')
+        pmc_file = os.path.join(ROOT, 'profiles', 'r06_svd_call_pmc.json')
         if not os.path.exists(pmc_file):
-            pmc_file = os.path.join(ROOT, 'profiles', 'r04_svd_call_pmc.json')
+            pmc_file = os.path.join(ROOT, 'profiles', 'r05_svd_call_pmc.json')
         if args.config == 'heis2048' and chi == CONFIGS['heis2048'][1] and os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 pmc = json.load(f)
@@ -652,6 +688,11 @@ def compact(out):
               "svd_isometry_defect", "matvec_max_rel_err", "E0_rel_err", "trunc_err_eps", "S_mid_entropy", "tebd_route", "prep_s"):
         if k in out:
             c[k] = out[k]
+    hp = out.get("sv_vs_highprec")
+    if isinstance(hp, dict) and "sv_max_rel_err_vs_highprec" in hp:      # (the per-decade table stays in the bench_detail line)
+        c["sv_max_rel_err_vs_highprec"] = hp["sv_max_rel_err_vs_highprec"]
+        c["lapack_max_rel_err_vs_highprec"] = hp["lapack_max_rel_err_vs_highprec"]
+        c["sv_vs_highprec_worst_ratio_to_lapack"] = hp["worst_ratio_to_lapack"]
     tp = out.get("tebd_parity")
     if isinstance(tp, dict):
         c["tebd_parity"] = {k: tp[k] for k in ("after_steps", "S_mid_entropy_abs_err", "trunc_err_eps_rel_err", "schmidt_top8_max_abs_err",

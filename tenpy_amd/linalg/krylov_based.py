@@ -133,7 +133,7 @@ class LanczosGroundState:
         cb = _lib.LANCZOS_CALLBACK(record)
         ptrs = np.array([t.data_ptr() for t in bufs], dtype=np.int64)
         info = np.zeros(4, dtype=np.float64)
-        timed = npc.gemm_timer.enabled
+        timed = npc.gemm_timer.sample()
         ccb = None
         if collective is not None:
             ccb = _lib.COLLECTIVE_CALLBACK(collective)

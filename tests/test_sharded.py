@@ -28,6 +28,13 @@ def _worker(rank, world, port, ret):
         from tenpy_amd.algorithms.sharded import ShardedTwoSiteH, row_partition
         from tenpy_amd.models.spin_chains import spin_half_leg, xxz_chain_mpo
         from tenpy_amd.networks.mps import MPS
+        def same(got, want):
+            """Sharded == unsharded: bit for bit at world 2; with more, smaller row panels the emulation's BLAS (micro-kernels chosen by the
+            panel height) differs in the last bit -- the device kernel sums every element in one fixed order whatever the partition is."""
+            if world == 2:
+                np.testing.assert_array_equal(got, want)
+            else:
+                np.testing.assert_allclose(got, want, rtol=0, atol=1e-14 * max(1., float(np.abs(want).max())))
         rec = [r for r in golden('dmrg.pkl') if r['name'] == 'xxz_L12_chi20_hz'][0]
         L = rec['L']
         H = xxz_chain_mpo(L, rec['Jxx'], rec['Jz'], rec['hz'])
@@ -54,7 +61,7 @@ def _worker(rank, world, port, ret):
             assert kb.stats.get('n_native_sharded', 0) == n0 + 1
             E_r, v_r, N_r = LanczosGroundState(hr, th, {'N_min': 2, 'N_max': 20, 'P_tol': 1.e-14}).run()
             assert N_s == N_r and abs(E_s - E_r) <= 1e-13 * abs(E_r)
-            np.testing.assert_array_equal(hs.prepare_svd(v_s).to_ndarray(), hr.prepare_svd(v_r).to_ndarray())
+            same(hs.prepare_svd(v_s).to_ndarray(), hr.prepare_svd(v_r).to_ndarray())
         # matvec: sharded == unsharded on this rank
         i0 = L // 2 - 1
         from tenpy_amd.algorithms import mps_common
@@ -68,8 +75,8 @@ def _worker(rank, world, port, ret):
             a, b = ref_H.matvec(theta), sh_H.matvec(theta)
             a2, b2 = ref_H.matvec(theta), sh_H.matvec(theta)    # cached plans
             np.testing.assert_array_equal(a._qdata, b._qdata)
-            np.testing.assert_array_equal(a.to_ndarray(), b.to_ndarray())
-            np.testing.assert_array_equal(a2.to_ndarray(), b2.to_ndarray())
+            same(b.to_ndarray(), a.to_ndarray())
+            same(b2.to_ndarray(), a2.to_ndarray())
             bounds = sh_H._sharded['bounds']
             n_rows = (ref_H._LPf if factored else ref_H.LHeff).legs[0].ind_len
             assert bounds[0] == 0 and bounds[-1] == n_rows and np.all(np.diff(bounds) >= 0)
@@ -86,16 +93,16 @@ def _worker(rank, world, port, ret):
         finally:
             npc.SVD_DIST_GROUP = None
         Ul, Sl, Vl = npc.svd(th2, inner_labels=['vR', 'vL'])
-        np.testing.assert_array_equal(Sd, Sl)
-        np.testing.assert_array_equal(Ud.to_ndarray(), Ul.to_ndarray())
-        np.testing.assert_array_equal(Vd.to_ndarray(), Vl.to_ndarray())
+        same(Sd, Sl)
+        same(Ud.to_ndarray(), Ul.to_ndarray())
+        same(Vd.to_ndarray(), Vl.to_ndarray())
         owners = npc.svd_block_owners(np.array([9, 5, 5, 2, 2, 1]), np.array([9, 5, 5, 2, 2, 1]), world)
         assert set(owners.tolist()) == set(range(min(world, 6)))      # LPT with fewer blocks than ranks: some ranks own nothing
         # edge bonds have fewer rows than ranks: ranks with EMPTY row ranges run the same program (VERDICT r5 task 6)
         e_H = ShardedTwoSiteH(eng.env, 0)
         e_th = e_H.combine_theta(psi.get_theta(0, n=2))
         e_ref = TwoSiteH(eng.env, 0).matvec(e_th)
-        np.testing.assert_array_equal(e_H.matvec(e_th).to_ndarray(), e_ref.to_ndarray())
+        same(e_H.matvec(e_th).to_ndarray(), e_ref.to_ndarray())
         if e_H._sharded is not None:
             e_b = e_H._sharded['bounds']
             assert len(e_b) == world + 1 and (world <= 2 or np.any(np.diff(e_b) == 0) or e_b[-1] >= world)
