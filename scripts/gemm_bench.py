@@ -10,7 +10,7 @@ from tenpy_amd.linalg import np_conserved as npc
 from tenpy_amd.linalg.charges import ChargeInfo, LegCharge, LegPipe
 
 
-def dense(n, reps=5):
+def dense(n, reps=int(os.environ.get('REPS', '40'))):
     ch = ChargeInfo()
     leg = LegCharge.from_trivial(n, ch)
     fill = os.environ.get('FILL', 'rand')     # 'ones': constant data -> low toggle power (DVFS check)
@@ -39,7 +39,7 @@ def sectors(chi, var=8.0):
     return q[keep], n[keep]
 
 
-def matvec(chi, reps=5):
+def matvec(chi, reps=int(os.environ.get('REPS', '40'))):
     ch = ChargeInfo([1])
     q, n = sectors(chi)
     vL = LegCharge.from_qind(ch, np.concatenate([[0], np.cumsum(n)]), q.reshape(-1, 1), qconj=+1)
@@ -68,6 +68,19 @@ def matvec(chi, reps=5):
         torch.cuda.synchronize()
         ts.append((time.time() - t0) / reps)
     fl = p1.flops + p2.flops
+    for nm, pl, t in (('step1', p1, ts[0]), ('step2', p2, ts[1])):
+        bm, bn = npc._gemm_tile(pl.dtype, pl.cfg)
+        tk, lk = pl.tasks_host, pl.links_host
+        kpad = np.array([np.sum(-(-lk[f:f + c, 2] // 16) * 16) for f, c in zip(tk[:, 4], tk[:, 5])])
+        mm, nn = tk[:, 1], tk[:, 2]
+        pads = {}
+        for g in (bm, 64, 16):       # rows/cols padded to the tile, to 64 and to 16
+            gm, gn = min(g, bm), min(g, bn)
+            pads[g] = float(np.sum(2.0 * (-(-mm // gm) * gm) * (-(-nn // gn) * gn) * kpad))
+        sk = getattr(pl, 'sk', None)
+        print("   %s cfg %d tile %dx%d tiles %d%s: useful %.2f GF; padded to tile %.3fx, to 64 %.3fx, to 16 %.3fx; rate on tile-padded work %.1f TF/s" % (
+            nm, pl.cfg, bm, bn, pl.n_tiles, (' split-K %d tiles' % sk.n_tiles) if sk is not None else '', pl.flops / 1e9,
+            pads[bm] / pl.flops, pads[64] / pl.flops, pads[16] / pl.flops, pads[bm] / t / 1e12), flush=True)
     print("matvec chi=%d: sectors %s  step1 %.3f ms (%.1f TF/s, %d gemms, %d tiles)  step2 %.3f ms (%.1f TF/s, %d gemms, %d tiles)  "
           "total %.3f ms = %.2f TFLOP/s, %.1f GB min traffic" % (
               chi, n.tolist(), ts[0] * 1e3, p1.flops / ts[0] / 1e12, p1.n_gemm, p1.n_tiles, ts[1] * 1e3, p2.flops / ts[1] / 1e12,
@@ -77,7 +90,7 @@ def matvec(chi, reps=5):
 if __name__ == '__main__':
     from tenpy_amd import _lib
     if os.environ.get('GEMM_VARIANT'):
-        _lib.load().tpa_gemm_set_variant(int(os.environ['GEMM_VARIANT']))
+        _lib.load().tpa_gemm_set_variant(int(os.environ['GEMM_VARIANT']))      # (TPA_GEMM_VARIANT in the environment does the same for any program)
     if os.environ.get('XCD_ORDER'):
         npc.XCD_TILE_ORDER = bool(int(os.environ['XCD_ORDER']))
     if os.environ.get('GEMM_CFG'):

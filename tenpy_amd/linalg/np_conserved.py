@@ -2070,7 +2070,8 @@ def _gemm_tile(dtype, cfg):
 
 
 FORCE_GEMM_CFG = None           # tuning hook
-GEMM_MIN_LARGE_TILES = 2048    # below this many 128x128 tiles the 64x64 configuration fills the 256 CUs better
+GEMM_MIN_LARGE_TILES = 2048    # below this many large (cfg 0) tiles the 64x64 configuration fills the 256 CUs better
+GEMM_LARGE_TILE_PAD = 1.02     # ... and above this ratio of the padded work (large tiles / small tiles) it wastes less arithmetic
 
 
 def _plan_host(a_qdata, b_qdata, ncontr, contr_nblocks):
@@ -2232,14 +2233,20 @@ def _build_plan(a, b, ca, cb, fa, fb):
     tasks[:, 4], tasks[:, 5] = first, counts
     # tiles, heaviest chains first
     ksum = np.add.reduceat(K[ga], first)
-    plan.cfg = 0
-    for cfg in (0, 1):
+    # large tiles only where they fill the device AND the block edges pad (almost) as little as on the small tile: the sector sizes of
+    # a DMRG theta (871, 450, 148 ... rows) lose 3 % more on 128 x 64 than on 64 x 64 tiles and are faster on the small one
+    pad = {}
+    for cfg in (1, 0):
         bm, bn = _gemm_tile(plan.dtype, cfg)
         tm, tn = (m_res + bm - 1) // bm, (n_res + bn - 1) // bn
         ntile = tm * tn
         plan.cfg = cfg
-        if int(np.sum(ntile)) >= GEMM_MIN_LARGE_TILES or FORCE_GEMM_CFG == 0:
-            break
+        pad[cfg] = float(np.sum(ntile * ksum)) * bm * bn
+    if FORCE_GEMM_CFG != 0 and (int(np.sum(ntile)) < GEMM_MIN_LARGE_TILES or (plan.dtype.kind != 'c' and pad[0] > GEMM_LARGE_TILE_PAD * pad[1])):
+        plan.cfg = 1
+        bm, bn = _gemm_tile(plan.dtype, 1)
+        tm, tn = (m_res + bm - 1) // bm, (n_res + bn - 1) // bn
+        ntile = tm * tn
     if FORCE_GEMM_CFG is not None and plan.cfg != FORCE_GEMM_CFG:
         plan.cfg = FORCE_GEMM_CFG
         bm, bn = _gemm_tile(plan.dtype, plan.cfg)
