@@ -167,10 +167,8 @@ int tpa_convert(int from_dtype, int to_dtype, int64_t n, const void *src_dev, vo
                 void *stream);
 /* Tile shape (rows, cols of C per workgroup) of GEMM configuration `cfg` for `dtype`. */
 int tpa_gemm_tile_shape(int dtype, int cfg, int *bm, int *bn);
-/* Tuning hook: variant of the large-tile real kernel (0: 4 waves x 64x64, 1: 8 waves x 64x32); bits 1-6: BK = 32 and the wave
- * tilings of the 64 x 64 tile measured in rounds 3-4; bit 7 (128): the double-buffered LDS loop of round 5 (two operand images, one
- * barrier per k-tile) for the real 64 x 64 tile -- built on request, measured SLOWER (dense 4096^3 50.0 -> 46.2 TFLOP/s: the second
- * image costs two workgroups per CU), therefore off by default (profiles/r05_gemm_double_buffer.txt). */
+/* Tuning hook (also TPA_GEMM_VARIANT in the environment): bit 0 = the round-6 loop of the real kernel also for launches of <= 1024
+ * tiles (default there: eight wavefronts per 64 x 64 tile on the round-4 loop; profiles/r06_gemm_v2.txt). */
 int tpa_gemm_set_variant(int v);
 
 /* ---- K5: batched block SVD, one-sided (Hestenes) Jacobi -- replaces svd_flat / LAPACK gesdd
