@@ -288,7 +288,7 @@ CACHE_MAX = 4096
 # above that.  The cold path drops the same order: its rank-revealing QR stops at residual COLUMN norms of 1e-15 |A|_F
 # (QRP_RANK_TOL), i.e. up to sqrt(n) 1e-15 |A|_F ~ 3e-14 |A|_F of Frobenius mass.  Singular values move by <= E_TOL sigma_max.
 E_TOL = 1.e-13
-E_RANK_TOL = float(os.environ.get('TPA_SVD_E_RANK_TOL', '1e-15'))       # singular vectors with values above this fraction of |A|_F are remembered as warm-start basis
+E_RANK_TOL = float(os.environ.get('TPA_SVD_E_RANK_TOL', '4e-15'))       # singular vectors with values above this fraction of |A|_F are remembered as warm-start basis
 
 
 CACHE_MAX_BYTES = None      # device bytes held by the cached bases (LRU): TPA_SVD_WARM_CACHE_GB, else 1/6 of the device's memory (48 GB on an MI355X)
