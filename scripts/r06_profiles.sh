@@ -37,4 +37,11 @@ for cfg in xxz512 hubbard1024; do
   SPAN=$(tail -c 4000 $O/r06_bench_${cfg}_under_rocprof.json | tail -1 | python -c "import sys,json; print(2*json.loads(sys.stdin.read())['value'])")
   [ -n "$f" ] && python scripts/gap_analysis.py "$f" $SPAN > $O/r06_idle_gap_analysis_$cfg.txt 2>&1
 done
+# (4) the grouped GEMM under the SQ counters: dense 4096^3 on the 128 x 64 tile and the chi = 2048 matvec structure on the 64 x 64 tile (new loop)
+cd /tmp
+DENSE=4096 CHIS=2048 REPS=10 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/g1 -o g -- python $R/scripts/gemm_bench.py > $O/r06_gemm_pmc_stdout.txt 2>&1 < /dev/null
+f=$(find /tmp/g1 -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python $R/scripts/pmc_by_grid.py "$f" gemm_chain > $O/r06_gemm_pmc_sq_counters.txt 2>&1
+DENSE=4096 CHIS=2048 REPS=10 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/g2 -o g -- python $R/scripts/gemm_bench.py > /tmp/o_g2.txt 2>&1 < /dev/null
+f=$(find /tmp/g2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r06_gemm_bench_kernel_stats.csv
+cd $R
 ls -la $O
