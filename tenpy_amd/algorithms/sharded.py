@@ -116,7 +116,7 @@ def restrict_plan_rows(plan, res_leg0, lo, hi):
     tiles = np.zeros((len(t_task), 4), dtype=np.int32)
     tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task, local // np.repeat(tn, ntile), local % np.repeat(tn, ntile)
     sub.n_tiles = len(tiles)
-    sub.tasks_dev, sub.links_dev, sub.tiles_dev = dev.to_device(new_tasks), dev.to_device(new_links), dev.to_device(tiles)
+    sub.tasks_dev, sub.links_dev, sub.tiles_dev = dev.to_device_packed(new_tasks, new_links, tiles)
     return sub
 
 

@@ -93,7 +93,7 @@ def gemm_table(dtype, spec):
         tiles[:, 0] = t_task[order]
         tiles[:, 1] = (local // np.repeat(tn, ntile))[order]
         tiles[:, 2] = (local % np.repeat(tn, ntile))[order]
-        tab = (dev.to_device(tasks), dev.to_device(links), dev.to_device(tiles), len(tiles))
+        tab = dev.to_device_packed(tasks, links, tiles) + (len(tiles),)
         _tables[key] = tab
         if len(_tables) > _TABLES_MAX:
             _tables.popitem(last=False)
@@ -380,7 +380,7 @@ def _row_norms_plan(off, rows, cols):
         tab = np.zeros(((int(o_off[-1]) + 3) // 4 * 4, 2), dtype=np.int32) - 1
         tab[:int(o_off[-1]), 0] = np.repeat(np.arange(nb), rows)
         tab[:int(o_off[-1]), 1] = np.arange(int(o_off[-1])) - np.repeat(o_off[:-1], rows)
-        pl = _plan_put(key, (dev.to_device(jobs), dev.to_device(tab), len(tab), int(o_off[-1]), o_off[:-1].copy(), nb))
+        pl = _plan_put(key, dev.to_device_packed(jobs, tab) + (len(tab), int(o_off[-1]), o_off[:-1].copy(), nb))
     return pl
 
 
@@ -499,6 +499,17 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
     both = dev.empty(2 * n_rows, np.float64)
     _row_norms_launch(dtype, E, A['norms'], both[:n_rows])
     _row_norms_launch(dtype, a_arena, A['norms'], both[n_rows:])
+    # Host work of stage B that does not depend on the outcome of the test below, done while the device is still busy with stage A:
+    # in the all-or-nothing mode the only way on is "every block passed" -- that plan and its work areas are looked up BEFORE the wait.
+    B = None
+    if need_all and len(A['act']) == nb:
+        all_keep = np.ones(len(A['act']), dtype=bool)
+        keyB = keyA + (all_keep.tobytes(), np.asarray(u_off_all).tobytes(), np.asarray(v_off_all).tobytes())
+        B = _plan_get(keyB)
+        if B is None:
+            B = _plan_put(keyB, _warm_plan_b(dtype, cplx, side, A, all_keep, np.asarray(u_off_all, dtype=np.int64), np.asarray(v_off_all, dtype=np.int64)))
+        dev.scratch('warm_JU', B['nJU'], dtype), dev.scratch('warm_JV', B['nJV'], dtype), dev.scratch('warm_JS', B['nJS'], np.float64)
+        dev.scratch('warm_Z', B['nZ'], dtype)
     both_h = dev.to_host(both)                                                           # ONE read-back for the two reductions
     nrm, nrmA = _row_norms_read(both_h[:n_rows], A['norms']), _row_norms_read(both_h[n_rows:], A['norms'])
     ok = np.isfinite(nrm) & np.isfinite(nrmA) & (nrmA > 0.)
@@ -519,8 +530,9 @@ def svd_blocks_warm(dtype, a_arena, offs, ms, ns, b_arena, b_off, b_k, b_len, si
         return done, S_out
     # ---- stage B (planned per set of blocks that are still warm): Jacobi on the rows of W (k x p, k <= p) without any QR, then
     #      W = U' S VH'  ->  X = VH'^H S (U'^H Bq);  Z = U'^H Bq (k x len) is the accumulated basis
-    keyB = keyA + (keep.tobytes(), u_off_all.tobytes(), v_off_all.tobytes())
-    B = _plan_get(keyB)
+    keyB = keyA + (keep.tobytes(), np.asarray(u_off_all).tobytes(), np.asarray(v_off_all).tobytes())
+    if B is None or not np.all(keep):
+        B = _plan_get(keyB)
     if B is None:
         B = _plan_put(keyB, _warm_plan_b(dtype, cplx, side, A, keep, np.asarray(u_off_all, dtype=np.int64), np.asarray(v_off_all, dtype=np.int64)))
     JU = dev.scratch('warm_JU', B['nJU'], dtype)

@@ -2262,9 +2262,7 @@ def _build_plan(a, b, ca, cb, fa, fb):
     tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task[order], t_row[order], t_col[order]
     plan.n_tiles = len(tiles)
     plan.tasks_host, plan.links_host = tasks, links
-    plan.tasks_dev = dev.to_device(tasks)
-    plan.links_dev = dev.to_device(links)
-    plan.tiles_dev = dev.to_device(tiles)
+    plan.tasks_dev, plan.links_dev, plan.tiles_dev = dev.to_device_packed(tasks, links, tiles)
     cmul = 8 if plan.dtype.kind == 'c' else 2
     plan.flops = int(cmul * np.sum(M[ga] * K[ga] * N[gb]))
     esz = 16 if plan.dtype.kind == 'c' else 8
@@ -2362,8 +2360,8 @@ def _split_k(plan, tasks, links, tm, tn, knob=None):
     tiles = np.zeros((len(t_task), 4), dtype=np.int32)
     tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task[order], t_row[order], t_col[order]
     sk.tasks_host, sk.links_host, sk.jobs_host, sk.terms_host = new_tasks, new_links, jobs, terms
-    sk.tasks_dev, sk.links_dev, sk.tiles_dev = dev.to_device(sk.tasks_host), dev.to_device(sk.links_host), dev.to_device(tiles)
-    sk.jobs_dev, sk.terms_dev = dev.to_device(sk.jobs_host), dev.to_device(sk.terms_host)
+    sk.tasks_dev, sk.links_dev, sk.tiles_dev, sk.jobs_dev, sk.terms_dev = dev.to_device_packed(sk.tasks_host, sk.links_host, tiles, sk.jobs_host,
+                                                                                            sk.terms_host)
     sk.n_tiles, sk.total, sk.n_jobs = len(tiles), off, len(jobs)
     sk.max_elems = int(np.max(tasks[:, 1] * tasks[:, 2]))
     return sk
