@@ -198,6 +198,33 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
                   void *u_base, double *s_dev, void *vh_base, void *work_dev, int64_t work_bytes,
                   int max_sweeps, double tol, int *sweeps_done, void *stream);
 
+/* ---- the per-bond SVD section of a sweep as ONE call (round 6) -- replaces, for a two-site wave function whose bond has been
+ *      decomposed before, the per-block LAPACK calls of npc.svd (np_conserved.py:3676-3760, worker :4950-5002) inside svd_theta
+ *      (truncation.py:258): the WARM route (project on the singular vectors Bq of the bond's previous visit, residual test, one-sided
+ *      Jacobi on W = Bq X^H without any QR, accumulated basis, results in the layout of tpa_svd_batch, singular values on the host,
+ *      ordered clean-up of the vectors below the absolute floor).  All tables are built inside and uploaded in one copy per stage.
+ * side   : 0 = 'R' (X = A: the basis spans the row space of theta; sweep moving right), 1 = 'L' (X = A^T).
+ * blocks : HOST int64[n_blocks][8] = {a_off, m, n, u_off, s_off, v_off, b_off, b_k}: A_b (m x n row-major at a_off; the blocks lie back
+ *          to back and fill a_numel elements), results U_b (m x kk) / S_b (kk) / VH_b (kk x n) at u_off / s_off / v_off (kk = min(m, n)),
+ *          basis Bq_b (b_k x n (side 0) or b_k x m (side 1), row-major, orthonormal rows, 0 < b_k <= kk) at b_off in basis_arena.
+ * u_arena / v_arena (u_numel / v_numel elements) are cleared here; s_host (HOST, sum of kk doubles) receives S (zero beyond b_k).
+ * e_tol  : per block |X - (X Bq^H) Bq|_F <= e_tol |X|_F or the call returns 1 ("stale basis") with info[0] = the worst relative
+ *          residual, info[1] = number of failing blocks, and the result arenas cleared -- the caller goes on with the sketch / cold route.
+ * lowdin_basis: one first-order Loewdin step on the accumulated basis (every few warm generations of a bond).
+ * clean_iterations, clean_floor: ordered re-orthonormalisation (tpa_tri_lower_batch) of the normalised Jacobi rows over the
+ *          significant vectors when some lie below clean_floor |S_b|_2 (0 iterations: none) -- the counterpart of tol < 0 below.
+ * alg_warm / alg_restore: tpa_svd_set_algorithm values for the Jacobi stage (bit 9: no pivoted QR) and afterwards.
+ * max_sweeps, tol, sweeps_done: as for tpa_svd_batch.  info: HOST double[4].  f64 only.  Synchronises the stream.
+ * Returns 0 (done), 1 (stale), or a TPA_E_* code of the Jacobi stage. */
+int tpa_svd_theta(int dtype, int side, const int64_t *blocks, int n_blocks, int64_t a_numel, const void *a_arena,
+                  const void *basis_arena, void *u_arena, int64_t u_numel, void *v_arena, int64_t v_numel, double *s_host,
+                  double e_tol, int lowdin_basis, int clean_iterations, double clean_floor, int alg_warm, int alg_restore,
+                  int max_sweeps, double tol, int *sweeps_done, double *info, void *stream);
+/* The warm-start bases of the bond's next visit out of a finished decomposition: rows [0, ksig_b) of VH_b -> basis_r (ksig x n,
+ * back to back), columns [0, ksig_b) of U_b transposed -> basis_l (ksig x m).  blocks as above (m, n, u_off, v_off are read). */
+int tpa_svd_theta_store(int dtype, const int64_t *blocks, const int64_t *ksig, int n_blocks, const void *u_arena, const void *v_arena,
+                        void *basis_r, void *basis_l, void *stream);
+
 /* Algorithm switch (test / benchmark hook): 0 (default) = pivoted-QR preconditioner + block Jacobi (16-row MFMA
  * Gram + in-LDS eigen-solve); bit 0 = one wavefront per row pair; bit 1 = two-kernel Jacobi rounds instead of the fused one; bit 2 = full local
  * sweep in every round; bits 4-7 = local sweeps; bit 9 (512) = no pivoted-QR preconditioner; bit 10 (1024) = NO predicted

@@ -14,7 +14,7 @@ OUT_DIR = os.environ.get("TPA_BUILD_OUT") or os.path.join(HERE, "_lib")      # (
 LIB_PATH = os.path.join(OUT_DIR, "libtenpy_amd.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["tpa_gemm.hip", "tpa_vec.hip", "tpa_copy.hip", "tpa_svd.hip", "tpa_qr.hip", "tpa_util.hip",
+SOURCES = ["tpa_gemm.hip", "tpa_vec.hip", "tpa_copy.hip", "tpa_svd.hip", "tpa_svd_theta.hip", "tpa_qr.hip", "tpa_util.hip",
            "tpa_plan.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("TPA_BUILD_FLAGS", "").split()
 

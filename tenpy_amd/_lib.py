@@ -52,6 +52,10 @@ _SIGS = {
     "tpa_svd_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp]),
     "tpa_svd_set_algorithm": (ctypes.c_int, [ctypes.c_int]),
+    "tpa_svd_theta": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int64, _vp, _vp, _vp, ctypes.c_int64, _vp, ctypes.c_int64,
+                                     _vp, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp, _vp]),
+    "tpa_svd_theta_store": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "tpa_svd_set_rank_cap": (ctypes.c_int, [ctypes.c_int]),
     "tpa_svd_call_log": (ctypes.c_int64, [_i64p, ctypes.c_int64, ctypes.c_int]),
     "tpa_qr_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),

@@ -2818,6 +2818,22 @@ def _svd_warm_store(a, key, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
     if np.any(ksig <= 0):
         return
     ms, ns, ks = (np.ascontiguousarray(x, dtype=np.int64) for x in (ms, ns, ks))
+    L = dev.lib()
+    if SVD_THETA_NATIVE and a.dtype.kind != 'c' and hasattr(L, 'tpa_svd_theta_store'):
+        r_off = np.concatenate([[0], np.cumsum(ksig * ns)])
+        l_off = np.concatenate([[0], np.cumsum(ksig * ms)])
+        sect = a.__dict__.get('_tpa_sector_keys')
+        if sect is None or sect[0] is not a._qdata:
+            sect = a.__dict__['_tpa_sector_keys'] = (a._qdata, _leg_sector_keys(a.legs[0], a._qdata[:, 0]), _leg_sector_keys(a.legs[1], a._qdata[:, 1]))
+        Rb, Lb = dev.empty(int(r_off[-1]), a.dtype), dev.empty(int(l_off[-1]), a.dtype)
+        zero = np.zeros(len(ms), dtype=np.int64)
+        blocks = np.ascontiguousarray(np.stack([zero, ms, ns, np.asarray(u_offs[:-1]), zero, np.asarray(v_offs[:-1]), zero, zero], axis=1), dtype=np.int64)
+        kc = np.ascontiguousarray(ksig, dtype=np.int64)
+        dev.check(L.tpa_svd_theta_store(dev.code(a.dtype), blocks.ctypes.data, kc.ctypes.data, len(ms), U_arena.data_ptr(), V_arena.data_ptr(),
+                                        Rb.data_ptr(), Lb.data_ptr(), dev.stream()), "svd_theta_store")
+        _svd_warm.cache_put(key, 'R', _svd_warm.Basis(Rb, r_off[:-1].copy(), kc.copy(), ns, sect[2], a.dtype))
+        _svd_warm.cache_put(key, 'L', _svd_warm.Basis(Lb, l_off[:-1].copy(), kc.copy(), ms, sect[1], a.dtype))
+        return
     pkey = _svd_warm._key('store', ksig, ms, ns, ks, np.ascontiguousarray(u_offs, dtype=np.int64), np.ascontiguousarray(v_offs, dtype=np.int64))
     pl = _svd_warm._plan_get(pkey)
     if pl is None:
@@ -2844,6 +2860,7 @@ def _svd_warm_store(a, key, U_arena, V_arena, S_host, ms, ns, ks, u_offs, s_offs
 # Measured on the chi = 2048 theta (round 3): the second batch is a second dependent chain of Jacobi rounds whose length is set by
 # the ROWS of its largest block (~3 ms for blocks of ~150 rows), so mixed calls lose; default: all or nothing.
 SVD_WARM_MAX_COLD_FRACTION = 0.0
+SVD_THETA_NATIVE = os.environ.get('TPA_SVD_THETA_NATIVE', '1') != '0'      # real data: the warm route and the basis store as native calls (tpa_svd_theta)
 # Skipping 1-3 visits after a stale attempt was right while a stale attempt cost 9.3 ms (round 3 / early round 4: it decomposed the blocks
 # that had passed before it gave up); at 0.5 ms per failed attempt against ~7 ms saved by a hit it only throws hits away.  Measured at the
 # end of round 4 (5 + 6 sweeps at chi = 2048, profiles/r04_bench_heis2048_no_cooldown_5_6.json): 65 % instead of 43 % of the calls go
@@ -2880,9 +2897,48 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
     if np.sum(weight[~found]) > SVD_WARM_MAX_COLD_FRACTION * np.sum(weight):
         _svd_warm.stats['fb_nomatch'] += 1
         return None
-    U_arena = dev.zeros(int(u_offs[-1]), a.dtype)
-    V_arena = dev.zeros(int(v_offs[-1]), a.dtype)
     total_sweeps = [0]
+    age = _svd_warm.ages.get(key, 0) + 1
+    native_stale = False
+    U_arena = V_arena = None
+    if SVD_THETA_NATIVE and a.dtype.kind != 'c' and np.all(found) and hasattr(L, 'tpa_svd_theta') \
+            and np.all((b_k > 0) & (b_k <= ks) & (b_len == (ns if side == 'R' else ms))) \
+            and np.array_equal(offs, np.concatenate([[0], np.cumsum(ms * ns)[:-1]])) and int(np.sum(ms * ns)) == int(a._arena.numel()):
+        # the whole warm route as ONE native call (csrc/tpa_svd_theta.hip; include/tenpy_amd.h): tables built in C++, one staged upload
+        # per stage, residual test, Jacobi, accumulated basis, result copies, singular values, ordered clean-up
+        U_arena, V_arena = dev.empty(int(u_offs[-1]), a.dtype), dev.empty(int(v_offs[-1]), a.dtype)
+        blocks = np.ascontiguousarray(np.stack([offs, ms, ns, u_offs[:-1], s_offs[:-1], v_offs[:-1], b_off, b_k], axis=1), dtype=np.int64)
+        S_host = np.zeros(int(s_offs[-1]), dtype=np.float64)
+        info = np.zeros(4, dtype=np.float64)
+        clean_it = SVD_LOWDIN_ITERATIONS if _svd_floor_now[0] > 0. else 0
+        rc = L.tpa_svd_theta(code, 0 if side == 'R' else 1, blocks.ctypes.data, nblk, int(a._arena.numel()), a._arena.data_ptr(),
+                             basis.arena.data_ptr(), U_arena.data_ptr(), int(u_offs[-1]), V_arena.data_ptr(), int(v_offs[-1]),
+                             S_host.ctypes.data, _svd_warm.E_TOL, int(age % 8 == 0), clean_it, float(_svd_floor_now[0]),
+                             SVD_ALGORITHM_CHAIN_WARM[0], SVD_ALGORITHM_CHAIN[0], SVD_MAX_SWEEPS, _svd_tol_arg(), dev.byref(sweeps),
+                             info.ctypes.data, dev.stream())
+        _svd_warm.stats['native_calls'] = _svd_warm.stats.get('native_calls', 0) + 1
+        if rc == 0:
+            _svd_warm.ages[key] = age
+            _svd_warm.stats['warm_calls'] += 1
+            _svd_warm.stats['warm_sweeps'] += sweeps.value
+            _svd_warm.stats['e_rel_last'] = float(info[0])
+            _svd_warm.stats['e_rel_max'] = max(_svd_warm.stats['e_rel_max'], float(info[0]))
+            _svd_warm.last_kind = 'warm'
+            return U_arena, None, V_arena, S_host
+        if rc == 1:            # stale basis: on to the sketch / cold route below (the result arenas come back cleared)
+            _svd_warm.stats['fb_stale'] += int(info[1])
+            _svd_warm.stats['e_rel_last'] = float(info[0])
+            _svd_warm.stats['e_rel_max'] = max(_svd_warm.stats['e_rel_max'], float(info[0]))
+            native_stale = True
+        elif rc in (dev.E_NOCONV, getattr(dev, 'E_NAN', -3)):
+            _svd_warm.stats['fb_svd'] += nblk
+            _svd_warm.stats['fallbacks'] += 1
+            return None
+        else:
+            dev.check(rc, "svd_theta")
+    if U_arena is None:
+        U_arena = dev.zeros(int(u_offs[-1]), a.dtype)
+        V_arena = dev.zeros(int(v_offs[-1]), a.dtype)
 
     def run_svd(j, arena, U, S, VH, qrp):
         sw = dev.c_int()
@@ -2895,10 +2951,12 @@ def _svd_warm_try(L, code, a, hint, jobs, offs, ms, ns, ks, u_offs, s_offs, v_of
         return S_h
 
     # the accumulated basis U'^H Bc drifts from orthonormality by ~eps per warm generation: one Loewdin step every 8th keeps it there
-    age = _svd_warm.ages.get(key, 0) + 1
-    done, S_blocks = _svd_warm.svd_blocks_warm(a.dtype, a._arena, offs, ms, ns, basis.arena, b_off, b_k, b_len, side, run_svd,
-                                               (U_arena, V_arena, u_offs[:-1], v_offs[:-1]),
-                                               lowdin_basis=(age % 8 == 0), need_all=(SVD_WARM_MAX_COLD_FRACTION <= 0.))
+    if native_stale:
+        done, S_blocks = np.zeros(nblk, dtype=bool), [None] * nblk
+    else:
+        done, S_blocks = _svd_warm.svd_blocks_warm(a.dtype, a._arena, offs, ms, ns, basis.arena, b_off, b_k, b_len, side, run_svd,
+                                                   (U_arena, V_arena, u_offs[:-1], v_offs[:-1]),
+                                                   lowdin_basis=(age % 8 == 0), need_all=(SVD_WARM_MAX_COLD_FRACTION <= 0.))
     cold = np.nonzero(~done)[0]
     sk_wait = _svd_warm.sketch_cooldown.get(key, 0)
     if sk_wait > 0:

@@ -108,6 +108,10 @@ class MockLib:
         self.real = _lib.load()
 
     def __getattr__(self, name):  # host-only entry points
+        if name in ('tpa_svd_theta', 'tpa_svd_theta_store'):
+            # device-only composite entry points (csrc/tpa_svd_theta.hip): the emulation runs the Python route of linalg/_svd_warm.py,
+            # which is built from emulated primitives (np_conserved._svd_warm_try tests for the attribute)
+            raise AttributeError(name)
         return getattr(self.real, name)
 
     # ---- K1 --------------------------------------------------------------------------------------

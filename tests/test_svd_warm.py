@@ -243,3 +243,67 @@ def test_warm_cache_is_bounded_by_bytes_and_tied_to_its_owner(backend, monkeypat
     c = Owner()
     assert sw.owner_token(c) not in (ta, tb)        # tokens are never handed out twice
     sw.cache_clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side", ['R', 'L'])
+@pytest.mark.parametrize("sizes", [([40, 70, 9, 33], [52, 70, 17, 20]), ([146, 292, 77, 5], [146, 200, 160, 5]), ([1086, 329], [1068, 658])])
+def test_native_svd_theta_against_the_python_route(side, sizes, monkeypatch):
+    """``tpa_svd_theta`` (csrc/tpa_svd_theta.hip: the warm route and the basis store as native calls) against the Python-driven route of
+    the same algorithm: same routes taken, singular values / reconstruction / isometries of both against LAPACK, and against each other."""
+    from tenpy_amd import _lib
+    _lib.require_gpu()
+    npc.clear_device_caches()
+    sizes_l, sizes_r = sizes
+    res, routes = {}, {}
+    for native in (True, False):
+        monkeypatch.setattr(npc, 'SVD_THETA_NATIVE', native)
+        rng = np.random.RandomState(11)
+        dense, legL, legR = _blocked(rng, sizes_l, sizes_r, decay=14.)
+        _svd_warm.cache_clear()
+        for k in _svd_warm.stats:
+            _svd_warm.stats[k] = 0
+        a = npc.Array.from_ndarray(dense, [legL, legR])
+        npc.svd_hint = ('bondN', side)
+        U, S, VH = npc.svd(a)
+        _check(dense, legL, legR, U, S, VH)
+        out = []
+        cur = dense
+        for step in range(3):          # three warm generations: each starts from the basis the previous one stored
+            d2 = cur.copy()
+            for q in range(legL.block_number):
+                sl = (slice(legL.slices[q], legL.slices[q + 1]), slice(legR.slices[q], legR.slices[q + 1]))
+                blk = cur[sl]
+                mix = np.eye(blk.shape[0]) + 1e-7 * rng.standard_normal((blk.shape[0],) * 2)
+                mixr = np.eye(blk.shape[1]) + 1e-7 * rng.standard_normal((blk.shape[1],) * 2)
+                d2[sl] = (mix @ blk) if side == 'R' else (blk @ mixr)
+            a2 = npc.Array.from_ndarray(d2, [legL, legR])
+            npc.svd_hint = ('bondN', side)
+            U, S, VH = npc.svd(a2)
+            _check(d2, legL, legR, U, S, VH)
+            out.append((S.copy(), U.to_ndarray(), VH.to_ndarray()))
+            cur = d2
+        # (a generation whose residual lands just above E_TOL -- wide blocks of the largest case, side L: 1.5e-13 -- goes through the
+        #  sketch route on BOTH routes: the residuals agree to the last digit)
+        routes[native] = {k: _svd_warm.stats[k] for k in ('warm_calls', 'sketch_calls', 'cold_calls', 'fb_stale')}
+        assert _svd_warm.stats['warm_calls'] >= 2 and _svd_warm.stats['warm_calls'] + _svd_warm.stats['sketch_calls'] == 3, dict(_svd_warm.stats)
+        assert _svd_warm.stats['cold_calls'] == 1
+        assert (_svd_warm.stats.get('native_calls', 0) == 3) == native
+        # a stale basis: the native call reports it and the sketch route takes over
+        d3 = cur.copy()
+        for q in range(legL.block_number):
+            sl = (slice(legL.slices[q], legL.slices[q + 1]), slice(legR.slices[q], legR.slices[q + 1]))
+            m, n = cur[sl].shape
+            x = rng.standard_normal((m, 2)) @ rng.standard_normal((2, n))
+            d3[sl] = cur[sl] + 1e-7 * x / np.abs(x).max()
+        npc.svd_hint = ('bondN', side)
+        U, S, VH = npc.svd(npc.Array.from_ndarray(d3, [legL, legR]))
+        _check(d3, legL, legR, U, S, VH)
+        assert _svd_warm.stats['fb_stale'] > routes[native]['fb_stale'] and _svd_warm.stats['sketch_calls'] == routes[native]['sketch_calls'] + 1, dict(_svd_warm.stats)
+        res[native] = out
+        npc.clear_device_caches()
+    assert routes[True] == routes[False], routes
+    for (S1, U1, V1), (S0, U0, V0) in zip(res[True], res[False]):
+        assert np.abs(S1 - S0).max() <= 1e-14 * S0.max()
+        keep = S0 > 1e-9 * S0.max()          # (vectors of well separated values agree up to sign)
+        assert np.abs(np.abs(np.sum(U1[:, keep] * U0[:, keep], axis=0)) - 1.).max() < 1e-6
