@@ -214,7 +214,8 @@ int tpa_svd_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a
  * clean_iterations, clean_floor: ordered re-orthonormalisation (tpa_tri_lower_batch) of the normalised Jacobi rows over the
  *          significant vectors when some lie below clean_floor |S_b|_2 (0 iterations: none) -- the counterpart of tol < 0 below.
  * alg_warm / alg_restore: tpa_svd_set_algorithm values for the Jacobi stage (bit 9: no pivoted QR) and afterwards.
- * max_sweeps, tol, sweeps_done: as for tpa_svd_batch.  info: HOST double[4].  f64 only.  Synchronises the stream.
+ * max_sweeps, tol, sweeps_done: as for tpa_svd_batch.  info: HOST double[4].  f64 only.  Waits for the residual test and for the
+ * singular values; the result copies and the clean-up may still be queued on the stream when it returns.
  * Returns 0 (done), 1 (stale), or a TPA_E_* code of the Jacobi stage. */
 int tpa_svd_theta(int dtype, int side, const int64_t *blocks, int n_blocks, int64_t a_numel, const void *a_arena,
                   const void *basis_arena, void *u_arena, int64_t u_numel, void *v_arena, int64_t v_numel, double *s_host,

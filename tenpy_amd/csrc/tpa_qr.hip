@@ -223,13 +223,15 @@ extern "C" int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, con
     TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
     if (n_jobs <= 0) return 0;
     {   // The work areas come from hipMallocAsync / hipFreeAsync.  The default pool gives freed memory back to the OS at the next
-        // synchronisation (release threshold 0), so every call would map its ~100 MB afresh: keep what the pool has handed out.
+        // synchronisation (release threshold 0), so every call would map its ~100 MB afresh: keep up to 8 GB of what the pool has
+        // handed out (bounded -- ADVICE r5: an unbounded threshold kept the multi-GB peak of a batched TEBD QR for the life of the
+        // process, invisible to torch's allocator and to the memory budgets of linalg/_device.py).
         static bool pool_kept = false;
         if (!pool_kept) {
             int devid = 0;
             hipMemPool_t pool;
             if (hipGetDevice(&devid) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, devid) == hipSuccess) {
-                uint64_t thr = UINT64_MAX;
+                uint64_t thr = (uint64_t)8 << 30;
                 (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
             }
             (void)hipGetLastError();

@@ -381,6 +381,11 @@ extern "C" int tpa_svd_theta(int dtype, int side, const int64_t *blocks, int n_b
         if (rc) return rc;
     }
     TPA_HIP_CHECK(hipMemcpyAsync(ph + p_S, JS, 8 * (size_t)nJS, hipMemcpyDeviceToHost, st));
+    // the host waits for the singular values only (event right behind their copy): the accumulated basis, the result copies and the
+    // clean-up below run while the caller already works on the truncation
+    static hipEvent_t ev_S = nullptr;
+    if (!ev_S) TPA_HIP_CHECK(hipEventCreateWithFlags(&ev_S, hipEventDisableTiming));
+    TPA_HIP_CHECK(hipEventRecord(ev_S, st));
     TPA_RC(run_gemm(tZ, tabA, JU, basis_arena, Z, st));
     if (lowdin_basis) {      // Z <- (3 Z - (Z Z^T) Z) / 2   (G lives in the JU area: U' has been consumed)
         TPA_RC(run_gemm(tLG, tabA, Z, Z, JU, st));
@@ -390,7 +395,7 @@ extern "C" int tpa_svd_theta(int dtype, int side, const int64_t *blocks, int n_b
     }
     TPA_RC(run_copy(tC1, tabA, Z, R ? v_arena : u_arena, st));
     TPA_RC(run_copy(tC2, tabA, JV, R ? u_arena : v_arena, st));
-    TPA_HIP_CHECK(hipStreamSynchronize(st));
+    TPA_HIP_CHECK(hipEventSynchronize(ev_S));
     const double *SJ = (const double *)(ph + p_S);
     for (int64_t i = 0; i < nS; ++i) s_host[i] = 0.0;
     for (const Blk &k : B)

@@ -278,7 +278,7 @@ _budget_cache = {}
 
 def memory_budget(env_name, fraction, fallback_gb):
     """Byte cap for a cache / batch work area: ``env_name`` (GB) if set, else ``fraction`` of the TOTAL memory of the current
-    device (``torch.cuda.mem_get_info``), else ``fallback_gb`` when no device can be asked (the emulated device of the CPU
+    device but at most 0.9 of what is FREE at the first call (``torch.cuda.mem_get_info``), else ``fallback_gb`` when no device can be asked (the emulated device of the CPU
     tests).  The defaults of rounds 3-4 (48 GB of warm-start bases, 96 GB of batched TEBD work areas) were 1/6 and 1/3 of an
     MI355X's 288 GB, hard-coded; a smaller GPU ran out of memory."""
     got = _budget_cache.get(env_name)
@@ -290,7 +290,13 @@ def memory_budget(env_name, fraction, fallback_gb):
     else:
         try:
             t = torch()
-            nbytes = int(fraction * t.cuda.mem_get_info()[1]) if t.cuda.is_available() else int(fallback_gb * (1 << 30))
+            if t.cuda.is_available():
+                free, total = t.cuda.mem_get_info()
+                # (several processes on one GPU -- xdist workers of the reference suite, ranks sharing a device -- must not
+                #  each claim a fraction of the WHOLE device: never more than what is free at first use)
+                nbytes = int(min(fraction * total, 0.9 * free))
+            else:
+                nbytes = int(fallback_gb * (1 << 30))
         except Exception:
             nbytes = int(fallback_gb * (1 << 30))
     _budget_cache[env_name] = nbytes

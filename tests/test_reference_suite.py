@@ -43,7 +43,19 @@ def run_reference_tests(args, timeout=3000, plugin='refsuite_plugin', extra_env=
     env = dict(os.environ)
     env.update(extra_env or {})
     env['PYTHONPATH'] = os.pathsep.join([HERE, ROOT, REF, env.get('PYTHONPATH', '')])
-    cmd = [sys.executable, '-m', 'pytest', '-p', plugin, '-p', 'no:cacheprovider', '-q'] + ([] if '-n' in args else ['-x']) + list(args)
+    args = list(args)
+    if '-n' in args:
+        # workers only where pytest-xdist is importable and no GPU is visible (`-n` was a hard dependency, and on the GPU box
+        # it started 3-4 concurrent device processes) -- mirrors conftest.pytest_cmdline_main
+        try:
+            import xdist  # noqa: F401
+            have = not os.path.exists('/dev/kfd')
+        except ImportError:
+            have = False
+        if not have:
+            i = args.index('-n')
+            del args[i:i + 2]
+    cmd = [sys.executable, '-m', 'pytest', '-p', plugin, '-p', 'no:cacheprovider', '-q'] + ([] if '-n' in args else ['-x']) + args
     res = subprocess.run(cmd, cwd=os.path.join(REF, 'tests'), env=env, capture_output=True, text=True, timeout=timeout)
     tail = (res.stdout[-3000:] + "\n" + res.stderr[-2000:])
     assert res.returncode == 0, "reference tests failed on the mirror:\n" + tail
