@@ -503,8 +503,8 @@ def run(argv=None, emit=True):
                           "parallelism": "1 GPU" if world == 1 else
                           ("bonds of every half-step dealt over %d GPUs, one broadcast per new tensor" % world if (is_tebd and not args.qr) else
                            "%d replicas" % world if is_tebd else
-                           "strong scaling of ONE chain: matvec row-sharded over %d GPUs (1 all-gather each), SVD blocks dealt out (LPT + all-gather), rest "
-                           "replicated; predicted bound 1.2x/1.3x/1.4x on 2/4/8 GPUs (DESIGN 5)" % world)},
+                           "strong scaling of ONE chain: matvec row-sharded over %d GPUs (1 all-gather), SVD blocks dealt out (LPT + all-gather), rest "
+                           "replicated; predicted Amdahl bound 1.2x/1.3x/1.4x on 2/4/8 GPUs (DESIGN 5)" % world)},
                "prep_s": t_prep, "roofline": roof_svd, "roofline_gemm": roof_gemm, "energy_err": None}
         if roof_eigh is not None:
             out["roofline_eigh"] = roof_eigh
@@ -670,10 +670,10 @@ def compact(out):
     cfg = out.get("config", {})
     c["config"] = {"workload": (cfg.get("workload") or "")[:230], "name": cfg.get("name"), "parallelism": (cfg.get("parallelism") or "")[:200]}
     tebd = str(out.get("unit")) == "s/step"
-    c["roofline"] = _roof_compact(out.get("roofline"), "tpa_svd_batch (+warm start, clean-up): one entry per npc.svd, all charge blocks")
+    c["roofline"] = _roof_compact(out.get("roofline"), "tpa_svd_batch / tpa_svd_theta (+ clean-up): per npc.svd, all charge blocks")
     if "roofline_eigh" in out and out.get("roofline") is out.get("roofline_eigh"):
         c["roofline"]["kernel"] = "tpa_eigh_batch: Hermitian block eigensolver (_eig_based_svd)"
-    c["roofline_gemm"] = _roof_compact(out.get("roofline_gemm"), "gemm_chain_kernel<f64|c128>: grouped chained MFMA GEMM")
+    c["roofline_gemm"] = _roof_compact(out.get("roofline_gemm"), "gemm_chain kernels: grouped chained MFMA GEMM")
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
         c["cpu_baseline"] = {k: (cb[k][:200] if isinstance(cb[k], str) else cb[k]) for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
@@ -727,7 +727,7 @@ def compact(out):
             if "error" in o:
                 c["other_configs"][name] = {"error": str(o["error"])[:80]}
                 continue
-            e = {"value": o.get("value"), "unit": o.get("unit")}
+            e = {"value": o.get("value")}
             for rk, ek in (("roofline", "frac"), ("roofline_gemm", "gemm_frac"), ("roofline_svd", "svd_frac")):
                 if isinstance(o.get(rk), dict):
                     e[ek] = o[rk].get("frac")
@@ -741,8 +741,9 @@ def compact(out):
             c["other_configs"][name] = e
     mf = out.get("module_form")
     if isinstance(mf, dict):
-        c["module_form"] = {k: mf[k] for k in ("s_per_sweep_steady", "s_per_sweep_at_target_chi", "ramp_sweeps_s", "E", "svd_warm", "vs_standalone",
-                                               "skipped", "error") if k in mf}
+        c["module_form"] = {k: mf[k] for k in ("s_per_sweep_steady", "s_per_sweep_at_target_chi", "E", "vs_standalone", "skipped", "error") if k in mf}
+        if isinstance(mf.get("svd_warm"), dict):      # (the full dictionary and the ramp sweeps: bench_detail line)
+            c["module_form"]["svd_calls_warm_sketch_cold"] = [mf["svd_warm"].get(k) for k in ("warm_calls", "sketch_calls", "cold_calls")]
         if "error" in c["module_form"]:
             c["module_form"]["error"] = str(c["module_form"]["error"])[:120]
     fd = out.get("force_dist")

@@ -95,7 +95,13 @@ class LanczosGroundState:
     def _run_native(self, prog):
         """``_build_krylov`` + ``_calc_result_full`` through ``tpa_lanczos_run`` / ``tpa_krylov_combine``: the device side of every
         step is enqueued by a C++ loop, the reference's host side of a step (tridiagonal ``eigh``, ``_converged``) runs in the
-        callback one step late -- the same numbers as :meth:`_build_krylov_pipelined`, without ~0.5 ms of interpreter time per step."""
+        callback one step late -- the same numbers as :meth:`_build_krylov_pipelined`, without ~0.5 ms of interpreter time per step.
+
+        Sharded operators (``collective`` callback): the failure agreement at the end only covers errors raised AFTER the run's last
+        collective.  A rank that fails mid-run (HIP error, or the collective callback returning 1) reaches the agreement all-reduce while
+        the others sit in the next all-gather of the same communicator -- mismatched collectives, which hang until the process group's
+        timeout instead of raising the intended error (set a finite ``timeout`` on ``init_process_group``).  The success path
+        pays one extra all-reduce and one host read per bond for the agreement."""
         from .. import _lib
         ops, bufs, gemm_plans = prog[:3]
         collective = prog[3] if len(prog) > 3 else None       # sharded operators: the all-gather of the row panels (op kind 3)
