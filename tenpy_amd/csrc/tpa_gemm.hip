@@ -319,7 +319,7 @@ void gemm_chain2_kernel(
     struct View {
         const double *pa, *pb;       // advance by one k-tile per load
         int64_t ka, kb;              // that advance (doubles)
-        int oa[EA], ob[EB];          // element offsets of the thread's elements relative to pa / pb (rows / columns clamped into the block)
+        int64_t oa[EA], ob[EB];      // element offsets of the thread's elements relative to pa / pb (rows / columns clamped into the block)
         int kka, dka, kkb, dkb;      // k index inside the tile of element r: kk + r * dk (tail predicate)
         int la, dla, lb, dlb;        // LDS offset of element r: l + r * dl (doubles, inside an operand plane)
         int K;
@@ -340,7 +340,7 @@ void gemm_chain2_kernel(
             v.dla = di * LD + dk;
 #pragma unroll
             for (int r = 0; r < EA; ++r)
-                v.oa[r] = (int)((int64_t)min(row0 + i + r * di, m - 1) * L.a_rs + (int64_t)(kk + r * dk) * L.a_ks);
+                v.oa[r] = (int64_t)min(row0 + i + r * di, m - 1) * L.a_rs + (int64_t)(kk + r * dk) * L.a_ks;
         }
         {
             const int j = b_kfast ? (tid / BK) : (tid % BN), kk = b_kfast ? (tid % BK) : (tid / BN);
@@ -353,7 +353,7 @@ void gemm_chain2_kernel(
             v.dlb = dj * LD + dk;
 #pragma unroll
             for (int r = 0; r < EB; ++r)
-                v.ob[r] = (int)((int64_t)min(col0 + j + r * dj, n - 1) * L.b_ns + (int64_t)(kk + r * dk) * L.b_ks);
+                v.ob[r] = (int64_t)min(col0 + j + r * dj, n - 1) * L.b_ns + (int64_t)(kk + r * dk) * L.b_ks;
         }
     };
     double ra[EA], rb[EB];

@@ -94,6 +94,27 @@ def test_gemm_strided_chain_accumulate(env, cplx, cfg):
     assert (C - ref).abs().max().item() < 1e-11
 
 
+def test_gemm_row_stride_beyond_2_31_elements(env):
+    """Element offsets inside ONE operand block above 2^31 (a view with a huge row stride: rows 2^29 elements apart, 21 GB arena): the
+    per-thread offsets of the round-6 loop are 64-bit."""
+    torch, lib, _lib = env
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * (1 << 30):
+        pytest.skip("needs 22 GB of device memory")
+    m, n, k, rs = 5, 70, 100, 1 << 29
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rows = torch.randn(m, k, dtype=torch.float64, generator=g).cuda()
+    A = torch.empty((m - 1) * rs + k, dtype=torch.float64, device='cuda')
+    for i in range(m):
+        A[i * rs:i * rs + k] = rows[i]
+    B = torch.randn(k, n, dtype=torch.float64, generator=g).cuda()
+    for cfg in (0, 1):
+        C = torch.full((m, n), float("nan"), dtype=torch.float64).cuda()
+        _run_gemm(torch, lib, _lib, 0, [[0, m, n, n, 0, 1, 0, 0]], [[0, 0, k, rs, 1, n, 1, 0]], A, B, C, cfg)
+        assert (C - rows @ B).abs().max().item() < 1e-11
+    del A
+
+
 def test_gemm_many_tasks(env):
     torch, lib, _lib = env
     rng = np.random.default_rng(3)
