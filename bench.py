@@ -504,7 +504,7 @@ def run(argv=None, emit=True):
                           ("bonds of every half-step dealt over %d GPUs, one broadcast per new tensor" % world if (is_tebd and not args.qr) else
                            "%d replicas" % world if is_tebd else
                            "strong scaling of ONE chain: matvec row-sharded over %d GPUs (1 all-gather), SVD blocks dealt out (LPT + all-gather), rest "
-                           "replicated; predicted Amdahl bound ~1.0x/1.05x/1.1x on 2/4/8 GPUs (DESIGN 5)" % world)},
+                           "replicated; predicted Amdahl bound ~1.15x/1.25x/1.3x on 2/4/8 GPUs (DESIGN 5)" % world)},
                "prep_s": t_prep, "roofline": roof_svd, "roofline_gemm": roof_gemm, "energy_err": None}
         if roof_eigh is not None:
             out["roofline_eigh"] = roof_eigh

@@ -24,7 +24,7 @@ import numpy as np
 
 from ..linalg import _device as dev
 from ..linalg import np_conserved as npc
-from .mps_common import TwoSiteH
+from .mps_common import TwoSiteH, _gemm_ops
 
 __all__ = ['ShardedTwoSiteH', 'row_partition', 'restrict_plan_rows', 'lanczos_row_panels', 'RowPanelOps', 'ShardedTEBDEngine']
 
@@ -116,7 +116,11 @@ def restrict_plan_rows(plan, res_leg0, lo, hi):
     tiles = np.zeros((len(t_task), 4), dtype=np.int32)
     tiles[:, 0], tiles[:, 1], tiles[:, 2] = t_task, local // np.repeat(tn, ntile), local % np.repeat(tn, ntile)
     sub.n_tiles = len(tiles)
+    sub.tasks_host, sub.links_host = new_tasks, new_links
     sub.tasks_dev, sub.links_dev, sub.tiles_dev = dev.to_device_packed(new_tasks, new_links, tiles)
+    # split-K of its OWN (round 6): a row panel has 1 / world of the tiles of the full launch -- the few-tiles / long-chains case the
+    # plan-level split was made for (the sharded path at world 1 ran step 2 of the matvec unsplit: 0.16 s per chi = 2048 sweep)
+    sub.sk = npc._split_k(sub, new_tasks, new_links, tm, tn)
     return sub
 
 
@@ -215,10 +219,22 @@ class ShardedTwoSiteH(TwoSiteH):
         jobs = np.ascontiguousarray(jobs[keep])
         all_segs = [restrict_plan_rows_segments(p2, leg0, int(bounds[r]), int(bounds[r + 1])) for r in range(self.world)]
         maxlen = max(sum(n for _, n in segs) for segs in all_segs)
-        return dict(p1=p1, p2=p2, sp1=sp1, sp2=sp2, a01=a01, T1=T1, T3=T3, segs=all_segs, maxlen=max(maxlen, 1),
-                    key=(theta._struct_key(), theta.dtype), bounds=bounds, n_lin=len(jobs),
+        nT1, nT3 = int(T1._arena.numel()), int(T3._arena.numel())
+        T1._arena = T3._arena = None      # only their block structure is kept; the data live in scratch (`_mid`)
+        return dict(p1=p1, p2=p2, sp1=sp1, sp2=sp2, a01=a01, T1=T1, T3=T3, nT1=nT1, nT3=nT3, segs=all_segs, maxlen=max(maxlen, 1),
+                    key=(theta._struct_key(), theta.dtype), lkey=self._LPf._struct_key(), rkey=self._RPf._struct_key(),
+                    world=(self.world, self.rank), bounds=bounds, n_lin=len(jobs),
                     lin_jobs=dev.to_device(jobs) if len(jobs) else None, lin_terms=dev.to_device(terms),
                     lin_max=int(np.max(jobs[:, 2])) if len(jobs) else 0)
+
+    @staticmethod
+    def _mid(s):
+        """The two intermediates of the factored matvec as scratch arenas (the tables of a bond are kept across sweeps, its
+        2 x 150 MB of intermediates are not); the Arrays ``T1`` / ``T3`` of the plan dictionary are re-pointed to them."""
+        dt = s['p2'].dtype
+        t1, t3 = dev.scratch('shard_t1', s['nT1'], dt), dev.scratch('shard_t3', s['nT3'], dt)
+        s['T1']._arena, s['T3']._arena = t1, t3
+        return t1, t3
 
     def _matvec_sharded_factored(self, theta):
         if self._sharded is None or self._sharded['key'] != (theta._struct_key(), theta.dtype):
@@ -229,6 +245,7 @@ class ShardedTwoSiteH(TwoSiteH):
             self.flops_per_matvec = s['p1'].flops + s['p2'].flops
             self.bytes_per_matvec = s['p1'].bytes_min + s['p2'].bytes_min + s['a01'].bytes
         s = self._sharded
+        self._mid(s)
         T1, T3 = s['T1'], s['T3']
         if not s['sp1'].local_empty:
             s['sp1'].apply(self._LPf, theta, out_arena=T1._arena)
@@ -305,7 +322,21 @@ class ShardedTwoSiteH(TwoSiteH):
         if prog is not None and prog[0] == key:
             return prog[1]
         if self._sharded is None or self._sharded['key'] != key:
-            self._sharded = self._build_sharded_factored(theta) if self.factored else self._build_sharded(theta)
+            # tables of this bond's previous visits (`_sharded_cache`: a dictionary owned by the engine, keyed by the block structure of
+            # the vector -- a bond whose theta has to be embedded in the structure of H theta asks twice per visit), valid while the
+            # environments keep their shape
+            cache = self.__dict__.get('_sharded_cache') if self.factored else None
+            s = cache.get(key) if cache is not None else None
+            if s is not None and (s.get('lkey') != self._LPf._struct_key() or s.get('rkey') != self._RPf._struct_key()
+                                  or s.get('world') != (self.world, self.rank)):
+                s = None
+            if s is None:
+                s = self._build_sharded_factored(theta) if self.factored else self._build_sharded(theta)
+                if cache is not None and s is not None:
+                    if len(cache) >= 4:
+                        cache.clear()
+                    cache[key] = s
+            self._sharded = s
             if self._sharded is not None:
                 s = self._sharded
                 self.flops_per_matvec = s['p1'].flops + s['p2'].flops
@@ -325,20 +356,20 @@ class ShardedTwoSiteH(TwoSiteH):
                 dt = p2.dtype
                 send = dev.scratch('shard_send', s['maxlen'], dt)
                 recv = dev.scratch('shard_recv', s['maxlen'] * self.world, dt)
-                mid = [s['T1']._arena, s['T3']._arena] if self.factored else [s['tmp']._arena]
+                mid = list(self._mid(s)) if self.factored else [s['tmp']._arena]
                 bufs = [left._arena, right._arena] + mid + [send, recv]
                 i_send, i_recv = len(bufs) - 2, len(bufs) - 1
                 ops = []
                 sp1, sp2 = s['sp1'], s['sp2']
                 if not sp1.local_empty:
-                    ops.append([0, sp1.cfg, sp1.tasks_dev.data_ptr(), sp1.links_dev.data_ptr(), sp1.tiles_dev.data_ptr(), sp1.n_tiles, 0, -1, 2, 0, 0, 0])
+                    ops += _gemm_ops(sp1, 0, -1, 2, bufs, 'shard_sk1')
                 last_mid = 2
                 if self.factored:
                     if s['n_lin']:
                         ops.append([1, 0, s['lin_jobs'].data_ptr(), s['lin_terms'].data_ptr(), 0, s['n_lin'], 2, 0, 3, s['lin_max'], 0, 0])
                     last_mid = 3
                 if not sp2.local_empty:
-                    ops.append([0, sp2.cfg, sp2.tasks_dev.data_ptr(), sp2.links_dev.data_ptr(), sp2.tiles_dev.data_ptr(), sp2.n_tiles, last_mid, 1, -2, 0, 0, 0])
+                    ops += _gemm_ops(sp2, last_mid, 1, -2, bufs, 'shard_sk2')
                 if n_pk:
                     ops.append([2, 0, pk.data_ptr(), 0, 0, n_pk, -2, 0, i_send, mx_pk, 0, 0])
                 ops.append([3, 0, 0, 0, 0, 0, i_send, 0, i_recv, 0, 0, 0])
@@ -510,6 +541,7 @@ class RowPanelOps:
         theta = self.gather(panel)
         out_arena = dev.zeros(s['p2'].res_total, self.dtype)
         if H.factored:
+            H._mid(s)
             T1, T3 = s['T1'], s['T3']
             if not s['sp1'].local_empty:
                 s['sp1'].apply(H._LPf, theta, out_arena=T1._arena)

@@ -274,7 +274,8 @@ def test_flop_share_per_rank():
 
 def test_row_restricted_plan_writes_its_rows_only():
     """`restrict_plan_rows` copied the split-K tables of the FULL plan, and `TensordotPlan.apply` prefers them -- a half-row
-    sub-plan then ran the whole GEMM.  A sub-plan has no `sk`, and `apply` leaves every element outside its segments untouched."""
+    sub-plan then ran the whole GEMM.  A sub-plan never carries the parent's `sk` (round 6: it gets a split of its OWN row panel), and
+    `apply` leaves every element outside its segments untouched."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from _pytest.monkeypatch import MonkeyPatch
@@ -309,9 +310,11 @@ def test_row_restricted_plan_writes_its_rows_only():
         leg0 = Heff.LHeff.legs[0]
         bounds = row_partition(np.ones(leg0.ind_len), 2)
         covered = np.zeros(plan.res_total, dtype=int)
+        n_own_split = 0
         for r in range(2):
             sub = restrict_plan_rows(plan, leg0, int(bounds[r]), int(bounds[r + 1]))
-            assert sub.sk is None
+            assert sub.sk is not plan.sk
+            n_own_split += sub.sk is not None
             out = dev.empty(plan.res_total, plan.dtype)
             out.fill_(777.)
             res = sub.apply(Heff.LHeff, theta, out_arena=out)
@@ -323,6 +326,7 @@ def test_row_restricted_plan_writes_its_rows_only():
             np.testing.assert_allclose(got[mine], want[mine], rtol=0, atol=1e-13 * np.abs(want).max())
             covered += mine
         assert np.all(covered == 1)
+        assert n_own_split > 0, "the row panels of this plan are few-tile launches: they get a split of their own"
     finally:
         mp.undo()
         from tenpy_amd.linalg import np_conserved as npc
