@@ -275,15 +275,21 @@ int tpa_qr_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_
  * (linalg/_svd_warm.py::svd_blocks_sketch). */
 int tpa_qr_set_algorithm(int v);
 
-/* ---- K7: batched Hermitian eigendecomposition, cyclic Jacobi (np.linalg.eigh per block,
- *      np_conserved.py:5059-5061) ----------------------------------------------------------
- * jobs : int64[n_jobs][8] = {a_off, n, w_off, v_off, 0,0,0,0} (HOST);  A_b n x n Hermitian row-major,
+/* ---- K7: batched Hermitian eigendecomposition (np.linalg.eigh per block, np_conserved.py:5059-5061; `_eig_worker` :5041)
+ * jobs : int64[n_jobs][8] = {a_off, n, w_off, v_off, 0,0,0,0} (HOST);  A_b n x n Hermitian row-major (lower triangle read, UPLO = 'L'),
  *   eigenvalues ascending at w_off in w_dev, eigenvectors as COLUMNS of V_b (n x n row-major).
- * work_dev >= tpa_eigh_worksize bytes. Synchronises the stream. */
+ * Blocks of >= 96 rows: TWO-SIDED block Jacobi on A_b + mu (mu = 2 |A_b|_F) itself -- 32-row blocks, per round one cyclic Jacobi solve
+ * of every 64 x 64 diagonal pair block and the two-sided MFMA update S[P, P'] <- Q_P S[P, P'] Q_P'^H, Qtot[P, :] <- Q_P Qtot[P, :];
+ * no GEMM over the data, no squared spectrum; stops when no |S_ij| > eps sqrt(n) sqrt(S_ii S_jj) is left (absolute accuracy
+ * eps sqrt(n) |A_b|_F, LAPACK's class).  Smaller blocks (and tpa_eigh_set_direct(0)): the one-sided iteration on the rows of A_b + mu.
+ * All blocks of the call share the launches: callers batch independent matrices (np_conserved.eigh_batched: the bond matrices of a
+ * TEBD half-step).  work_dev >= tpa_eigh_worksize bytes.  Synchronises the stream. */
 int64_t tpa_eigh_worksize(int dtype, const int64_t *jobs_host, int n_jobs);
 int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *a_base,
                    double *w_dev, void *v_base, void *work_dev, int64_t work_bytes, int max_sweeps,
                    double tol, int *sweeps_done, void *stream);
+/* Test hook: 0 = tpa_eigh_batch always takes the shift + one-sided route (rounds 1 - 5), 1 = default. */
+int tpa_eigh_set_direct(int on);
 
 /* ---- host planner: integer bookkeeping of _tensordot_worker (_npc_helper.pyx:1498-1786) ---
  * Inputs describe operand a with its contracted legs LAST and b with its contracted legs FIRST

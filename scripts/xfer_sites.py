@@ -20,13 +20,13 @@ def wrap(name):
         st = traceback.extract_stack(limit=5)
         site = ' <- '.join('%s:%d' % (s.filename.split('/')[-1], s.lineno) for s in reversed(st[:-1]))
         cnt[(name, site)] += 1
-        if name == 'to_device':
+        if name == 'to_device' and len(a) and hasattr(a[0], 'nbytes'):
             byt[(name, site)] += np.asarray(a[0]).nbytes
         return f(*a, **k)
     setattr(dev, name, g)
 
 
-for n in ('to_device', 'to_host', 'read_scalar', 'zeros', 'clone', 'take'):
+for n in ('to_device', 'to_device_packed', 'to_host', 'read_scalar', 'zeros', 'clone', 'take'):
     wrap(n)
 from tenpy_amd.models.spin_chains import xxz_chain_mpo, spin_half_leg
 from tenpy_amd.networks.mps import MPS

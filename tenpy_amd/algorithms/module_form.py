@@ -129,9 +129,10 @@ def hinted_mixed_svd(ref_mixed_svd):
 def batched_tebd_evolve_step(ref_tebd):
     """Fused caller for the reference's ``TEBDEngine.evolve_step`` (algorithms/tebd.py:374-414): the bonds of one half-step do not
     share a site, so their decompositions go to the device as ONE batched call each (``np_conserved.svd_batched`` for
-    ``TEBDEngine.update_bond``, tebd.py:416-483; ``qr_batched`` + ``svd_batched`` for ``QRBasedTEBDEngine.update_bond``, :685-738).
+    ``TEBDEngine.update_bond``, tebd.py:416-483; ``qr_batched`` + ``svd_batched`` / ``eigh_batched`` for ``QRBasedTEBDEngine.update_bond``, :685-738).
     The per-bond statements before and after the decomposition are the reference's, in the reference's order; engines whose
-    ``update_bond`` is not one of those two (subclasses, ``use_eig_based_svd``), and everything else, run the reference's loop."""
+    ``update_bond`` is not one of those two (subclasses), and everything else, run the reference's loop; with ``use_eig_based_svd``
+    the Hermitian eigenproblems of the bond matrices are ONE ``eigh_batched`` call."""
     import numpy as np
     from ..linalg import truncation as dev_trunc
     ref_evolve_step = ref_tebd.TEBDEngine.evolve_step
@@ -142,8 +143,7 @@ def batched_tebd_evolve_step(ref_tebd):
     def evolve_step(self, U_idx_dt, odd):
         upd = type(self).update_bond
         qr_based = upd is ref_update_qr
-        if not (upd is ref_update or qr_based) or not getattr(self.psi, 'finite', False) \
-                or (qr_based and self.options.get('use_eig_based_svd', False, bool)):
+        if not (upd is ref_update or qr_based) or not getattr(self.psi, 'finite', False):
             return ref_evolve_step(self, U_idx_dt, odd)
         Us = self._U[U_idx_dt]
         bonds = [int(i) for i in np.arange(int(odd) % 2, self.psi.L, 2) if Us[i] is not None]
@@ -182,7 +182,8 @@ def batched_tebd_evolve_step(ref_tebd):
         total = TruncationError()
         if qr_based:
             compute_err = self.options.get('compute_err', True, bool)
-            res = dev_trunc.decompose_theta_qr_based_batched(extra, self.trunc_params, compute_err, False)
+            res = dev_trunc.decompose_theta_qr_based_batched(extra, self.trunc_params, compute_err, False,
+                                                             use_eig_based_svd=self.options.get('use_eig_based_svd', False, bool))
             for i, C, theta, (_, S, B_R, form, err, renormalize) in zip(bonds, Cs, thetas, res):
                 i0, i1 = i - 1, i
                 if compute_err:         # the reference's warning (tebd.py:712-725), same condition, same text

@@ -171,15 +171,11 @@ class TEBDEngine:
 class QRBasedTEBDEngine(TEBDEngine):
     """TEBD with the QR-based truncation (reference ``QRBasedTEBDEngine.update_bond``, tebd.py:685-738; options
     ``cbe_expand`` (0.1), ``cbe_expand_0``, ``cbe_min_block_increase`` (1), ``use_eig_based_svd``, ``compute_err``)."""
-    # the bond matrices Xi of a half-step are decomposed in one batched block SVD (truncation.decompose_theta_qr_based_batched); the
-    # `use_eig_based_svd` flavour stays bond by bond
+    # the bond matrices Xi of a half-step are decomposed in one batched block SVD, or -- `use_eig_based_svd` -- one batched Hermitian
+    # eigen-decomposition (truncation.decompose_theta_qr_based_batched)
     batch_bonds_default = True
 
     def update_bonds_batched(self, bonds, U):
-        if self.options.get('use_eig_based_svd', False):
-            for i in bonds:
-                self.update_bond(i, U[i])
-            return
         psi = self.psi
         Cs, items = [], []
         for i in bonds:
@@ -194,7 +190,8 @@ class QRBasedTEBDEngine(TEBDEngine):
             Cs.append(C)
             items.append((old_B_L.qtotal, old_B_R.qtotal, old_B_R.get_leg('vL'), theta, False, expand,
                           self.options.get('cbe_min_block_increase', 1)))
-        res = decompose_theta_qr_based_batched(items, self.trunc_params, self.options.get('compute_err', True), False)
+        res = decompose_theta_qr_based_batched(items, self.trunc_params, self.options.get('compute_err', True), False,
+                                               use_eig_based_svd=self.options.get('use_eig_based_svd', False))
         for i, C, it, (_, S, B_R, form, err, renorm) in zip(bonds, Cs, items, res):
             i0, i1 = i - 1, i
             assert form[1] == 'B'

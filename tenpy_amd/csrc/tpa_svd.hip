@@ -1366,6 +1366,36 @@ __global__ __launch_bounds__(NT) void svd_norms_kernel(const SvdJob *__restrict_
     if (lane == 0) sig[J.sig_off + jr.y] = sqrt(a);
 }
 
+// Direct Hermitian iteration (tpa_svd_direct): S <- W (the n x n input image, R = L = n), Qtot <- 1; and its epilogue sig_i = S_ii.
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void eigh_direct_init_kernel(const SvdJob *__restrict__ jobs, const int2 *__restrict__ rows,
+                                                              const double *__restrict__ W, double *__restrict__ S, double *__restrict__ Qt) {
+    const int gw = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int2 jr = rows[gw];
+    if (jr.x < 0) return;
+    const SvdJob J = jobs[jr.x];
+    const int64_t r = jr.y;
+    for (int64_t c = lane; c < J.R; c += 64) {
+        if (CPLX) {
+            reinterpret_cast<double2 *>(S)[J.g_off + r * J.R + c] = reinterpret_cast<const double2 *>(W)[J.w_off + r * J.L + c];
+            reinterpret_cast<double2 *>(Qt)[J.g_off + r * J.R + c] = double2{(c == r) ? 1.0 : 0.0, 0.0};
+        } else {
+            S[J.g_off + r * J.R + c] = W[J.w_off + r * J.L + c];
+            Qt[J.g_off + r * J.R + c] = (c == r) ? 1.0 : 0.0;
+        }
+    }
+}
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void eigh_direct_diag_kernel(const SvdJob *__restrict__ jobs, const int2 *__restrict__ rows,
+                                                              const double *__restrict__ S, double *__restrict__ sig) {
+    const int gw = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int2 jr = rows[gw];
+    if (jr.x < 0 || (threadIdx.x & 63) != 0) return;
+    const SvdJob J = jobs[jr.x];
+    sig[J.sig_off + jr.y] = S[(CPLX ? 2 : 1) * (J.g_off + (int64_t)jr.y * J.R + jr.y)];
+}
+
 // The order of the singular values on the device (round 5): perm[sig_off + rank(j)] = j with
 //     rank(j) = #{i : s_i > s_j} + #{i < j : s_i == s_j},
 // the permutation of a stable sort by descending sigma (what the host did with std::stable_sort between two copies: D2H of sigma, a
@@ -2634,6 +2664,16 @@ inline void b32_solve_launch(int n_pairs, hipStream_t st, const SvdJob *jobs, co
 // test_eigh_batch_mixer_blocks: 7.6e-9 at 570 / 1086 rows).  tpa_eigh_batch therefore switches the predicted-convergence exit off for its
 // call: the iteration ends only when the exact Gram matrix of a sweep start shows no pair left to rotate.
 static thread_local int tpa_svd_strict = 0;
+// eigh as a TWO-SIDED block Jacobi iteration of its own (round 6, tpa_eigh_batch): the rounds of a Gram-only sweep ARE a two-sided Jacobi
+// method on a Hermitian matrix S (solve: cyclic Jacobi on the 64 x 64 diagonal block of a pair; update: S[P, P'] <- Q_P S[P, P'] Q_P'^H,
+// Qtot[P, :] <- Q_P Qtot[P, :]).  For a Hermitian input the SVD detour -- S = W W^H by a GEMM at the start of every sweep, [W | G] <- Qtot
+// [W | G] by two more at its end -- buys nothing: with `tpa_svd_direct` S starts as the (shifted) matrix itself, every sweep continues on the
+// S the previous one left, Qtot accumulates over the whole call, eigenvalues = diag(S), eigenvectors = rows of Qtot.  No GEMM at all
+// (a third of the flops of a sweep), no squaring of the spectrum.  The stopping rule |S_ij| <= eps sqrt(n) sqrt(S_ii S_jj) reads
+// |H_ij| <= eps sqrt(n) mu on the shifted matrix: the absolute accuracy class of LAPACK's eigh, as before.
+static thread_local int tpa_svd_direct = 0;        // request (set around svd_run by tpa_eigh_batch)
+static thread_local int tpa_svd_direct_used = 0;   // answer: the call ran the direct iteration (eigenvectors come out on the G side)
+int tpa_eigh_direct = 1;                           // test hook (TPA_EIGH_DIRECT=0 / tpa_eigh_set_direct): the shift + one-sided SVD route of rounds 1 - 5
 int tpa_svd_dyn_round0 = 1;      // the first round of a sweep adapts to the activity of its pairs (bit 25 of tpa_svd_set_algorithm: off)
 int tpa_svd_dyn = 1;             // 0 (TPA_SVD_DYN=0 / bit 24 of tpa_svd_set_algorithm): the full round-robin schedule in every sweep (rounds 3 - 5)
 int64_t tpa_svd_dyn_rounds = 0, tpa_svd_dyn_rounds_static = 0, tpa_svd_dyn_sweeps = 0;      // statistics (tpa_svd_dyn_stats)
@@ -3144,16 +3184,31 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     const bool use_gonly = (CPLX ? (use_block && tpa_svd_b32 && !lay.b32_pairs.empty()) : use_b32) && tpa_svd_gonly &&
                            tpa_svd_predict_convergence && lay.ref.enabled && !lay.b32_gup.empty();
     const int rounds_g = (int)std::max<int64_t>(lay.nb32_max_pad - 1, 1);
+    bool direct = false, direct_started = false;      // tpa_svd_direct: two-sided iteration on the Hermitian input itself
+    const double *direct_s = nullptr;                  // where its S ended up
+    tpa_svd_direct_used = 0;
     if (use_gonly && !converged && jac_limit > 0) {
         const B32GUp *gup = (const B32GUp *)(work + lay.off_gup);
         double *Wn = W2, *Gn = G2;
         int rc_g = 0;
         auto g_begin = [&]() {        // S = W W^T (both triangles) -> Mm,  Qtot = 1 -> Qm
+            if (direct) {             // S = W itself, once; later sweeps go on with the S of the previous one
+                if (!direct_started) eigh_direct_init_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, Wc, Mm, Qm);
+                direct_started = true;
+                return;
+            }
             if (int rc = gemm(rt.gram, Wc, Wc, P)) rc_g = rc;
             ref_nsm_kernel<CPLX><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Mm, 0.0, -1.0, 1.0, nullptr, Qm);
         };
         const bool fused = !CPLX && tpa_svd_fused_rounds;
         const bool overlap_c = CPLX && tpa_svd_overlap_c;
+        {   // the direct iteration exists for the two default round drivers: complex (two launches per round, S in place) and the
+            // real activity-driven one; every job must be square (tpa_eigh_batch's are)
+            const bool dyn_ok = fused && tpa_svd_dyn && tpa_svd_lookahead && !lay.b32_act.empty() && lay.off_sched != 0;
+            bool square = true;
+            for (const SvdJob &J : lay.jobs) square = square && (J.R == J.L);
+            direct = tpa_svd_direct && square && (CPLX ? !overlap_c : dyn_ok);
+        }
         static thread_local hipStream_t st2 = nullptr;
         static thread_local hipEvent_t ev_c[2] = {nullptr, nullptr};
         bool rest_pending = false;
@@ -3174,7 +3229,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             if (CPLX) {
                 // complex data: solve(r) -> [tiles the solves of round r + 1 read] on the call's stream, the other tiles on a second
                 // stream beside solve(r + 1); the last round of a sweep only has to bring its transforms into Qtot
-                const bool last = (r == rounds_g - 1);
+                const bool last = (r == rounds_g - 1) && !direct;      // (direct: the next sweep continues on this S)
                 double2 *qbr = (double2 *)b32q + (int64_t)(r & 1) * n_pairs * TB * TB;
                 int *fbr = b32f + (r & 1) * n_pairs;
                 svd_b32_solve_c_kernel<<<n_pairs, NTSC, 0, st>>>(b32p, qbr, fbr, cnt, fro2, rho, full_local, (const double2 *)Mm, r);
@@ -3208,6 +3263,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 svd_b32_gupdate_kernel<<<n_gup - lay.n_gup_s, NTB, 0, st>>>(gup + lay.n_gup_s, r, sbuf[r & 1], Qm, qb2[r & 1], fb2[r & 1]);
         };
         auto g_end = [&]() {          // [W | G] <- Qtot [W | G] into the other image
+            if (direct) return;       // (Qtot accumulates over the whole call)
             if (rest_pending) {
                 if (hipStreamWaitEvent(st, ev_c[1], 0) != hipSuccess) rc_g = 999;
                 rest_pending = false;
@@ -3280,7 +3336,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             TPA_HIP_CHECK(hipMemcpyAsync(sched_dev, sched_stage, (size_t)n_pairs * sizeof(B32Sched), hipMemcpyHostToDevice, st));
             auto sweep_head = [&]() {      // exact Gram matrix, activity of the block pairs, first round: enqueued before the host knows the activity
                 g_begin();
-                b32_activity_kernel<<<n_act_ents, 256, 0, st>>>(jobs, act_ents, Mm, fro2, rho, act_dev);
+                b32_activity_kernel<<<n_act_ents, 256, 0, st>>>(jobs, act_ents, sbuf[0], fro2, rho, act_dev);
                 if (hipMemcpyAsync(act_host, act_dev, (size_t)lay.n_act * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipEventRecord(ev_post, st) != hipSuccess)
                     rc_g = 999;
@@ -3315,8 +3371,12 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                     svd_b32_round_kernel<<<n_pairs + n_gup, NTS3, 0, st>>>(jobs, b32p, n_pairs, gup, r, sbuf[(r - 1) & 1], sbuf[r & 1], Qm,
                                                                            qb2[(r - 1) & 1], qb2[r & 1], fb2[(r - 1) & 1], fb2[r & 1], cnt, fro2,
                                                                            rho, 0, sched_dev + (size_t)r * n_pairs, sched_dev + (size_t)(r - 1) * n_pairs);
-                {   // the transforms of the last round still have to reach Qtot
+                {   // the transforms of the last round still have to reach Qtot -- and, direct iteration, S (in place: S_(rl+1) in image rl & 1)
                     const int rl = n_r - 1;
+                    if (direct) {
+                        svd_b32_gupdate_kernel<<<n_gup, NTB, 0, st>>>(gup, rl, sbuf[rl & 1], Qm, qb2[rl & 1], fb2[rl & 1], sched_dev + (size_t)rl * n_pairs);
+                        if (rl & 1) std::swap(sbuf[0], sbuf[1]);       // the next sweep starts from sbuf[0]
+                    } else
                     svd_b32_gupdate_kernel<<<n_gup - lay.n_gup_s, NTB, 0, st>>>(gup + lay.n_gup_s, rl, sbuf[rl & 1], Qm, qb2[rl & 1], fb2[rl & 1],
                                                                                 sched_dev + (size_t)rl * n_pairs);
                 }
@@ -3357,6 +3417,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         }
         if (rest_pending) TPA_HIP_CHECK(hipStreamWaitEvent(st, ev_c[1], 0));      // (look-ahead round of a sweep that was not needed)
         }
+        if (direct) direct_s = CPLX ? Mm : sbuf[0];
     } else
     if (use_b32 && tpa_svd_lookahead && !converged && jac_limit > 0) {
         TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
@@ -3418,6 +3479,19 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     W = Wc;
     G = Gc;
     if (sweeps_done) *sweeps_done = sweep;
+    if (direct && direct_s != nullptr) {      // eigenvalues (+ shift) = diag(S); the accumulated transform stands in for G
+        eigh_direct_diag_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, direct_s, sig);
+        // Qtot is a product of (sweeps x rounds) 64 x 64 transforms: orthonormal to ~1e-13 ... 1e-12 only.  One Newton-Schulz step
+        // Q <- (3/2 - 1/2 Q Q^H) Q on the GEMM tables of the Gram-only sweeps (square jobs: the W plane and the R x R planes share their
+        // offsets) squares that defect -- three n^3 products per CALL instead of three per sweep.
+        eigh_direct_init_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, Qm, Wc, Gc);      // Wc <- Qtot (Gc <- 1: any finite data)
+        if (int rc = gemm(rt.gram, Wc, Wc, P)) return rc;
+        ref_nsm_kernel<CPLX><<<n_rt, NTM, 0, st>>>(jobs, rrt, P, rt.nsplit_g, pstride, Mm, 1.5, 0.5, 1.0, nullptr, nullptr);
+        double *Wo = (Wc == W) ? W2 : W;        // the other image
+        if (int rc = gemm(rt.apply, Mm, Wc, Wo)) return rc;
+        G = Wo;
+        tpa_svd_direct_used = 1;
+    } else
     svd_norms_kernel<CPLX><<<g_rows, NT, 0, st>>>(jobs, rows, W, sig);
     TPA_LAUNCH_CHECK();
     posted[4] = 0u;     // (mapped host word: set by svd_rank_kernel if a singular value is not finite)
@@ -3973,23 +4047,34 @@ struct EighJob {  // int64[8]
     int64_t a_off, n, w_off, v_off, ap_off, s_off, pad0, pad1;
 };
 
+constexpr int EIGH_PARTS = 32;      // workgroups per job of the elementwise passes (a batched TEBD call holds ~100 blocks of 1024 x 1024)
+template <bool CPLX>
+__global__ __launch_bounds__(NT) void eigh_fro_kernel(const EighJob *__restrict__ jobs, const double *__restrict__ A, double *__restrict__ fpart) {
+    __shared__ double red[NT / 64];
+    const EighJob J = jobs[blockIdx.y];
+    const int64_t tot = J.n * J.n * (CPLX ? 2 : 1);
+    const double *a = A + (CPLX ? 2 : 1) * J.a_off;
+    double s = 0;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < tot; e += (int64_t)EIGH_PARTS * NT) s = fma(a[e], a[e], s);
+    s = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) fpart[blockIdx.y * EIGH_PARTS + blockIdx.x] = s;
+}
+
 template <bool CPLX>
 __global__ __launch_bounds__(NT) void eigh_shift_kernel(const EighJob *__restrict__ jobs,
-                                                        const double *__restrict__ A,
+                                                        const double *__restrict__ A, const double *__restrict__ fpart,
                                                         double *__restrict__ Ap, double *__restrict__ mu) {
-    __shared__ double red[NT / 64];
-    const EighJob J = jobs[blockIdx.x];
-    const int64_t n = J.n, tot = n * n * (CPLX ? 2 : 1);
+    const EighJob J = jobs[blockIdx.y];
+    const int64_t n = J.n;
     const double *a = A + (CPLX ? 2 : 1) * J.a_off;
     double *ap = Ap + (CPLX ? 2 : 1) * J.ap_off;
     double s = 0;
-    for (int64_t e = threadIdx.x; e < tot; e += NT) s = fma(a[e], a[e], s);
-    s = block_sum<NT>(s, red);
+    for (int k = 0; k < EIGH_PARTS; ++k) s += fpart[blockIdx.y * EIGH_PARTS + k];      // fixed order: every workgroup gets the same bits
     // mu = 2 ||A||_F (1 if A == 0): spectrum of A' lies in [||A||_F, 3 ||A||_F] > 0, so every singular
     // vector is well defined and the Jacobi iteration sees a condition number <= 3.
     const double m = (s > 0.0) ? 2.0 * sqrt(s) : 1.0;
-    if (threadIdx.x == 0) mu[blockIdx.x] = m;
-    for (int64_t e = threadIdx.x; e < n * n; e += NT) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) mu[blockIdx.y] = m;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n * n; e += (int64_t)EIGH_PARTS * NT) {
         const int64_t i = e / n, j = e % n;
         if (CPLX) {
             // enforce Hermitian symmetry from the lower triangle like UPLO='L'
@@ -4014,17 +4099,23 @@ __global__ __launch_bounds__(NT) void eigh_finish_kernel(const EighJob *__restri
                                                          const double *__restrict__ U,
                                                          const double *__restrict__ S,
                                                          const double *__restrict__ mu,
-                                                         double *__restrict__ Wout, double *__restrict__ V) {
-    const EighJob J = jobs[blockIdx.x];
+                                                         double *__restrict__ Wout, double *__restrict__ V, int from_vh) {
+    // from_vh (the direct two-sided iteration): `U` is the VH plane of the SVD layout, whose row k is the conjugate of row k of the
+    // accumulated transform; the job ran on W = A'^T, so eigenvector k of A' is conj(VH[k, :]).  (The U plane is W / sigma there: unused.)
+    const EighJob J = jobs[blockIdx.y];
     const int64_t n = J.n;
-    const double m = mu[blockIdx.x];
-    for (int64_t j = threadIdx.x; j < n; j += NT) Wout[J.w_off + j] = S[J.s_off + (n - 1 - j)] - m;
-    for (int64_t e = threadIdx.x; e < n * n; e += NT) {
+    const double m = mu[blockIdx.y];
+    if (blockIdx.x == 0)
+        for (int64_t j = threadIdx.x; j < n; j += NT) Wout[J.w_off + j] = S[J.s_off + (n - 1 - j)] - m;
+    for (int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x; e < n * n; e += (int64_t)gridDim.x * NT) {
         const int64_t i = e / n, j = e % n;
-        if (CPLX)
-            reinterpret_cast<double2 *>(V)[J.v_off + e] = reinterpret_cast<const double2 *>(U)[J.ap_off + i * n + (n - 1 - j)];
-        else
-            V[J.v_off + e] = U[J.ap_off + i * n + (n - 1 - j)];
+        const int64_t src = from_vh ? (J.ap_off + (n - 1 - j) * n + i) : (J.ap_off + i * n + (n - 1 - j));
+        if (CPLX) {
+            double2 v = reinterpret_cast<const double2 *>(U)[src];
+            if (from_vh) v.y = -v.y;
+            reinterpret_cast<double2 *>(V)[J.v_off + e] = v;
+        } else
+            V[J.v_off + e] = U[src];
     }
 }
 
@@ -4032,7 +4123,7 @@ struct EighLayout {
     std::vector<EighJob> jobs;
     std::vector<int64_t> svd_jobs;  // int64[8] per job, offsets into the workspace planes
     int64_t mat_elems = 0, s_elems = 0;
-    int64_t off_ap = 0, off_u = 0, off_vh = 0, off_s = 0, off_mu = 0, off_jobs = 0, off_svd = 0, total = 0;
+    int64_t off_ap = 0, off_u = 0, off_vh = 0, off_s = 0, off_mu = 0, off_fpart = 0, off_jobs = 0, off_svd = 0, total = 0;
 };
 
 EighLayout make_eigh_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
@@ -4064,6 +4155,8 @@ EighLayout make_eigh_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     o = align_up(o + lay.s_elems * 8, 256);
     lay.off_mu = o;
     o = align_up(o + (int64_t)n_jobs * 8, 256);
+    lay.off_fpart = o;
+    o = align_up(o + (int64_t)n_jobs * EIGH_PARTS * 8, 256);
     lay.off_jobs = o;
     o = align_up(o + (int64_t)n_jobs * sizeof(EighJob), 256);
     lay.off_svd = o;
@@ -4093,30 +4186,46 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
     char *work = (char *)work_dev;
     EighJob *jobs = (EighJob *)(work + lay.off_jobs);
     double *mu = (double *)(work + lay.off_mu);
+    double *fpart = (double *)(work + lay.off_fpart);
     TPA_HIP_CHECK(hipMemcpyAsync(jobs, lay.jobs.data(), lay.jobs.size() * sizeof(EighJob), hipMemcpyHostToDevice, st));
     Layout slay = make_layout(dtype, lay.svd_jobs.data(), n_jobs);
     int rc;
+    int direct_req = tpa_eigh_direct;
+    if (const char *e = getenv("TPA_EIGH_DIRECT")) direct_req = atoi(e) != 0;
+    constexpr int EIGH_FIN_PARTS = EIGH_PARTS;
     if (dtype == TPA_F64) {
-        eigh_shift_kernel<false><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, (double *)(work + lay.off_ap), mu);
+        eigh_fro_kernel<false><<<dim3(EIGH_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)a_base, fpart);
+        eigh_shift_kernel<false><<<dim3(EIGH_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)a_base, fpart, (double *)(work + lay.off_ap), mu);
         TPA_LAUNCH_CHECK();
         tpa_svd_strict = 1;
+        tpa_svd_direct = direct_req;
         rc = svd_run<false>(slay, n_jobs, work + lay.off_ap, work + lay.off_u, (double *)(work + lay.off_s),
                             work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st, 0.0);
-        tpa_svd_strict = 0;
+        tpa_svd_strict = tpa_svd_direct = 0;
         if (rc != 0) return rc;
-        eigh_finish_kernel<false><<<n_jobs, NT, 0, st>>>(jobs, (const double *)(work + lay.off_u), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base);
+        const int fv = tpa_svd_direct_used;
+        eigh_finish_kernel<false><<<dim3(EIGH_FIN_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)(work + (fv ? lay.off_vh : lay.off_u)), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base, fv);
     } else {
-        eigh_shift_kernel<true><<<n_jobs, NT, 0, st>>>(jobs, (const double *)a_base, (double *)(work + lay.off_ap), mu);
+        eigh_fro_kernel<true><<<dim3(EIGH_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)a_base, fpart);
+        eigh_shift_kernel<true><<<dim3(EIGH_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)a_base, fpart, (double *)(work + lay.off_ap), mu);
         TPA_LAUNCH_CHECK();
         tpa_svd_strict = 1;
+        tpa_svd_direct = direct_req;
         rc = svd_run<true>(slay, n_jobs, work + lay.off_ap, work + lay.off_u, (double *)(work + lay.off_s),
                            work + lay.off_vh, work + lay.off_svd, max_sweeps, sweeps_done, st, 0.0);
-        tpa_svd_strict = 0;
+        tpa_svd_strict = tpa_svd_direct = 0;
         if (rc != 0) return rc;
-        eigh_finish_kernel<true><<<n_jobs, NT, 0, st>>>(jobs, (const double *)(work + lay.off_u), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base);
+        const int fv = tpa_svd_direct_used;
+        eigh_finish_kernel<true><<<dim3(EIGH_FIN_PARTS, n_jobs), NT, 0, st>>>(jobs, (const double *)(work + (fv ? lay.off_vh : lay.off_u)), (const double *)(work + lay.off_s), mu, w_dev, (double *)v_base, fv);
     }
     TPA_LAUNCH_CHECK();
     TPA_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+/* Test hook: 0 = tpa_eigh_batch takes the shift + one-sided SVD route of rounds 1 - 5, 1 (default) = the direct two-sided iteration. */
+extern "C" int tpa_eigh_set_direct(int on) {
+    tpa_eigh_direct = on ? 1 : 0;
     return 0;
 }
 

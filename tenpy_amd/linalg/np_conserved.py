@@ -3665,64 +3665,103 @@ def eigh(a, UPLO='L', sort=None):
     Returns ``(W, V)``: eigenvalues as host 1-D array (ascending inside each charge block) and the
     eigenvectors as columns of the device Array ``V``.
     """
-    if a.rank != 2 or a.shape[0] != a.shape[1]:
-        raise ValueError("expect a square matrix!")
-    a.legs[0].test_contractible(a.legs[1])
-    if np.any(a.qtotal != a.chinfo.make_valid()):
-        raise ValueError("Non-trivial qtotal -> Nilpotent. Not diagonizable!?")
-    a_labels = a._labels
-    piped_axes, a = a.as_completely_blocked()
-    leg = a.legs[0]
-    n_all = leg.get_block_sizes().astype(np.int64)
-    resw = np.zeros(a.shape[0], dtype=np.float64)
+    return eigh_batched([a], UPLO, sort)[0]
+
+
+def eigh_batched(arrays, UPLO='L', sort=None):
+    """``[eigh(a, UPLO, sort) for a in arrays]`` for INDEPENDENT Hermitian matrices -- the bond matrices ``Xi^dagger Xi`` of all bonds of
+    a Trotter half-step on the ``use_eig_based_svd`` route (reference ``truncation.py:473-530`` called per bond from
+    ``algorithms/tebd.py:685-738``) -- as ONE ``tpa_eigh_batch`` call over the charge blocks of all of them: the Jacobi rounds of the
+    eigensolver are a latency chain that fills a few CUs per matrix, independent matrices share its launches.  Per matrix the result is
+    bit-identical to :func:`eigh` (the blocks never interact)."""
+    if len(arrays) == 0:
+        return []
+    dtype = arrays[0].dtype
+    preps = []
+    a_base = v_base = w_base = 0
+    for a in arrays:
+        if a.rank != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError("expect a square matrix!")
+        if a.dtype != dtype:
+            raise ValueError("eigh_batched: mixed dtypes")
+        a.legs[0].test_contractible(a.legs[1])
+        if np.any(a.qtotal != a.chinfo.make_valid()):
+            raise ValueError("Non-trivial qtotal -> Nilpotent. Not diagonizable!?")
+        a_labels = a._labels
+        piped_axes, ab = a.as_completely_blocked()
+        leg = ab.legs[0]
+        n_all = leg.get_block_sizes().astype(np.int64)
+        v_offs = np.concatenate([[0], np.cumsum(n_all * n_all)])
+        pr = dict(a=ab, labels=a_labels, piped=piped_axes, leg=leg, n_all=n_all, v_offs=v_offs, a_base=a_base, v_base=v_base,
+                  w_base=w_base, jobs=None)
+        if ab.stored_blocks:
+            offs, ms, ns = _blocked_matrix_jobs(ab)
+            w_offs = np.concatenate([[0], np.cumsum(ms)])
+            jobs = np.zeros((len(ms), 8), dtype=np.int64)
+            jobs[:, 0], jobs[:, 1], jobs[:, 2] = offs + a_base, ms, w_offs[:-1] + w_base
+            jobs[:, 3] = v_offs[:-1][ab._qdata[:, 0]] + v_base
+            pr['jobs'], pr['w_offs'], pr['ms'] = jobs, w_offs, ms
+            a_base += int(ab._arena.numel())
+            w_base += int(w_offs[-1])
+        v_base += int(v_offs[-1])
+        preps.append(pr)
     # V starts as identity on every sector; sectors with a stored block get the eigenvectors
-    V = Array([leg if not isinstance(leg, LegPipe) else leg, leg.conj() if not isinstance(leg, LegPipe) else leg.to_LegCharge().conj()], a.dtype)
-    nq = leg.block_number
-    v_offs = np.concatenate([[0], np.cumsum(n_all * n_all)])
-    ident = np.concatenate([np.eye(int(n)).reshape(-1) for n in n_all]) if nq else np.zeros(0)
-    have = np.zeros(nq, dtype=bool)
-    have[a._qdata[:, 0]] = True
-    V_arena = dev.to_device(ident.astype(a.dtype))
-    V._qdata = np.ascontiguousarray(np.stack([np.arange(nq), np.arange(nq)], axis=1), dtype=np.intp)
-    V._offsets = v_offs[:-1].astype(np.int64)
-    V._arena = V_arena
-    V._qdata_sorted = True
-    if a.stored_blocks:
-        offs, ms, ns = _blocked_matrix_jobs(a)
-        nblk = len(ms)
-        w_offs = np.concatenate([[0], np.cumsum(ms)])
-        jobs = np.zeros((nblk, 8), dtype=np.int64)
-        jobs[:, 0], jobs[:, 1], jobs[:, 2] = offs, ms, w_offs[:-1]
-        jobs[:, 3] = v_offs[:-1][a._qdata[:, 0]]
+    ident = [np.eye(int(n)).reshape(-1) for pr in preps for n in pr['n_all']]
+    V_big = dev.to_device((np.concatenate(ident) if ident else np.zeros(0)).astype(dtype))
+    with_blocks = [pr for pr in preps if pr['jobs'] is not None]
+    W_host = None
+    if with_blocks:
+        if len(with_blocks) == 1:
+            big = with_blocks[0]['a']._arena
+        else:
+            big = dev.scratch('eigh_batched_in', a_base, dtype)
+            for pr in with_blocks:
+                n_a = int(pr['a']._arena.numel())
+                big[pr['a_base']:pr['a_base'] + n_a].copy_(pr['a']._arena)
+        jobs = np.ascontiguousarray(np.concatenate([pr['jobs'] for pr in with_blocks]))
+        nblk = len(jobs)
         L = dev.lib()
-        code = dev.code(a.dtype)
-        W_dev = dev.empty(int(w_offs[-1]), np.float64)
+        code = dev.code(dtype)
+        W_dev = dev.empty(w_base, np.float64)
         wb = L.tpa_eigh_worksize(code, jobs.ctypes.data, nblk)
         work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
         sweeps = dev.c_int()
         ev = eigh_timer.begin()
-        dev.check(L.tpa_eigh_batch(code, jobs.ctypes.data, nblk, a._arena.data_ptr(), W_dev.data_ptr(), V_arena.data_ptr(),
+        dev.check(L.tpa_eigh_batch(code, jobs.ctypes.data, nblk, big.data_ptr(), W_dev.data_ptr(), V_big.data_ptr(),
                                    work.data_ptr(), int(wb), 60, 0.0, dev.byref(sweeps), dev.stream()), "eigh_batch")
-        eigh_timer.end(ev, eigh_work(ms, a.dtype.itemsize, a.dtype.kind == 'c'))
+        eigh_timer.end(ev, eigh_work(jobs[:, 1], np.dtype(dtype).itemsize, np.dtype(dtype).kind == 'c'))
         W_host = dev.to_host(W_dev)
-        perm_full = np.arange(a.shape[0], dtype=np.int64)
-        need_perm = False
-        for b in range(nblk):
-            qi = a._qdata[b, 0]
-            w = W_host[w_offs[b]:w_offs[b + 1]]
-            if sort is not None and sort != '<':
-                pb = _argsort(w, sort)
-                w = w[pb]
-                sl = leg.get_slice(qi)
-                perm_full[sl] = sl.start + pb
-                need_perm = True
-            resw[leg.get_slice(qi)] = w
-        if need_perm:
-            V = _permute_within_blocks(V, perm_full, 1)
-    if len(piped_axes) > 0:
-        V = V.split_legs(0)
-    V.iset_leg_labels([a_labels[0], 'eig'])
-    return resw, V
+    out = []
+    for pr in preps:
+        ab, leg, v_offs = pr['a'], pr['leg'], pr['v_offs']
+        nq = leg.block_number
+        resw = np.zeros(ab.shape[0], dtype=np.float64)
+        V = Array([leg if not isinstance(leg, LegPipe) else leg, leg.conj() if not isinstance(leg, LegPipe) else leg.to_LegCharge().conj()], dtype)
+        V._qdata = np.ascontiguousarray(np.stack([np.arange(nq), np.arange(nq)], axis=1), dtype=np.intp)
+        V._offsets = v_offs[:-1].astype(np.int64)
+        V._arena = V_big if len(preps) == 1 else V_big[pr['v_base']:pr['v_base'] + int(v_offs[-1])]
+        V._qdata_sorted = True
+        if pr['jobs'] is not None:
+            w_offs = pr['w_offs']
+            perm_full = np.arange(ab.shape[0], dtype=np.int64)
+            need_perm = False
+            for b in range(len(pr['ms'])):
+                qi = ab._qdata[b, 0]
+                w = W_host[pr['w_base'] + w_offs[b]:pr['w_base'] + w_offs[b + 1]]
+                if sort is not None and sort != '<':
+                    pb = _argsort(w, sort)
+                    w = w[pb]
+                    sl = leg.get_slice(qi)
+                    perm_full[sl] = sl.start + pb
+                    need_perm = True
+                resw[leg.get_slice(qi)] = w
+            if need_perm:
+                V = _permute_within_blocks(V, perm_full, 1)
+        if len(pr['piped']) > 0:
+            V = V.split_legs(0)
+        V.iset_leg_labels([pr['labels'][0], 'eig'])
+        out.append((resw, V))
+    return out
 
 
 def eig(a, sort=None):

@@ -154,33 +154,43 @@ def svd_theta_batched(thetas, trunc_par, qtotal_LRs=None, inner_labels=['vR', 'v
 
 def _eig_based_svd(A, need_U=True, need_Vd=True, inner_labels=[None, None], trunc_params=None):
     """SVD of a matrix through ``eigh`` of ``A A^dagger`` or ``A^dagger A`` (reference :473).  Only one of U / Vd."""
-    assert A.rank == 2
+    return _eig_based_svd_batched([A], need_U, need_Vd, inner_labels, trunc_params)[0]
+
+
+def _eig_based_svd_batched(As, need_U=True, need_Vd=True, inner_labels=[None, None], trunc_params=None):
+    """:func:`_eig_based_svd` for independent matrices (the bond matrices of one Trotter half-step): the Hermitian eigenproblems of
+    all of them in ONE batched device call (``np_conserved.eigh_batched``), then the reference's truncation per matrix."""
     if need_U and need_Vd:
         raise NotImplementedError
-    U = Vd = None
+    for A in As:
+        assert A.rank == 2
+    Us, Vds = [None] * len(As), [None] * len(As)
     if need_U:
-        L, U = npc.eigh(npc.tensordot(A, A.conj(), [1, 1]), sort='>')
-        S = np.sqrt(np.abs(L))
-        U = U.ireplace_label('eig', inner_labels[0])
+        res = npc.eigh_batched([npc.tensordot(A, A.conj(), [1, 1]) for A in As], sort='>')
+        Ss = [np.sqrt(np.abs(L)) for L, _ in res]
+        Us = [U.ireplace_label('eig', inner_labels[0]) for _, U in res]
     elif need_Vd:
-        L, V = npc.eigh(npc.tensordot(A.conj(), A, [0, 0]), sort='>')
-        S = np.sqrt(np.abs(L))
-        Vd = V.iconj().itranspose().ireplace_label('eig*', inner_labels[1])
+        res = npc.eigh_batched([npc.tensordot(A.conj(), A, [0, 0]) for A in As], sort='>')
+        Ss = [np.sqrt(np.abs(L)) for L, _ in res]
+        Vds = [V.iconj().itranspose().ireplace_label('eig*', inner_labels[1]) for _, V in res]
     else:
-        A2 = npc.tensordot(A, A.conj(), [1, 1]) if A.shape[1] >= A.shape[0] else npc.tensordot(A.conj(), A, [0, 0])
-        S = np.sqrt(np.abs(npc.eigvalsh(A2)))
-    if trunc_params is not None:
-        keep, renormalize, trunc_err = truncate(S, trunc_params)
-        S = S[keep] / renormalize
-        if need_U:
-            U.iproject(keep, 1)
-        if need_Vd:
-            Vd.iproject(keep, 0)
-    else:
-        renormalize = np.linalg.norm(S)
-        S = S / renormalize
-        trunc_err = TruncationError()
-    return U, S, Vd, trunc_err, renormalize
+        A2s = [npc.tensordot(A, A.conj(), [1, 1]) if A.shape[1] >= A.shape[0] else npc.tensordot(A.conj(), A, [0, 0]) for A in As]
+        Ss = [np.sqrt(np.abs(L)) for L, _ in npc.eigh_batched(A2s)]
+    out = []
+    for U, S, Vd in zip(Us, Ss, Vds):
+        if trunc_params is not None:
+            keep, renormalize, trunc_err = truncate(S, trunc_params)
+            S = S[keep] / renormalize
+            if need_U:
+                U.iproject(keep, 1)
+            if need_Vd:
+                Vd.iproject(keep, 0)
+        else:
+            renormalize = np.linalg.norm(S)
+            S = S / renormalize
+            trunc_err = TruncationError()
+        out.append((U, S, Vd, trunc_err, renormalize))
+    return out
 
 
 def _qr_theta_Y0(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase):
@@ -340,12 +350,17 @@ def _decompose_qr_prepare_batched(items):
     return [(A_L, B_R, Xi) for A_L, (B_R, Xi) in zip(A_Ls, BX)]
 
 
-def decompose_theta_qr_based_batched(items, trunc_params, compute_err, return_both_T):
+def decompose_theta_qr_based_batched(items, trunc_params, compute_err, return_both_T, use_eig_based_svd=False):
     """:func:`decompose_theta_qr_based` (block SVD of the bond matrix) for several INDEPENDENT two-site wave functions -- the bonds of one
     Trotter half-step -- with the two block QRs and the bond matrices of all of them in ONE batched device call each (``np_conserved.qr_batched``,
-    ``svd_theta_batched``); ``items`` = list of
+    ``svd_theta_batched``, or ``eigh_batched`` with ``use_eig_based_svd``); ``items`` = list of
     ``(old_qtotal_L, old_qtotal_R, old_bond_leg, theta, move_right, expand, min_block_increase)``.  Same results item by item."""
     prep = _decompose_qr_prepare_batched(items)
-    res = svd_theta_batched([p[2] for p in prep], trunc_params)
+    if use_eig_based_svd:            # only the factor on the side we move to comes out of the eigen-decompositions
+        move_right = items[0][4]
+        res = _eig_based_svd_batched([p[2] for p in prep], need_U=move_right, need_Vd=not move_right, inner_labels=['vR', 'vL'],
+                                     trunc_params=trunc_params)
+    else:
+        res = svd_theta_batched([p[2] for p in prep], trunc_params)
     return [_decompose_qr_finish(it[3], A_L, B_R, Xi, U, S, Vd, renorm, it[4], compute_err, return_both_T)
             for it, (A_L, B_R, Xi), (U, S, Vd, _, renorm) in zip(items, prep, res)]

@@ -563,3 +563,71 @@ def test_copy_scale_gather(env):
     _lib.check(lib.tpa_gather_axis_batch(0, gj.data_ptr(), 1, 72, _dev(torch, idx).data_ptr(), s_d.data_ptr(),
                                          out.data_ptr(), st))
     np.testing.assert_array_equal(out.cpu().numpy().reshape(6, 3, 4), src[:, idx, :])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cplx", [False, True])
+def test_eigh_direct_two_sided_iteration(env, cplx):
+    """Round 6: ``tpa_eigh_batch`` as a two-sided block Jacobi iteration on the Hermitian matrix itself (blocks of >= 96 rows; no Gram
+    GEMMs, accumulated transform + one Newton-Schulz step) against LAPACK and against the shift + one-sided route it replaces
+    (``tpa_eigh_set_direct(0)``): indefinite, flat positive definite (``Xi^dagger Xi`` of a TEBD bond matrix), graded rank-deficient
+    PSD (the mixer's density matrix) and +/- pairs, blocks of different sizes sharing the launches (incl. one below 96 rows)."""
+    torch, lib, _lib = env
+    g = torch.Generator(device="cpu").manual_seed(31)
+    dt = torch.complex128 if cplx else torch.float64
+    ns = [130, 300, 40, 257, 96]
+    mats = []
+    for k, n in enumerate(ns):
+        x = torch.randn(n, n, dtype=dt, generator=g)
+        if k == 0:
+            h = x + x.conj().T                                           # indefinite
+        elif k == 1:
+            h = x.conj().T @ x / n                                       # flat, positive definite
+        elif k == 2:
+            h = x + x.conj().T
+        elif k == 3:
+            y = x[:, :n // 2] * torch.logspace(0, -8, n // 2, dtype=torch.float64).to(dt)
+            h = y @ y.conj().T                                           # graded, rank n / 2
+        else:
+            q, _ = torch.linalg.qr(x)
+            lam = torch.cat([torch.linspace(1, 2, n // 2, dtype=torch.float64), -torch.linspace(1, 2, n - n // 2, dtype=torch.float64)])
+            h = (q * lam.to(dt)) @ q.conj().T                            # +/- lambda pairs
+        mats.append(0.5 * (h + h.conj().T))
+    jobs, a_off, w_off = [], 0, 0
+    for n in ns:
+        jobs.append([a_off, n, w_off, a_off, 0, 0, 0, 0])
+        a_off += n * n
+        w_off += n
+    A = torch.cat([x.reshape(-1) for x in mats]).cuda()
+    jh = np.array(jobs, np.int64)
+    wb = lib.tpa_eigh_worksize(int(cplx), jh.ctypes.data, len(jobs))
+    work = torch.empty(wb, dtype=torch.uint8).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    try:
+        for direct in (1, 0):
+            lib.tpa_eigh_set_direct(direct)
+            W = torch.zeros(w_off, dtype=torch.float64).cuda()
+            V = torch.zeros(a_off, dtype=dt).cuda()
+            sw = ctypes.c_int()
+            _lib.check(lib.tpa_eigh_batch(int(cplx), jh.ctypes.data, len(jobs), A.data_ptr(), W.data_ptr(), V.data_ptr(),
+                                          work.data_ptr(), wb, 60, 0.0, ctypes.byref(sw), st), "eigh")
+            torch.cuda.synchronize()
+            out[direct] = (W.cpu(), V.cpu(), sw.value)
+    finally:
+        lib.tpa_eigh_set_direct(1)
+    for direct in (1, 0):
+        W, V, sweeps = out[direct]
+        for b, n in enumerate(ns):
+            j = jobs[b]
+            w = W[j[2]:j[2] + n]
+            v = V[j[3]:j[3] + n * n].reshape(n, n)
+            ref = torch.linalg.eigvalsh(mats[b])
+            nrm = torch.linalg.norm(mats[b]).item()
+            assert torch.all(w[1:] >= w[:-1])                                                    # ascending, like LAPACK
+            assert (w - ref).abs().max().item() < 2e-14 * n * nrm, (direct, b)
+            assert (mats[b] @ v - v * w.to(dt)).abs().max().item() < 1e-13 * n * nrm, (direct, b)
+            assert (v.conj().T @ v - torch.eye(n, dtype=dt)).abs().max().item() < (1e-13 if direct else 1e-12), (direct, b)
+    # same eigenvalues by both routes
+    assert (out[1][0] - out[0][0]).abs().max().item() < 4e-14 * max(ns) * max(torch.linalg.norm(m).item() for m in mats)
+

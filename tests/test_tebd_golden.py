@@ -56,6 +56,31 @@ def test_qr_tebd_quench(backend, name, batch):
         np.testing.assert_allclose(psi.entanglement_entropy(), rec['S_qr'][step], rtol=0, atol=1e-9)
 
 
+def test_qr_tebd_eig_route_batched_equals_bond_by_bond(backend):
+    """``use_eig_based_svd``: the Hermitian eigenproblems of the bond matrices of a half-step in ONE ``eigh_batched`` call (the default)
+    give the state of the bond-by-bond loop -- same bond dimensions, Schmidt values and truncation error (reference
+    ``QRBasedTEBDEngine.update_bond`` with ``use_eig_based_svd``, tebd.py:685-738 / truncation.py:473-530)."""
+    from tenpy_amd.algorithms.tebd import QRBasedTEBDEngine
+    rec = [r for r in golden('tebd.pkl') if r['name'] == 'tfi_quench_L10_parity'][0]
+    L = rec['L']
+    _, p = spin_half_leg(rec['conserve'])
+    up = dict(rec['state_labels'])['up']
+    out = []
+    for batch in (True, False):
+        psi = MPS.from_product_state([p] * L, [up] * L, dtype=np.complex128)
+        eng = QRBasedTEBDEngine(psi, rec['h_bond'], {'dt': rec['dt'], 'cbe_expand': 0.5, 'batch_bonds': batch, 'use_eig_based_svd': True,
+                                                     'trunc_params': {'chi_max': rec['chi'], 'svd_min': 1.e-10}})
+        for step in range(len(rec['chi_qr'])):
+            eng.evolve_step_order2()
+        out.append((list(psi.chi), [np.asarray(psi.get_SL(i)) for i in range(1, L)], eng.trunc_err.eps, psi.entanglement_entropy()))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+    assert abs(out[0][2] - out[1][2]) <= 1e-14
+    # and against the reference's QR engine (SVD of the bond matrix): the eigenvalue route loses the tiny values, not the entropy
+    np.testing.assert_allclose(out[0][3], rec['S_qr'][len(rec['chi_qr']) - 1], rtol=0, atol=1e-7)
+
+
 def test_batch_group_size_respects_the_memory_cap(backend):
     """``batch_bonds=True`` batches a whole half-step only as far as the SVD work areas (~24x the dense theta per bond) fit the cap."""
     from tenpy_amd.algorithms.tebd import batch_group_size
