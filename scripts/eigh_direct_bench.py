@@ -42,6 +42,7 @@ a_dev = dev.to_device(flat)
 wb = L.tpa_eigh_worksize(code, jobs.ctypes.data, nb)
 work = torch.empty(int(wb), dtype=torch.uint8, device='cuda')
 wref = [np.linalg.eigvalsh(m) for m in mats[:2]]
+L.tpa_svd_set_algorithm(int(os.environ.get('ALG', '0')))
 for direct in (1, 0, 1):
     L.tpa_eigh_set_direct(direct)
     W = dev.empty(nb * n, np.float64)
