@@ -290,6 +290,14 @@ int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, const void *
                    double tol, int *sweeps_done, void *stream);
 /* Test hook: 0 = tpa_eigh_batch always takes the shift + one-sided route (rounds 1 - 5), 1 = default. */
 int tpa_eigh_set_direct(int on);
+/* Eigenpairs of Hermitian blocks out of their SVDs A_b = U_b S_b VH_b (tpa_svd_batch), WITH the check that this is legitimate: where |lambda|
+ * is not shared by a positive and a negative eigenvalue, v_i = d_i u_i (d_i = +/-1), lambda_i = d_i S_i and u_i is the eigenvector.
+ * np_conserved.eigh_batched takes this route for real data (the graded, rank-deficient density matrices of the mixer, mps_common.py:1972-2079:
+ * ~7 Jacobi sweeps on the rank-r factor instead of 35 - 40 on the matrix) and falls back to tpa_eigh_batch if err is not at rounding level.
+ * jobs : int64[n_jobs][8] = {u_off, n, s_off, vh_off, lam_off, 0,0,0} (HOST);  lam_dev[lam_off + i] = d_i S_i (order of S: descending |lambda|),
+ * err_dev[job] = max_i S_i |v_i - d_i u_i| = max_i |A u_i - lambda_i u_i|.  Asynchronous on `stream`. */
+int tpa_eigh_from_svd(int dtype, const int64_t *jobs_host, int n_jobs, const void *u_base, const double *s_dev,
+                      const void *vh_base, double *lam_dev, double *err_dev, void *stream);
 
 /* ---- host planner: integer bookkeeping of _tensordot_worker (_npc_helper.pyx:1498-1786) ---
  * Inputs describe operand a with its contracted legs LAST and b with its contracted legs FIRST

@@ -64,6 +64,7 @@ _SIGS = {
     "tpa_eigh_batch": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int64,
                                       ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int), _vp]),
     "tpa_eigh_set_direct": (ctypes.c_int, [ctypes.c_int]),
+    "tpa_eigh_from_svd": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tpa_plan_tensordot": (ctypes.c_int, [_vp, ctypes.c_int64, ctypes.c_int, _vp, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int64, _i64p, _vp,
                                           ctypes.c_int64, _i64p]),

@@ -4223,6 +4223,117 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
     return 0;
 }
 
+// ---- eigenpairs of a Hermitian block out of its SVD (np_conserved.eigh_batched, real data) ---------------------------------------
+// A = U S V^H with A Hermitian: wherever |lambda| is not degenerate between a positive and a negative eigenvalue, v_i = d_i u_i with
+// d_i = +/-1, lambda_i = d_i sigma_i and u_i is the eigenvector.  The SVD path (pivoted QR + one-sided Jacobi on the rank-r factor) needs
+// ~7 sweeps on the graded, rank-deficient density matrices of the mixer where the Jacobi iteration on the matrix itself needs 35 - 40
+// (clusters below the off-diagonal norm converge linearly).  This kernel CHECKS the premise instead of assuming it: per vector
+// d_i = sign(Re u_i . v_i) and err_i = sigma_i |v_i - d_i u_i| (the residual of u_i as an eigenvector, |A u_i - lambda_i u_i|);
+// lam <- d_i sigma_i, errmax[job] <- max_i err_i.  The caller accepts the result only if errmax is at rounding level and takes the
+// two-sided iteration otherwise (+/- pairs, a matrix that is not Hermitian in its upper triangle).
+namespace {
+struct EigFromSvdJob {  // int64[8]
+    int64_t u_off, n, s_off, vh_off, lam_off, pad0, pad1, pad2;
+};
+template <bool CPLX>
+__global__ __launch_bounds__(256) void eigh_from_svd_kernel(const EigFromSvdJob *__restrict__ jobs, const double *__restrict__ U,
+                                                            const double *__restrict__ S, const double *__restrict__ VH,
+                                                            double *__restrict__ lam, unsigned long long *__restrict__ errmax) {
+    constexpr int ES = CPLX ? 2 : 1;
+    __shared__ double tr[64][65], ti[CPLX ? 64 : 1][65];
+    __shared__ double red[4][64];
+    const EigFromSvdJob J = jobs[blockIdx.y];
+    const int64_t n = J.n;
+    const int i0 = blockIdx.x * 64;
+    if (i0 >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = i0 + lane;               // this thread's vector (column of U, row of VH)
+    const double *Ub = U + ES * J.u_off, *Vb = VH + ES * J.vh_off;
+    double sgn = 1.0;
+    double out = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double acc = 0.0;
+        for (int64_t k0 = 0; k0 < n; k0 += 64) {
+            __syncthreads();
+            // VH tile: rows i0 .. i0 + 63, columns k0 .. k0 + 63, read along k (coalesced); v_i[k] = conj(VH[i, k])
+            for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+                const int r = e >> 6, c = e & 63;
+                const bool ok = (i0 + r < n) && (k0 + c < n);
+                const int64_t g = (int64_t)(i0 + r) * n + k0 + c;
+                tr[r][c] = ok ? Vb[ES * g] : 0.0;
+                if (CPLX) ti[r][c] = ok ? -Vb[ES * g + 1] : 0.0;
+            }
+            __syncthreads();
+            if (i < n) {
+                for (int kk = wave * 16; kk < wave * 16 + 16; ++kk) {
+                    const int64_t k = k0 + kk;
+                    if (k >= n) break;
+                    const double ur = Ub[ES * (k * n + i)], ui = CPLX ? Ub[ES * (k * n + i) + 1] : 0.0;
+                    const double vr = tr[lane][kk], vi = CPLX ? ti[lane][kk] : 0.0;
+                    if (pass == 0)
+                        acc += ur * vr + ui * vi;                     // Re conj(u) . v
+                    else {
+                        const double dr = vr - sgn * ur, di = vi - sgn * ui;
+                        acc += dr * dr + di * di;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        red[wave][lane] = acc;
+        __syncthreads();
+        const double tot = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (pass == 0)
+            sgn = (tot < 0.0) ? -1.0 : 1.0;
+        else
+            out = tot;
+    }
+    double e = 0.0;
+    if (i < n && wave == 0) {
+        const double sg = S[J.s_off + i];
+        lam[J.lam_off + i] = sgn * sg;
+        e = sg * sqrt(out);
+        if (!(e == e)) e = 1.0e300;
+    }
+    if (wave == 0) {
+        e = wave_max(e);
+        if (lane == 0 && e > 0.0) atomicMax(errmax + blockIdx.y, (unsigned long long)__double_as_longlong(e));
+    }
+}
+}  // namespace
+
+/* Eigenvalues (with their signs) of Hermitian blocks from their SVDs + the check that the left singular vectors ARE the eigenvectors.
+ * jobs : int64[n_jobs][8] = {u_off, n, s_off, vh_off, lam_off, 0, 0, 0} (HOST); U_b n x n (vectors = columns), VH_b n x n (rows).
+ * lam_dev[lam_off + i] = d_i S_i, err_dev[job] = max_i S_i |v_i - d_i u_i| (double; zeroed here).  Asynchronous on `stream`. */
+extern "C" int tpa_eigh_from_svd(int dtype, const int64_t *jobs_host, int n_jobs, const void *u_base, const double *s_dev,
+                                 const void *vh_base, double *lam_dev, double *err_dev, void *stream) {
+    TPA_ARG_CHECK(dtype == TPA_F64 || dtype == TPA_C128);
+    if (n_jobs <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    pin_stage().reset();
+    EigFromSvdJob *stg = (EigFromSvdJob *)pin_stage().take((size_t)n_jobs * sizeof(EigFromSvdJob), st);
+    TPA_STAGE_CHECK(stg);
+    int64_t nmax = 0;
+    for (int b = 0; b < n_jobs; ++b) {
+        const int64_t *j = jobs_host + 8 * b;
+        TPA_ARG_CHECK(j[1] > 0);
+        stg[b] = EigFromSvdJob{j[0], j[1], j[2], j[3], j[4], 0, 0, 0};
+        nmax = std::max(nmax, j[1]);
+    }
+    EigFromSvdJob *jd = nullptr;
+    TPA_HIP_CHECK(hipMallocAsync((void **)&jd, (size_t)n_jobs * sizeof(EigFromSvdJob), st));
+    TPA_HIP_CHECK(hipMemcpyAsync(jd, stg, (size_t)n_jobs * sizeof(EigFromSvdJob), hipMemcpyHostToDevice, st));
+    TPA_HIP_CHECK(hipMemsetAsync(err_dev, 0, (size_t)n_jobs * 8, st));
+    const dim3 grid((unsigned)((nmax + 63) / 64), (unsigned)n_jobs);
+    if (dtype == TPA_F64)
+        eigh_from_svd_kernel<false><<<grid, 256, 0, st>>>(jd, (const double *)u_base, s_dev, (const double *)vh_base, lam_dev, (unsigned long long *)err_dev);
+    else
+        eigh_from_svd_kernel<true><<<grid, 256, 0, st>>>(jd, (const double *)u_base, s_dev, (const double *)vh_base, lam_dev, (unsigned long long *)err_dev);
+    TPA_LAUNCH_CHECK();
+    TPA_HIP_CHECK(hipFreeAsync(jd, st));
+    return 0;
+}
+
 /* Test hook: 0 = tpa_eigh_batch takes the shift + one-sided SVD route of rounds 1 - 5, 1 (default) = the direct two-sided iteration. */
 extern "C" int tpa_eigh_set_direct(int on) {
     tpa_eigh_direct = on ? 1 : 0;

@@ -3659,6 +3659,70 @@ def eigvalsh(a, UPLO='L', sort=None):
     return eigh(a, UPLO, sort)[0]
 
 
+# Real Hermitian blocks: eigenpairs out of the block SVD (pivoted QR + one-sided Jacobi on the rank-r factor), CHECKED on the device
+# (`tpa_eigh_from_svd`: |A u_i - lambda_i u_i| per vector); the two-sided Jacobi iteration of `tpa_eigh_batch` takes over if the check fails
+# (+/- lambda pairs, input that is not Hermitian in its upper triangle -- the reference reads the lower one only).  Why: the density matrices of
+# the mixer (`mix_rho`, mps_common.py:1972-2079) are graded over 14+ decades and rank deficient; Jacobi on the matrix itself converges
+# linearly on such clusters (34 - 39 sweeps at 1086 rows), the SVD path needs ~7 on half the rows.  Complex data (the flat-spectrum bond
+# matrices of the TEBD eig route) keeps the two-sided iteration: no QR, no Gram products, 15 sweeps against 12 + QR.
+EIGH_VIA_SVD = os.environ.get('TPA_EIGH_VIA_SVD', '1') != '0'
+EIGH_VIA_SVD_MIN_ROWS = 96
+EIGH_VIA_SVD_TOL = 2.e-12      # x sqrt(n) |A_b|_2: the GATE on max_i |A u_i - lambda_i u_i| (measured: a few eps sqrt(n) |A_b| on accepted blocks; O(|A_b|) on +/- pairs)
+eigh_stats = {'svd_calls': 0, 'svd_rejected': 0, 'jacobi_calls': 0, 'last_err_rel': 0.}
+
+
+def _eigh_via_svd(L, code, dtype, jobs, a_arena, W_dev, V_big):
+    """Eigenvalues (host, per block in the order of the singular values) with the eigenvectors written to the blocks of ``V_big``, or
+    ``None`` if the SVD of some block is not an eigendecomposition to rounding level (nothing is lost: the caller runs ``tpa_eigh_batch``)."""
+    nblk = len(jobs)
+    ns = jobs[:, 1]
+    vh_offs = np.concatenate([[0], np.cumsum(ns * ns)])
+    sj = np.zeros((nblk, 8), dtype=np.int64)
+    sj[:, 0], sj[:, 1], sj[:, 2] = jobs[:, 0], ns, ns
+    sj[:, 3], sj[:, 4], sj[:, 5] = jobs[:, 3], jobs[:, 2], vh_offs[:-1]      # U -> the blocks of V_big, S -> W_dev
+    VH = dev.scratch('eigh_vh', int(vh_offs[-1]), dtype)
+    S_dev = dev.scratch('eigh_s', int(W_dev.numel()), np.float64)
+    sweeps = dev.c_int()
+    floor_was = _svd_floor_now[0]
+    _svd_floor_now[0] = SVD_ABS_FLOOR_GENERIC          # every vector converged by the relative rule (this is a library call, not an engine's svd_theta)
+    try:
+        S_host = _svd_batch_robust(L, code, sj, nblk, a_arena, V_big, S_dev, VH, sweeps)
+    except (np.linalg.LinAlgError, ValueError):
+        return None
+    finally:
+        _svd_floor_now[0] = floor_was
+    ej = np.zeros((nblk, 8), dtype=np.int64)
+    ej[:, 0], ej[:, 1], ej[:, 2], ej[:, 3], ej[:, 4] = jobs[:, 3], ns, jobs[:, 2], vh_offs[:-1], jobs[:, 2]
+    err_dev = dev.empty(nblk, np.float64)
+    dev.check(L.tpa_eigh_from_svd(code, ej.ctypes.data, nblk, V_big.data_ptr(), S_dev.data_ptr(), VH.data_ptr(), W_dev.data_ptr(),
+                                  err_dev.data_ptr(), dev.stream()), "eigh_from_svd")
+    lam = dev.to_host(W_dev)
+    err = dev.to_host(err_dev)
+    smax = np.array([S_host[o] if n else 0. for o, n in zip(jobs[:, 2], ns)])      # (descending inside a block)
+    tol = EIGH_VIA_SVD_TOL * np.sqrt(ns) * smax
+    eigh_stats['last_err_rel'] = float(np.max(err / np.maximum(smax, 1e-300)))
+    if not np.all(np.isfinite(err)) or np.any(err > tol):
+        eigh_stats['svd_rejected'] += 1
+        return None
+    # Blocks of numerical rank r < n: the block SVD returns r vectors (the pivoted QR stops at the rank; S, U, VH are zero-padded behind
+    # it).  The eigenvectors of the null space = ANY orthonormal completion: Householder QR of the zero-padded n x n block of U gives a
+    # full orthogonal Q whose first r columns are +/- the r vectors (they are orthonormal: R is diagonal there), the others the complement.
+    ranks = np.array([int(np.count_nonzero(S_host[o:o + n])) for o, n in zip(jobs[:, 2], ns)], dtype=np.int64)
+    sel = np.nonzero(ranks < ns)[0]
+    if len(sel):
+        n_s, r_s = ns[sel], ranks[sel]
+        q_offs = np.concatenate([[0], np.cumsum(n_s * n_s)])
+        qj = np.zeros((len(sel), 8), dtype=np.int64)
+        qj[:, 0], qj[:, 1], qj[:, 2], qj[:, 3], qj[:, 4] = jobs[sel, 3], n_s, n_s, q_offs[:-1], q_offs[:-1]
+        Q_tmp = dev.scratch('eigh_q', int(q_offs[-1]), dtype)
+        R_tmp = dev.scratch('eigh_r', int(q_offs[-1]), dtype)
+        dev.check(L.tpa_qr_batch(code, qj.ctypes.data, len(sel), V_big.data_ptr(), Q_tmp.data_ptr(), R_tmp.data_ptr(), dev.stream()), "qr_batch")
+        cj = _copy_jobs_2d(jobs[sel, 3] + r_s, n_s, q_offs[:-1] + r_s, n_s, n_s, n_s - r_s)
+        _run_copy(dtype, cj, int(np.max(n_s * (n_s - r_s))), Q_tmp, V_big)
+    eigh_stats['svd_calls'] += 1
+    return lam
+
+
 def eigh(a, UPLO='L', sort=None):
     """Block-wise Hermitian eigendecomposition (reference np_conserved.py:3899, worker :5041).
 
@@ -3723,14 +3787,19 @@ def eigh_batched(arrays, UPLO='L', sort=None):
         L = dev.lib()
         code = dev.code(dtype)
         W_dev = dev.empty(w_base, np.float64)
-        wb = L.tpa_eigh_worksize(code, jobs.ctypes.data, nblk)
-        work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
-        sweeps = dev.c_int()
         ev = eigh_timer.begin()
-        dev.check(L.tpa_eigh_batch(code, jobs.ctypes.data, nblk, big.data_ptr(), W_dev.data_ptr(), V_big.data_ptr(),
-                                   work.data_ptr(), int(wb), 60, 0.0, dev.byref(sweeps), dev.stream()), "eigh_batch")
+        W_host = None
+        if EIGH_VIA_SVD and np.dtype(dtype).kind != 'c' and int(np.max(jobs[:, 1])) >= EIGH_VIA_SVD_MIN_ROWS:
+            W_host = _eigh_via_svd(L, code, dtype, jobs, big, W_dev, V_big)
+        if W_host is None:
+            wb = L.tpa_eigh_worksize(code, jobs.ctypes.data, nblk)
+            work = dev.torch().empty(int(wb), dtype=dev.torch().uint8, device='cuda')
+            sweeps = dev.c_int()
+            dev.check(L.tpa_eigh_batch(code, jobs.ctypes.data, nblk, big.data_ptr(), W_dev.data_ptr(), V_big.data_ptr(),
+                                       work.data_ptr(), int(wb), 60, 0.0, dev.byref(sweeps), dev.stream()), "eigh_batch")
+            W_host = dev.to_host(W_dev)
+            eigh_stats['jacobi_calls'] += 1
         eigh_timer.end(ev, eigh_work(jobs[:, 1], np.dtype(dtype).itemsize, np.dtype(dtype).kind == 'c'))
-        W_host = dev.to_host(W_dev)
     out = []
     for pr in preps:
         ab, leg, v_offs = pr['a'], pr['leg'], pr['v_offs']
@@ -3748,7 +3817,8 @@ def eigh_batched(arrays, UPLO='L', sort=None):
             for b in range(len(pr['ms'])):
                 qi = ab._qdata[b, 0]
                 w = W_host[pr['w_base'] + w_offs[b]:pr['w_base'] + w_offs[b + 1]]
-                if sort is not None and sort != '<':
+                # (tpa_eigh_batch returns ascending values; the SVD route returns them by descending magnitude)
+                if (sort is not None and sort != '<') or (len(w) > 1 and np.any(w[1:] < w[:-1])):
                     pb = _argsort(w, sort)
                     w = w[pb]
                     sl = leg.get_slice(qi)

@@ -403,6 +403,23 @@ class MockLib:
     def tpa_eigh_worksize(self, code, jobs_p, n):
         return 256
 
+    def tpa_eigh_set_direct(self, on):
+        return 0
+
+    def tpa_eigh_from_svd(self, code, jobs_p, n_jobs, u_p, s_p, vh_p, lam_p, err_p, stream):
+        dt = _npdt(code)
+        jobs = _host(jobs_p, (n_jobs, 8))
+        U, VH = REG.view(u_p, dt), REG.view(vh_p, dt)
+        S, lam, err = REG.view(s_p, np.float64), REG.view(lam_p, np.float64), REG.view(err_p, np.float64)
+        for b, (u_off, n, s_off, vh_off, lam_off, _, _, _) in enumerate(jobs):
+            u = U[u_off:u_off + n * n].reshape(n, n)
+            v = VH[vh_off:vh_off + n * n].reshape(n, n).conj().T
+            sg = S[s_off:s_off + n].copy()
+            d = np.where(np.real(np.sum(u.conj() * v, axis=0)) < 0, -1., 1.)
+            lam[lam_off:lam_off + n] = d * sg
+            err[b] = np.max(sg * np.linalg.norm(v - u * d[None, :], axis=0)) if n else 0.
+        return 0
+
     def tpa_eigh_batch(self, code, jobs_p, n_jobs, a_p, w_p, v_p, work_p, wb, max_sweeps, tol, sweeps_p, stream):
         dt = _npdt(code)
         jobs = _host(jobs_p, (n_jobs, 8))
