@@ -3667,7 +3667,7 @@ def eigvalsh(a, UPLO='L', sort=None):
 # matrices of the TEBD eig route) keeps the two-sided iteration: no QR, no Gram products, 15 sweeps against 12 + QR.
 EIGH_VIA_SVD = os.environ.get('TPA_EIGH_VIA_SVD', '1') != '0'
 EIGH_VIA_SVD_MIN_ROWS = 96
-EIGH_VIA_SVD_TOL = 2.e-12      # x sqrt(n) |A_b|_2: the GATE on max_i |A u_i - lambda_i u_i| (measured: a few eps sqrt(n) |A_b| on accepted blocks; O(|A_b|) on +/- pairs)
+EIGH_VIA_SVD_TOL = 5.e-13      # x sqrt(n) |A_b|_2: the GATE on max_i |A u_i - lambda_i u_i| (measured: a few eps sqrt(n) |A_b| on accepted blocks; O(|A_b|) on +/- pairs)
 eigh_stats = {'svd_calls': 0, 'svd_rejected': 0, 'jacobi_calls': 0, 'last_err_rel': 0.}
 
 
