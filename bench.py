@@ -728,8 +728,10 @@ def compact(out):
                 c["other_configs"][name] = {"error": str(o["error"])[:80]}
                 continue
             e = {"value": o.get("value")}
+            if o.get("value_sweeps_3_4_at_target_chi") is not None:
+                e["value_2p2"] = o["value_sweeps_3_4_at_target_chi"]
             for rk, ek in (("roofline", "frac"), ("roofline_gemm", "gemm_frac"), ("roofline_svd", "svd_frac")):
-                if isinstance(o.get(rk), dict):
+                if isinstance(o.get(rk), dict) and o[rk].get("frac"):
                     e[ek] = o[rk].get("frac")
             if isinstance(o.get("roofline"), dict):
                 e["ms_per_call"] = o["roofline"].get("avg_launch_ms")
@@ -752,7 +754,7 @@ def compact(out):
     for k in ("extras_s", "extras_error"):
         if k in out:
             c[k] = out[k] if k == "extras_s" else str(out[k])[:120]
-    c["detail"] = "earlier stdout lines {\"bench_detail\": ...}; builder copy under profiles/"
+    c["detail"] = "bench_detail lines above; copy under profiles/"
     c = _r(c)
     for k in ("E",):                        # energies keep every digit (the parity claim is 1e-10 relative)
         if k in out:
@@ -885,7 +887,7 @@ def extras(out, eng, args):
         out["roofline_vec"] = vector_roofline(sum(int(b.size) for b in eng.psi.get_theta(eng.psi.L // 2 - 1, n=2)._data))
     except Exception as e:
         out["roofline_vec"] = {"error": repr(e)}
-    # ---- the other BASELINE configurations, in this process (no second import of torch), one warm-up step + two timed steps each
+    # ---- the other BASELINE configurations, in this process (no second import of torch)
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_gemm", "energy_err",
             "energy_err_note", "sv_max_rel_err", "sv_max_rel_err_individual", "svd_isometry_defect", "matvec_max_rel_err", "E0_rel_err",
             "tebd_parity", "tebd_route", "cpu_baseline", "prep_s", "svd_stats", "roofline_eigh", "roofline_svd")
@@ -896,8 +898,14 @@ def extras(out, eng, args):
         t0 = time.time()
         try:
             is_t = name.startswith("tebd")
-            r = run(argv + ["--steps", "2", "--warmup", "1" if is_t else "2", "--no-extras", "--cpu-sample-bonds", "1"], emit=False)
+            # DMRG configurations: the headline's protocol (5 warm-up sweeps at the target chi, then the timed ones); the figure of the
+            # 2 + 2 sweep legs of rounds 4 - 6 (sweeps 3 and 4 at the target chi: still a third cold SVD calls) is kept beside it
+            r = run(argv + (["--steps", "2", "--warmup", "1"] if is_t else ["--steps", "3", "--warmup", "5"]) + ["--no-extras", "--cpu-sample-bonds", "1"], emit=False)
             o = {k: r[k] for k in keep if k in r}
+            if not is_t:
+                tgt = [e["s"] for e in r.get("untimed_sweeps", []) if str(e.get("kind", "")).startswith("warm-up at the target chi")]
+                if len(tgt) >= 4:
+                    o["value_sweeps_3_4_at_target_chi"] = float(np.mean(tgt[2:4]))
             if "svd_stats" in o:
                 o["svd_stats"] = {k: v for k, v in o["svd_stats"].items() if k in ("calls_timed", "jacobi_sweeps_per_call", "max_block")}
             if "cpu_baseline" in o and isinstance(o["cpu_baseline"], dict):
