@@ -629,3 +629,58 @@ def test_eigh_direct_two_sided_iteration(env, cplx):
     # same eigenvalues by both routes
     assert (out[1][0] - out[0][0]).abs().max().item() < 4e-14 * max(ns) * max(torch.linalg.norm(m).item() for m in mats)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cplx", [False, True])
+def test_eigh_from_svd_kernel(env, cplx):
+    """``tpa_eigh_from_svd`` against its definition: from LAPACK's SVD ``A = U S VH`` of Hermitian blocks, ``lam_i = d_i S_i`` with
+    ``d_i = sign(Re u_i^H v_i)`` and ``err = max_i S_i |v_i - d_i u_i|`` -- at rounding level for an indefinite block with distinct
+    |lambda|, O(|A|) for a block with +/- lambda pairs (whose singular subspaces mix), both dtypes, sizes off the 64-column tiles."""
+    torch, lib, _lib = env
+    rng = np.random.default_rng(3)
+    dt = np.complex128 if cplx else np.float64
+    ns = [70, 129, 64]
+    mats = []
+    for k, n in enumerate(ns):
+        x = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+        q, _ = np.linalg.qr(x)
+        if k == 1:      # +/- pairs
+            lam = np.concatenate([np.linspace(1, 2, n // 2), -np.linspace(1, 2, n - n // 2)])
+        else:
+            lam = np.linspace(-1, 2, n) + 0.01
+        h = (q * lam) @ q.conj().T
+        mats.append(0.5 * (h + h.conj().T))
+    U, S, VH, jobs = [], [], [], []
+    uo = so = 0
+    for n, h in zip(ns, mats):
+        u, sg, vh = np.linalg.svd(h)
+        U.append(u.reshape(-1)), S.append(sg), VH.append(vh.reshape(-1))
+        jobs.append([uo, n, so, uo, so, 0, 0, 0])
+        uo += n * n
+        so += n
+    Ud = torch.from_numpy(np.concatenate(U).astype(dt)).cuda()
+    Sd = torch.from_numpy(np.concatenate(S)).cuda()
+    Vd = torch.from_numpy(np.concatenate(VH).astype(dt)).cuda()
+    lam_d = torch.zeros(so, dtype=torch.float64).cuda()
+    err_d = torch.zeros(len(ns), dtype=torch.float64).cuda()
+    jh = np.array(jobs, np.int64)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tpa_eigh_from_svd(int(cplx), jh.ctypes.data, len(ns), Ud.data_ptr(), Sd.data_ptr(), Vd.data_ptr(), lam_d.data_ptr(),
+                                     err_d.data_ptr(), st), "eigh_from_svd")
+    torch.cuda.synchronize()
+    lam_h, err_h = lam_d.cpu().numpy(), err_d.cpu().numpy()
+    o = 0
+    for b, (n, h) in enumerate(zip(ns, mats)):
+        u, sg, vh = np.linalg.svd(h)
+        v = vh.conj().T
+        d = np.where(np.real(np.sum(u.conj() * v, axis=0)) < 0, -1., 1.)
+        ref_err = np.max(sg * np.linalg.norm(v - u * d[None, :], axis=0))
+        np.testing.assert_allclose(lam_h[o:o + n], d * sg, rtol=0, atol=1e-14)
+        assert abs(err_h[b] - ref_err) <= 1e-13 + 1e-10 * ref_err
+        if b == 1:
+            assert err_h[b] > 1e-3                    # +/- pairs: the left singular vectors are NOT eigenvectors
+        else:
+            assert err_h[b] < 1e-12
+            np.testing.assert_allclose(np.sort(lam_h[o:o + n]), np.linalg.eigvalsh(h), rtol=0, atol=1e-13)
+        o += n
+
