@@ -19,7 +19,10 @@
 #include <ctime>
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <numeric>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -2793,7 +2796,7 @@ struct Layout {
 
 inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
-Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
+Layout build_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     Layout lay;
     const int64_t esz = (dtype == TPA_C128) ? 16 : 8;
     for (int b = 0; b < n_jobs; ++b) {
@@ -2978,6 +2981,60 @@ Layout make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     }
     lay.total = o;
     return lay;
+}
+
+// The layout of a call depends on (dtype, job table) alone -- not on the algorithm switches, see above -- and building it costs 30 - 70 us of
+// host time (one table entry per row, row pair, 8- and 32-row block pair, Gram / apply GEMM tile) with the device idle: every npc.svd of a
+// steady-state sweep built the layouts of the SAME ~200 job tables again, twice (tpa_svd_worksize, then tpa_svd_batch).  Memoised per host
+// thread, least recently used entry out first (profiles/r06_idle_gap_analysis.txt: 190 us between the end of the Lanczos run and the
+// first upload of the SVD section).
+template <class T>
+struct LayoutCache {
+    struct Ent {
+        std::shared_ptr<const T> lay;
+        uint64_t stamp;
+    };
+    std::unordered_map<std::string, Ent> map;
+    uint64_t clock = 0;
+    static constexpr size_t CAP = 1024;      // x 0.1 - 0.5 MB per layout of a chi = 2048 call
+    template <class F>
+    std::shared_ptr<const T> get(int dtype, const int64_t *jobs_host, int n_jobs, F build) {
+        std::string key((size_t)n_jobs * 64 + 1, '\0');
+        key[0] = (char)dtype;
+        std::memcpy(&key[1], jobs_host, (size_t)n_jobs * 64);
+        auto it = map.find(key);
+        if (it != map.end()) {
+            it->second.stamp = ++clock;
+            return it->second.lay;
+        }
+        if (map.size() >= CAP) {      // evict the older half (rare: a sweep touches ~200 - 400 job tables)
+            std::vector<uint64_t> stamps;
+            stamps.reserve(map.size());
+            for (auto &kv : map) stamps.push_back(kv.second.stamp);
+            std::nth_element(stamps.begin(), stamps.begin() + stamps.size() / 2, stamps.end());
+            const uint64_t cut = stamps[stamps.size() / 2];
+            for (auto q = map.begin(); q != map.end();) q = (q->second.stamp < cut) ? map.erase(q) : std::next(q);
+        }
+        std::shared_ptr<const T> lay = std::make_shared<const T>(build());
+        map.emplace(std::move(key), Ent{lay, ++clock});
+        return lay;
+    }
+};
+static int tpa_layout_cache_on = getenv("TPA_SVD_LAYOUT_CACHE") ? atoi(getenv("TPA_SVD_LAYOUT_CACHE")) : 1;      // test hook: 0 = rebuild every time
+
+std::shared_ptr<const Layout> make_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
+    auto build = [&]() {
+        Layout l = build_layout(dtype, jobs_host, n_jobs);
+        if (tpa_layout_cache_on) {      // the entry stays: give the growth slack of the push_backs back
+            l.rows.shrink_to_fit(), l.pairs.shrink_to_fit(), l.bentries.shrink_to_fit(), l.wpairs.shrink_to_fit();
+            l.b32_entries.shrink_to_fit(), l.b32_pairs.shrink_to_fit(), l.b32_gup.shrink_to_fit(), l.b32_act.shrink_to_fit();
+            l.ref.tasks.shrink_to_fit(), l.ref.links.shrink_to_fit(), l.ref.tiles.shrink_to_fit(), l.ref.rtiles.shrink_to_fit();
+        }
+        return l;
+    };
+    if (!tpa_layout_cache_on) return std::make_shared<const Layout>(build());
+    static thread_local LayoutCache<Layout> cache;
+    return cache.get(dtype, jobs_host, n_jobs, build);
 }
 
 // number of svd_round_fused_kernel workgroups that are guaranteed to be resident together (occupancy query x CUs)
@@ -3523,7 +3580,7 @@ struct QrpLayout {
             total = 0;
 };
 
-QrpLayout make_qrp_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
+QrpLayout build_qrp_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     QrpLayout q;
     const int64_t esz = (dtype == TPA_C128) ? 16 : 8;
     for (int b = 0; b < n_jobs; ++b) {
@@ -3570,9 +3627,15 @@ QrpLayout make_qrp_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     q.off_tfac = take(q.tf_blocks * QNB * QNB * esz);
     q.off_tpan = take((int64_t)n_jobs * PNB * PNB * esz);
     q.off_nested = o;
-    o += make_layout(dtype, q.nested_max.data(), n_jobs).total;
+    o += build_layout(dtype, q.nested_max.data(), n_jobs).total;      // (its size only: not worth a slot of the cache)
     q.total = o;
     return q;
+}
+std::shared_ptr<const QrpLayout> make_qrp_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
+    auto build = [&]() { return build_qrp_layout(dtype, jobs_host, n_jobs); };
+    if (!tpa_layout_cache_on) return std::make_shared<const QrpLayout>(build());
+    static thread_local LayoutCache<QrpLayout> cache;
+    return cache.get(dtype, jobs_host, n_jobs, build);
 }
 
 constexpr int64_t QRP_MIN_DIM = 32;        // below this the plain Jacobi path is launch-cheaper
@@ -3751,7 +3814,9 @@ int svd_run_qrp(const Layout &lay, const QrpLayout &q, int n_jobs, const void *a
     int rc = 0;
     if (sweeps_done) *sweeps_done = 0;
     if (nn > 0) {
-        Layout nlay = make_layout(dtype, nested.data(), nn);
+        // (the nested job table depends on the numerical ranks of THIS call: not memoised)
+        const std::shared_ptr<const Layout> nlay_p = std::make_shared<const Layout>(build_layout(dtype, nested.data(), nn));
+        const Layout &nlay = *nlay_p;
         if (nlay.total > q.total - q.off_nested) {
             snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: internal work size mismatch");
             return TPA_E_BADARG;
@@ -3949,8 +4014,8 @@ int tpa_qr_wy_internal(int dtype, const int64_t *jobs_host, int n_jobs, const vo
 
 extern "C" int64_t tpa_svd_worksize(int dtype, const int64_t *jobs_host, int n_jobs) {
     if (n_jobs <= 0) return 256;
-    int64_t total = make_layout(dtype, jobs_host, n_jobs).total;
-    total = std::max(total, make_qrp_layout(dtype, jobs_host, n_jobs).total);
+    int64_t total = make_layout(dtype, jobs_host, n_jobs)->total;
+    total = std::max(total, make_qrp_layout(dtype, jobs_host, n_jobs)->total);
     return total;
 }
 
@@ -4015,7 +4080,8 @@ static int tpa_svd_batch_impl(int dtype, const int64_t *jobs_host, int n_jobs, c
     // tol < 0: floor |tol| on the SMALLER row of a pair (svd_needs_rotation; the caller post-processes with the ordered clean-up): the
     // sign goes down to the kernels with the value (svd_floor2)
     pin_stage().reset();      // the previous call on this thread ended with a stream synchronisation
-    Layout lay = make_layout(dtype, jobs_host, n_jobs);
+    const std::shared_ptr<const Layout> lay_p = make_layout(dtype, jobs_host, n_jobs);
+    const Layout &lay = *lay_p;
     TPA_ARG_CHECK(work_bytes >= lay.total);
     hipStream_t st = (hipStream_t)stream;
     int64_t dim_max = 0;
@@ -4023,7 +4089,8 @@ static int tpa_svd_batch_impl(int dtype, const int64_t *jobs_host, int n_jobs, c
     // complex: the panel lives in registers as (re, im) pairs -> max(m, n) <= 2048
     if (tpa_svd_use_qrp && !tpa_svd_force_pairwise && lay.rmax_pad >= QRP_MIN_DIM &&
         dim_max <= ((dtype == TPA_F64) ? (int64_t)NTP_MAX * RPT_MAX : (int64_t)2048)) {
-        QrpLayout q = make_qrp_layout(dtype, jobs_host, n_jobs);
+        const std::shared_ptr<const QrpLayout> q_p = make_qrp_layout(dtype, jobs_host, n_jobs);
+        const QrpLayout &q = *q_p;
         TPA_ARG_CHECK(work_bytes >= q.total);
         *used_qrp = 1;
         if (dtype == TPA_F64)
@@ -4160,7 +4227,7 @@ EighLayout make_eigh_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     lay.off_jobs = o;
     o = align_up(o + (int64_t)n_jobs * sizeof(EighJob), 256);
     lay.off_svd = o;
-    o += make_layout(dtype, lay.svd_jobs.data(), n_jobs).total;
+    o += make_layout(dtype, lay.svd_jobs.data(), n_jobs)->total;
     lay.total = o;
     return lay;
 }
@@ -4188,7 +4255,8 @@ extern "C" int tpa_eigh_batch(int dtype, const int64_t *jobs_host, int n_jobs, c
     double *mu = (double *)(work + lay.off_mu);
     double *fpart = (double *)(work + lay.off_fpart);
     TPA_HIP_CHECK(hipMemcpyAsync(jobs, lay.jobs.data(), lay.jobs.size() * sizeof(EighJob), hipMemcpyHostToDevice, st));
-    Layout slay = make_layout(dtype, lay.svd_jobs.data(), n_jobs);
+    const std::shared_ptr<const Layout> slay_p = make_layout(dtype, lay.svd_jobs.data(), n_jobs);
+    const Layout &slay = *slay_p;
     int rc;
     int direct_req = tpa_eigh_direct;
     if (const char *e = getenv("TPA_EIGH_DIRECT")) direct_req = atoi(e) != 0;
