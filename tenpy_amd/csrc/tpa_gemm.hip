@@ -23,6 +23,30 @@ struct Task {  // int64[8]
     int64_t c_off, m, n, ldc, link_begin, link_count, accumulate, pad;
 };
 
+// IDENTITY-ROW SKIP (round 6; used by the block SVD's product [W | G] <- Qtot [W | G], tpa_svd.hip: svd_run): a tile with tile.w > 0 of a
+// task with pad != 0 looks at the word ((const int *)pad)[tile.w - 1]; 0 means "the rows of A that this tile of C needs are unit vectors
+// e_row" (those rows of Qtot did not rotate in the sweep), so C[row, :] = B[row, :] and the tile is a COPY of the first link's B operand
+// instead of a chain of K / 16 k-tiles.  Every other caller leaves tile.w = 0 and pad = 0.  Returns true if the tile was handled.
+template <int ES, int NT, int BM, int BN>
+__device__ __forceinline__ bool gemm_identity_rows_tile(const Task &tk, const Link *__restrict__ links, const int4 tile, const double *__restrict__ Bbase,
+                                                        double *__restrict__ Cbase, const int tid) {
+    if (tile.w <= 0 || tk.pad == 0) return false;
+    if (reinterpret_cast<const int *>(tk.pad)[tile.w - 1] != 0) return false;
+    const Link L = links[tk.link_begin];
+    const int row0 = tile.y * BM, col0 = tile.z * BN;
+    const int rows = min(BM, (int)tk.m - row0), cols = min(BN, (int)tk.n - col0);
+    for (int e = tid; e < rows * BN; e += NT) {
+        const int r = e / BN, c = e % BN;
+        if (c < cols) {
+            const int64_t src = L.b_off + (int64_t)(row0 + r) * L.b_ks + (int64_t)(col0 + c) * L.b_ns;
+            const int64_t dst = tk.c_off + (int64_t)(row0 + r) * tk.ldc + col0 + c;
+#pragma unroll
+            for (int q = 0; q < ES; ++q) Cbase[ES * dst + q] = Bbase[ES * src + q];
+        }
+    }
+    return true;
+}
+
 template <bool CPLX, int BM, int BN, int TM, int TN, int BK_>
 struct Cfg {
     static constexpr int BK = BK_;
@@ -67,6 +91,7 @@ __global__ __launch_bounds__((Cfg<CPLX, BM, BN, TM, TN, BK_>::NT)) void gemm_cha
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / C::WN, wc = wave % C::WN;
     const int l15 = lane & 15, l4 = lane >> 4;
+    if (gemm_identity_rows_tile<ES, NT, BM, BN>(tk, links, tile, Bbase, Cbase, tid)) return;      // (workgroup-uniform)
 
     d4 acc[PL][TM][TN];
 #pragma unroll
@@ -305,6 +330,7 @@ void gemm_chain2_kernel(
     const int l15 = lane & 15, l4 = lane >> 4;
     // a wavefront whose sub-tile lies wholly outside the block stages its share of the operands and skips the arithmetic
     const bool wave_act = (row0 + wr * TM * 16 < m) && (col0 + wc * TN * 16 < n);
+    if (gemm_identity_rows_tile<1, NT, BM, BN>(tk, links, tile, Bbase, Cbase, tid)) return;      // (workgroup-uniform)
 
     d4 acc[TM][TN];
 #pragma unroll

@@ -2679,6 +2679,7 @@ static thread_local int tpa_svd_direct_used = 0;   // answer: the call ran the d
 int tpa_eigh_direct = 1;                           // test hook (TPA_EIGH_DIRECT=0 / tpa_eigh_set_direct): the shift + one-sided SVD route of rounds 1 - 5
 int tpa_svd_dyn_round0 = 1;      // the first round of a sweep adapts to the activity of its pairs (bit 25 of tpa_svd_set_algorithm: off)
 int tpa_svd_dyn = 1;             // 0 (TPA_SVD_DYN=0 / bit 24 of tpa_svd_set_algorithm): the full round-robin schedule in every sweep (rounds 3 - 5)
+int tpa_svd_apply_skip = getenv("TPA_SVD_APPLY_SKIP") ? atoi(getenv("TPA_SVD_APPLY_SKIP")) : 1;      // activity-driven sweeps: tiles of Qtot [W | G] whose rows did not rotate are copied (tpa_gemm.hip: identity-row skip)
 int64_t tpa_svd_dyn_rounds = 0, tpa_svd_dyn_rounds_static = 0, tpa_svd_dyn_sweeps = 0;      // statistics (tpa_svd_dyn_stats)
 
 inline void b32_host_pair_of(int R, int pair, int round, int &bi, int &bj) {      // = b32_pair_of_R on the device
@@ -2782,6 +2783,7 @@ struct Layout {
     std::vector<B32Act> b32_act;         // round 6: block pairs (bi <= bj) whose activity the exact Gram matrix of a sweep start decides
     std::vector<int> b32_act_off;        // per job: offset of its NBp x NBp activity words
     int64_t n_act = 0, off_act_ents = 0, off_act = 0, off_sched = 0;
+    int64_t n_rot = 0, off_rot = 0;      // words "this 64-row tile rotated in the sweep" (b32_rot_word): real data, activity-driven rounds
     RefTables ref;                 // GEMM tables of the Gram-only sweeps (empty unless the largest block has >= REF_MIN_R rows)
     int64_t off_rtasks = 0, off_rlinks = 0, off_rtiles = 0, off_rrt = 0;                // ... inside the uploaded table range
     int64_t off_w2 = 0, off_rp = 0, off_rq = 0, off_rm = 0;           // second [W | G] image, split-K partials, Qtot, S
@@ -2964,6 +2966,9 @@ Layout build_layout(int dtype, const int64_t *jobs_host, int n_jobs) {
     lay.off_b32q = o;            // two images of 64 x 64 transforms per pair
     o = align_up(o + ((dtype == TPA_C128) ? 4 : 2) * (int64_t)lay.b32_pairs.size() * TB * TB * 8, 256);
     if (lay.ref.enabled && !lay.b32_act.empty()) {
+        for (const SvdJob &J : lay.jobs) lay.n_rot = std::max<int64_t>(lay.n_rot, J.g_off / ROT_GRAIN + (J.R + 63) / 64 + 1);
+        lay.off_rot = o;
+        o = align_up(o + lay.n_rot * 4, 256);
         lay.off_act = o;
         o = align_up(o + lay.n_act * 4, 256);
         lay.off_sched = o;               // (nb32_max_pad + 2) rounds of one B32Sched per pair
@@ -3148,6 +3153,12 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
     BEntry *bent = (BEntry *)(work + lay.off_bent);
     double *gpart = (double *)(work + lay.off_gpart);
     int2 *wpairs = (int2 *)(work + lay.off_wpairs);
+    // the activity-driven Gram-only sweeps will run (the same terms as `use_gonly` / `use_dyn` below) -> identity-row skip of the sweep-end product
+    const bool dyn_path = !CPLX && !tpa_svd_force_pairwise && tpa_svd_b32 && !lay.b32_pairs.empty() && tpa_svd_gonly && tpa_svd_predict_convergence &&
+                          lay.ref.enabled && !lay.b32_gup.empty() && tpa_svd_fused_rounds && tpa_svd_dyn && tpa_svd_lookahead && !lay.b32_act.empty() &&
+                          lay.off_sched != 0;
+    const bool rot_skip = dyn_path && tpa_svd_apply_skip && !tpa_svd_direct && lay.n_rot > 0;
+    int *rot = rot_skip ? (int *)(work + lay.off_rot) : nullptr;
     {   // all host-built tables in one copy out of the pinned arena
         const int64_t t0 = lay.off_jobs, tbytes = lay.off_tab_end - lay.off_jobs;
         char *stg = pin_stage().take((size_t)tbytes, st);
@@ -3162,6 +3173,10 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         if (!lay.b32_act.empty()) stage_put(stg, t0, lay.off_act_ents, lay.b32_act);
         if (lay.ref.enabled) {
             stage_put(stg, t0, lay.off_rtasks, lay.ref.tasks);
+            if (rot_skip) {      // the tasks of Qtot [W | G] learn where the "rotated in this sweep" words are (their pad field; the layout is cached, the work area is not)
+                int64_t *tk = reinterpret_cast<int64_t *>(stg + (lay.off_rtasks - t0));
+                for (int64_t t = lay.ref.apply.task0, te = t + 2 * (int64_t)lay.jobs.size(); t < te; ++t) tk[8 * t + 7] = (int64_t)(intptr_t)(work + lay.off_rot);
+            }
             stage_put(stg, t0, lay.off_rlinks, lay.ref.links);
             stage_put(stg, t0, lay.off_rtiles, lay.ref.tiles);
             stage_put(stg, t0, lay.off_rrt, lay.ref.rtiles);
@@ -3334,6 +3349,10 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
         //      without "big" pairs is the last one.  With the floor of the stopping rule on the smaller row two thirds of the block
         //      pairs of a chi = 2048 theta are never active (profiles/r06_stopping_rule_emulation.txt).
         const bool use_dyn = fused && tpa_svd_dyn && tpa_svd_lookahead && !lay.b32_act.empty() && lay.off_sched != 0;
+        if (rot_skip && !use_dyn) {
+            snprintf(tpa_errbuf, sizeof(tpa_errbuf), "tpa_svd_batch: internal error (identity-row skip without the activity-driven rounds)");
+            return TPA_E_BADARG;
+        }
         if (use_dyn) {
             B32Sched *sched_dev = (B32Sched *)(work + lay.off_sched);
             int *act_dev = (int *)(work + lay.off_act);
@@ -3392,13 +3411,14 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
             TPA_HIP_CHECK(hipMemsetAsync(act_dev, 0, (size_t)lay.n_act * 4, st));      // (only the upper triangles of real blocks are ever written)
             TPA_HIP_CHECK(hipMemcpyAsync(sched_dev, sched_stage, (size_t)n_pairs * sizeof(B32Sched), hipMemcpyHostToDevice, st));
             auto sweep_head = [&]() {      // exact Gram matrix, activity of the block pairs, first round: enqueued before the host knows the activity
+                if (rot != nullptr && hipMemsetAsync(rot, 0, (size_t)lay.n_rot * 4, st) != hipSuccess) rc_g = 999;
                 g_begin();
                 b32_activity_kernel<<<n_act_ents, 256, 0, st>>>(jobs, act_ents, sbuf[0], fro2, rho, act_dev);
                 if (hipMemcpyAsync(act_host, act_dev, (size_t)lay.n_act * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipEventRecord(ev_post, st) != hipSuccess)
                     rc_g = 999;
                 svd_b32_solve2_kernel<<<n_pairs, NTS3, 0, st>>>(jobs, b32p, b32g, qb2[0], fb2[0], cnt, fro2, rho, 1, sbuf[0], 0, sched_dev,
-                                                                tpa_svd_dyn_round0 ? act_dev : nullptr);
+                                                                tpa_svd_dyn_round0 ? act_dev : nullptr, rot);
             };
             TPA_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned int), st));
             sweep_head();
@@ -3427,7 +3447,7 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                 for (int r = 1; r < n_r; ++r)
                     svd_b32_round_kernel<<<n_pairs + n_gup, NTS3, 0, st>>>(jobs, b32p, n_pairs, gup, r, sbuf[(r - 1) & 1], sbuf[r & 1], Qm,
                                                                            qb2[(r - 1) & 1], qb2[r & 1], fb2[(r - 1) & 1], fb2[r & 1], cnt, fro2,
-                                                                           rho, 0, sched_dev + (size_t)r * n_pairs, sched_dev + (size_t)(r - 1) * n_pairs);
+                                                                           rho, 0, sched_dev + (size_t)r * n_pairs, sched_dev + (size_t)(r - 1) * n_pairs, rot);
                 {   // the transforms of the last round still have to reach Qtot -- and, direct iteration, S (in place: S_(rl+1) in image rl & 1)
                     const int rl = n_r - 1;
                     if (direct) {
