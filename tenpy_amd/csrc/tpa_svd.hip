@@ -3435,6 +3435,20 @@ int svd_run(const Layout &lay, int n_jobs, const void *a_base, void *u_base, dou
                     converged = true;
                     break;
                 }
+                static const int dbg_act = getenv("TPA_SVD_DEBUG_ACT") ? atoi(getenv("TPA_SVD_DEBUG_ACT")) : 0;      // diagnostic: which jobs keep a call's sweeps alive
+                if (dbg_act) {
+                    std::string line;
+                    for (int b = 0; b < n_jobs_l; ++b) {
+                        const int R = (int)lay.jobs[b].R, NB = (R + BB - 1) / BB, NBp = (NB + 1) / 2 * 2;
+                        int na = 0, nbig = 0;
+                        for (int i = 0; i < NBp * NBp; ++i) {
+                            na += act_host[lay.b32_act_off[b] + i] != 0;
+                            nbig += (act_host[lay.b32_act_off[b] + i] & 2) != 0;
+                        }
+                        if (na) line += " R" + std::to_string(R) + ":" + std::to_string(na) + (nbig ? "b" : "");
+                    }
+                    fprintf(stderr, "svd_act sweep %d jobs %d:%s\n", sweep, n_jobs_l, line.c_str());
+                }
                 int n_r = 1;
                 for (int b = 0; b < n_jobs_l; ++b) {
                     b32_job_rounds((int)lay.jobs[b].R, act_host + lay.b32_act_off[b], max_rounds - 1, job_rounds[b]);
